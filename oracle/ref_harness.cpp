@@ -1,0 +1,277 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product.
+//
+// Harness around the *unmodified* reference library (oracle/_ref/libPolarCode_ref.so,
+// compiled from /root/reference by oracle/Makefile).  It only calls the reference's
+// public API:
+//   PolarCode::Construction::frozen_bits        (constructor.cpp:41-63)
+//   PolarCode::Encoding::ButterflyFipPacked     (butterfly_fip_packed.cpp:45-70)
+//   PolarCode::ErrorDetection::create           (errordetector.cpp:27-88)
+//   PolarCode::Decoding::{SclAvxFloat,FastSscAvxFloat,AdaptiveFloat}::decode_vector
+//                                               (decoder.cpp:154-167)
+// and peeks the final path metrics of SclAvxFloat (scl_avx_float.h: PathList::mMetric).
+//
+// Sub-commands
+//   gen   N K L ctor dsnr crcsize crctype ebn0_db count seed mode dectype out.bin
+//         writes a golden fixture (format below).  A FRESH decoder object is used for every
+//         codeword (the reference carries mMetric[0] over between calls).
+//   time  N K L ctor dsnr crcsize crctype ebn0_db rows threads seconds
+//         the reference's own CPU throughput: one decoder object per std::thread
+//         (simulator.cpp:95-101), prints one JSON line.
+//   frozen N K ctor dsnr          prints the frozen set (one index per line)
+//   crc   size type hexbytes      prints Detector::calculate()/check() for KAT pinning
+//
+// Fixture layout (little endian):
+//   u32 hdr[10] = {0x31584650 'PFX1', N, K, L, nF, count, nb=(K+7)/8, crcsize, crcnr, dectype}
+//   u32 F[nF]
+//   count x { f32 llr[N] | u8 info[nb] | u8 out[nb] | u8 ok | u8 npaths | f32 metrics[L] }
+// mode: awgn | noise | ties | quant      dectype: 0 float, 2 mixed
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <random>
+#include <stack>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <immintrin.h>
+
+#include <polarcode/datapool.txx>
+// every STL header the reference pulls in is already included above, so redefining the
+// access keywords only affects the reference's own class bodies.
+#define class struct
+#define private public
+#define protected public
+#include <polarcode/decoding/adaptive_float.h>
+#include <polarcode/decoding/fastssc_avx_float.h>
+#include <polarcode/decoding/scl_avx_float.h>
+#undef class
+#undef private
+#undef protected
+#include <polarcode/construction/constructor.h>
+#include <polarcode/encoding/butterfly_fip_packed.h>
+#include <polarcode/errordetection/errordetector.h>
+
+using namespace PolarCode;
+
+struct Code {
+    unsigned N, K, L, crcsize;
+    std::string crctype, ctor;
+    float dsnr;
+    int dectype;
+    std::vector<unsigned> F;
+};
+
+static Decoding::Decoder* make_decoder(const Code& c)
+{
+    Decoding::Decoder* d;
+    if (c.dectype == 2)
+        d = new Decoding::AdaptiveFloat(c.N, c.L, c.F);
+    else if (c.L == 1)
+        d = new Decoding::FastSscAvxFloat(c.N, c.F);
+    else
+        d = new Decoding::SclAvxFloat(c.N, c.L, c.F);
+    d->setErrorDetection(ErrorDetection::create(c.crcsize, c.crctype));
+    return d;
+}
+
+struct Gauss {
+    std::mt19937_64 g;
+    explicit Gauss(uint64_t s) : g(s) {}
+    double uni() { return (double)(g() >> 11) * (1.0 / 9007199254740992.0); }
+    double operator()()
+    {
+        double u1 = uni(), u2 = uni();
+        if (u1 < 1e-300) u1 = 1e-300;
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    }
+};
+
+static void make_row(const Code& c, Encoding::ButterflyFipPacked& enc, Gauss& rng,
+                     const std::string& mode, float ebn0_db, std::vector<uint8_t>& info,
+                     std::vector<float>& llr)
+{
+    const unsigned nb = (c.K + 7) / 8;
+    info.assign(std::max(nb, 8u), 0);
+    for (unsigned i = 0; i < nb; ++i) info[i] = (uint8_t)(rng.g() & 0xFF);
+    if (c.K % 8) info[nb - 1] &= (uint8_t)(0xFF << (8 - c.K % 8));
+    std::vector<uint8_t> cw(c.N / 8 + 32, 0);
+    enc.encode_vector(info.data(), cw.data()); // writes the CRC into info[] (encoder.cpp / generate())
+    llr.resize(c.N);
+    const double ebn0 = std::pow(10.0, ebn0_db / 10.0);
+    const double sigma = 1.0 / std::sqrt(2.0 * ebn0 * (double)c.K / (double)c.N);
+    for (unsigned i = 0; i < c.N; ++i) {
+        const int bit = (cw[i / 8] >> (7 - (i % 8))) & 1;
+        const double x = 1.0 - 2.0 * bit;
+        if (mode == "awgn") {
+            llr[i] = (float)(x + sigma * rng());
+        } else if (mode == "noise") {
+            llr[i] = (float)rng();
+        } else if (mode == "ties") {
+            llr[i] = (float)((rng.g() % 16 == 0) ? -x : x);
+        } else { // quant: int8-valued LLRs (many equal magnitudes)
+            double v = std::nearbyint((x + sigma * rng()) * 8.0);
+            v = std::max(-127.0, std::min(127.0, v));
+            llr[i] = (float)v;
+        }
+    }
+}
+
+static int cmd_gen(int argc, char** argv)
+{
+    if (argc < 15) { fprintf(stderr, "gen: bad args\n"); return 2; }
+    Code c;
+    c.N = atoi(argv[2]); c.K = atoi(argv[3]); c.L = atoi(argv[4]); c.ctor = argv[5];
+    c.dsnr = atof(argv[6]); c.crcsize = atoi(argv[7]); c.crctype = argv[8];
+    const float ebn0_db = atof(argv[9]);
+    const unsigned count = atoi(argv[10]);
+    const uint64_t seed = strtoull(argv[11], nullptr, 10);
+    const std::string mode = argv[12];
+    c.dectype = (std::string(argv[13]) == "mixed") ? 2 : 0;
+    const char* out = argv[14];
+    c.F = Construction::frozen_bits(c.N, c.K, c.dsnr, c.ctor);
+    const unsigned nb = (c.K + 7) / 8;
+
+    Encoding::ButterflyFipPacked enc(c.N, c.F);
+    enc.setErrorDetection(ErrorDetection::create(c.crcsize, c.crctype));
+    Gauss rng(seed);
+
+    FILE* f = fopen(out, "wb");
+    if (!f) { perror(out); return 1; }
+    const bool nr = c.crctype.find("nr") != std::string::npos;
+    uint32_t hdr[10] = { 0x31584650u, c.N, c.K, c.L, (uint32_t)c.F.size(), count, nb,
+                         c.crcsize, (uint32_t)nr, (uint32_t)c.dectype };
+    fwrite(hdr, 4, 10, f);
+    fwrite(c.F.data(), 4, c.F.size(), f);
+
+    std::vector<uint8_t> info;
+    std::vector<float> llr;
+    unsigned n_ok = 0, n_match = 0;
+    for (unsigned r = 0; r < count; ++r) {
+        make_row(c, enc, rng, mode, ebn0_db, info, llr);
+        std::unique_ptr<Decoding::Decoder> dec(make_decoder(c)); // fresh: metric starts at 0
+        std::vector<uint8_t> outb(nb + 16, 0);
+        const bool ok = dec->decode_vector(llr.data(), outb.data());
+        std::vector<float> metrics(c.L, 0.0f);
+        uint8_t npaths = 1;
+        Decoding::SclAvxFloat* scl = nullptr;
+        if (c.dectype == 0 && c.L > 1) scl = dynamic_cast<Decoding::SclAvxFloat*>(dec.get());
+        if (scl) {
+            unsigned p = scl->mPathList->mNextPathCount;
+            if (p < 1) p = 1;
+            npaths = (uint8_t)p;
+            for (unsigned i = 0; i < p && i < c.L; ++i) metrics[i] = scl->mPathList->mMetric[i];
+        }
+        const uint8_t okb = ok ? 1 : 0;
+        fwrite(llr.data(), 4, c.N, f);
+        fwrite(info.data(), 1, nb, f);
+        fwrite(outb.data(), 1, nb, f);
+        fwrite(&okb, 1, 1, f);
+        fwrite(&npaths, 1, 1, f);
+        fwrite(metrics.data(), 4, c.L, f);
+        n_ok += ok;
+        n_match += (memcmp(info.data(), outb.data(), nb) == 0);
+    }
+    fclose(f);
+    fprintf(stderr, "%s: N=%u K=%u L=%u |F|=%zu rows=%u ok=%u payload_match=%u\n", out, c.N, c.K,
+            c.L, c.F.size(), count, n_ok, n_match);
+    return 0;
+}
+
+static int cmd_time(int argc, char** argv)
+{
+    if (argc < 13) { fprintf(stderr, "time: bad args\n"); return 2; }
+    Code c;
+    c.N = atoi(argv[2]); c.K = atoi(argv[3]); c.L = atoi(argv[4]); c.ctor = argv[5];
+    c.dsnr = atof(argv[6]); c.crcsize = atoi(argv[7]); c.crctype = argv[8];
+    const float ebn0_db = atof(argv[9]);
+    const unsigned rows = atoi(argv[10]);
+    const unsigned threads = atoi(argv[11]);
+    const double seconds = atof(argv[12]);
+    c.dectype = 0;
+    c.F = Construction::frozen_bits(c.N, c.K, c.dsnr, c.ctor);
+    const unsigned nb = (c.K + 7) / 8;
+    Encoding::ButterflyFipPacked enc(c.N, c.F);
+    enc.setErrorDetection(ErrorDetection::create(c.crcsize, c.crctype));
+    Gauss rng(12345);
+    std::vector<float> all((size_t)rows * c.N);
+    std::vector<uint8_t> info;
+    std::vector<float> llr;
+    for (unsigned r = 0; r < rows; ++r) {
+        make_row(c, enc, rng, "awgn", ebn0_db, info, llr);
+        memcpy(&all[(size_t)r * c.N], llr.data(), 4 * c.N);
+    }
+    std::atomic<uint64_t> total(0);
+    std::atomic<uint64_t> oks(0);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) {
+        pool.emplace_back([&, t]() {
+            std::unique_ptr<Decoding::Decoder> dec(make_decoder(c));
+            std::vector<uint8_t> outb(nb + 16);
+            uint64_t n = 0, ok = 0;
+            for (;;) {
+                for (unsigned r = t; r < rows; r += threads) {
+                    ok += dec->decode_vector(&all[(size_t)r * c.N], outb.data());
+                    ++n;
+                }
+                const double el = std::chrono::duration<double>(
+                                      std::chrono::steady_clock::now() - t0).count();
+                if (el >= seconds) break;
+            }
+            total += n;
+            oks += ok;
+        });
+    }
+    for (auto& th : pool) th.join();
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("{\"kind\": \"reference\", \"N\": %u, \"K\": %u, \"L\": %u, \"threads\": %u, "
+           "\"codewords\": %llu, \"seconds\": %.4f, \"cw_per_s\": %.2f, \"ok_frac\": %.4f}\n",
+           c.N, c.K, c.L, threads, (unsigned long long)total.load(), el, total.load() / el,
+           (double)oks.load() / (double)std::max<uint64_t>(1, total.load()));
+    return 0;
+}
+
+static int cmd_frozen(int argc, char** argv)
+{
+    if (argc < 6) return 2;
+    auto F = Construction::frozen_bits(atoi(argv[2]), atoi(argv[3]), atof(argv[5]), argv[4]);
+    for (auto x : F) printf("%u\n", x);
+    return 0;
+}
+
+static int cmd_crc(int argc, char** argv)
+{
+    if (argc < 5) return 2;
+    std::unique_ptr<ErrorDetection::Detector> d(ErrorDetection::create(atoi(argv[2]), argv[3]));
+    std::string hex = argv[4];
+    std::vector<uint8_t> b(hex.size() / 2 + 16, 0);
+    const unsigned n = hex.size() / 2;
+    for (unsigned i = 0; i < n; ++i) b[i] = (uint8_t)strtoul(hex.substr(2 * i, 2).c_str(), nullptr, 16);
+    const bool chk = d->check(b.data(), (int)n);
+    d->generate(b.data(), (int)n);
+    printf("%s-%u check=%d generated=", d->getType().c_str(), d->getCheckBitCount(), (int)chk);
+    for (unsigned i = 0; i < n; ++i) printf("%02x", b[i]);
+    printf("\n");
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness gen|time|frozen|crc ...\n"); return 2; }
+    const std::string cmd = argv[1];
+    if (cmd == "gen") return cmd_gen(argc, argv);
+    if (cmd == "time") return cmd_time(argc, argv);
+    if (cmd == "frozen") return cmd_frozen(argc, argv);
+    if (cmd == "crc") return cmd_crc(argc, argv);
+    fprintf(stderr, "unknown command %s\n", cmd.c_str());
+    return 2;
+}

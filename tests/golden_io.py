@@ -1,0 +1,78 @@
+"""Loader for the golden fixtures under tests/golden/ (format: oracle/ref_harness.cpp header).
+
+A file may hold several concatenated fixtures (the sweep files do); ``load`` yields one
+``Fixture`` per record.  Fixtures are DATA produced by the unmodified reference library
+(oracle/gen_golden.sh); nothing here reads /root/reference.
+"""
+import glob
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MAGIC = 0x31584650
+
+
+@dataclass
+class Fixture:
+    name: str
+    N: int
+    K: int
+    L: int
+    frozen: np.ndarray      # uint32[nF], ascending
+    crc_size: int
+    crc_nr: bool
+    dectype: str            # "float" | "mixed"
+    llr: np.ndarray         # float32[count, N]
+    info: np.ndarray        # uint8[count, nb]   payload incl. checksum, as encoded
+    out: np.ndarray         # uint8[count, nb]   the reference decoder's output
+    ok: np.ndarray          # uint8[count]
+    npaths: np.ndarray      # uint8[count]
+    metrics: np.ndarray     # float32[count, L]  reference path metrics, best first
+
+    @property
+    def count(self):
+        return self.llr.shape[0]
+
+    @property
+    def crc_type(self):
+        return "crcnr" if self.crc_nr else "crc"
+
+
+def load(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    pos, idx, out = 0, 0, []
+    base = os.path.basename(path)
+    while pos < raw.size:
+        hdr = raw[pos:pos + 40].view(np.uint32)
+        assert hdr[0] == MAGIC, f"bad magic in {path} @ {pos}"
+        _, N, K, L, nF, count, nb, crcsize, crcnr, dectype = (int(x) for x in hdr)
+        pos += 40
+        frozen = raw[pos:pos + 4 * nF].view(np.uint32).copy()
+        pos += 4 * nF
+        rec = 4 * N + nb + nb + 1 + 1 + 4 * L
+        body = raw[pos:pos + rec * count].reshape(count, rec)
+        pos += rec * count
+        o = 0
+        llr = body[:, o:o + 4 * N].copy().view(np.float32).reshape(count, N); o += 4 * N
+        info = body[:, o:o + nb].copy(); o += nb
+        outb = body[:, o:o + nb].copy(); o += nb
+        ok = body[:, o].copy(); o += 1
+        npaths = body[:, o].copy(); o += 1
+        metrics = body[:, o:o + 4 * L].copy().view(np.float32).reshape(count, L)
+        out.append(Fixture(f"{base}#{idx}", N, K, L, frozen, crcsize, bool(crcnr),
+                           "mixed" if dectype == 2 else "float", llr, info, outb, ok, npaths,
+                           metrics))
+        idx += 1
+    return out
+
+
+def all_files(pattern="*.bin"):
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, pattern)))
+
+
+def load_named(name):
+    fx = load(os.path.join(GOLDEN_DIR, name))
+    assert len(fx) == 1
+    return fx[0]
