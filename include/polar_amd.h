@@ -1,0 +1,105 @@
+/*
+ * polar_amd.h -- C ABI of the MI355X-native batched polar SC / SCL decoder.
+ *
+ * Drop-in boundary for the reference's decode path (ant-uni-bremen/polar-codes):
+ *   PolarCode::Decoding::create()            src/polarcode/decoding/decoder.cpp:26-52
+ *   Decoder::setErrorDetection / setSystematic  decoder.cpp:101-111, include/.../decoder.h:120-143
+ *   Decoder::decode_vector(const float*, void*) decoder.cpp:154-167
+ *   Decoder::decode_vector(const char*,  void*) decoder.cpp:169-181
+ *   pypolar.PolarDecoder                      python/bindings/decoder_python.cc:17-75
+ * The reference decodes ONE codeword per call on the CPU; this library decodes B codewords per
+ * call on one GPU (one HIP kernel launch), bit-exact with the reference's float decoders
+ * (FastSscAvxFloat / SclAvxFloat / AdaptiveFloat) started from a fresh decoder state per codeword.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  All functions return 0 (PCD_OK) or a
+ * negative pcd_status; pcd_last_error() gives the message of the calling thread's last failure.
+ * There is NO CPU fallback: decoding without a usable HIP device fails with PCD_ERR_NO_DEVICE.
+ */
+#ifndef POLAR_AMD_H
+#define POLAR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcd_decoder pcd_decoder; /* opaque handle; not thread-safe (like the reference's Decoder) */
+
+typedef enum {
+    PCD_OK = 0,
+    PCD_ERR_INVALID_ARG = -1,   /* bad N / L / frozen set / null pointer                              */
+    PCD_ERR_UNKNOWN_TYPE = -2,  /* reference: std::logic_error("Unknown PolarDecoder type!")          */
+    PCD_ERR_UNSUPPORTED = -3,   /* "char"/"scan" decoders, CMAC / CRC-6 / CRC-16: not on this path     */
+    PCD_ERR_FROZEN_SET = -4,    /* reference: std::invalid_argument from FastSscAvx::createDecoder     */
+    PCD_ERR_CRC_SIZE = -5,      /* reference: std::logic_error("CRC INVALID SIZE!")                    */
+    PCD_ERR_UNKNOWN_DETECTOR = -6, /* reference: std::runtime_error("Unknown Error detector requested!") */
+    PCD_ERR_NO_DEVICE = -7,     /* no HIP device / HIP runtime error: the product path never falls back */
+    PCD_ERR_HIP = -8,
+    PCD_ERR_CAPACITY = -9       /* (N, L) exceeds what the kernels can hold            */
+} pcd_status;
+
+/* memory-space tags for the pointers handed to pcd_decode_* */
+enum { PCD_MEM_HOST = 0, PCD_MEM_DEVICE = 1 };
+
+/* Decoding::create(blockLength, listSize, frozenBits, decoderType)  decoder.cpp:26-52.
+ * type is matched like the reference (lower-cased substring): "float", "mixed"; "char" and "scan"
+ * are recognised but PCD_ERR_UNSUPPORTED.  listSize < 2 with a non-char type selects float SC
+ * (decoder.cpp:48-50).  frozen[] must be strictly ascending (what frozen_bits() returns).
+ * The new decoder carries the CRC-8 detector, as makeDecoder does (decoder.cpp:85).
+ * device: HIP device ordinal used by later decode calls (nothing touches the GPU here). */
+int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, size_t n_frozen,
+               const char* type, int device, pcd_decoder** out);
+void pcd_destroy(pcd_decoder* d);
+
+/* ErrorDetection::create(size, type)  errordetector.cpp:27-88 + Decoder::setErrorDetection.
+ * Supported: type containing "crc" with size 0 (dummy), 8, 11, 24, 32.  */
+int pcd_set_error_detection(pcd_decoder* d, unsigned size, const char* type);
+/* Decoder::setSystematic / isSystematic (default true, decoder.cpp:92) */
+int pcd_set_systematic(pcd_decoder* d, int systematic);
+int pcd_is_systematic(const pcd_decoder* d);
+
+size_t pcd_block_length(const pcd_decoder* d);                 /* Decoder::blockLength()  */
+size_t pcd_info_length(const pcd_decoder* d);                  /* Decoder::infoLength()   */
+size_t pcd_list_size(const pcd_decoder* d);                    /* Decoder::getListSize()  */
+size_t pcd_frozen_bits(const pcd_decoder* d, uint32_t* out, size_t cap); /* Decoder::frozenBits() */
+/* Decoder::getErrorDetectionMode(): "<TYPE>-<bits>", e.g. "CRC-8", "CRCNR-24", "DUMMY-0" */
+int pcd_error_detection_mode(const pcd_decoder* d, char* buf, size_t cap);
+size_t pcd_out_bytes(const pcd_decoder* d);                    /* (K + 7) / 8             */
+
+/* Batched Decoder::decode_vector(const float*, void*).
+ *   llr     : rows x N float32, row-major               (mem = PCD_MEM_HOST | PCD_MEM_DEVICE)
+ *   out     : rows x pcd_out_bytes() decoded bytes       (same memory space as llr)
+ *   ok      : rows x uint8, the detector verdict = decode()'s return value          (nullable)
+ *   metrics : rows x list_size float32 final path metrics, best first (SCL only)    (nullable)
+ *   stream  : hipStream_t (NULL = default stream).  Device pointers: asynchronous on `stream`;
+ *             host pointers: staged through device buffers and synchronised before returning. */
+int pcd_decode_f32(pcd_decoder* d, const float* llr, size_t rows, uint8_t* out, uint8_t* ok,
+                   float* metrics, int mem, void* stream);
+/* Batched Decoder::decode_vector(const char*, void*): int8 LLRs widened to float exactly as
+ * FloatContainer::insertLlr(const char*) does (bitcontainer.cpp:202-207). */
+int pcd_decode_i8(pcd_decoder* d, const int8_t* llr, size_t rows, uint8_t* out, uint8_t* ok,
+                  float* metrics, int mem, void* stream);
+
+/* Introspection of the compiled decode program (host only, no GPU): counts[0] = leaf ops,
+ * counts[1] = inner nodes, for the SC (list=0) or SCL (list=1) program of this decoder. */
+int pcd_program_stats(const pcd_decoder* d, int list, unsigned counts[2]);
+/* LDS bytes per codeword and codewords (waves) per workgroup the launch will use; 0 if n/a */
+int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4]);
+/* Time (ms) the most recent pcd_decode_* kernel(s) took, measured with HIP events on the launch
+ * stream when timing is enabled.  pcd_set_timing(d, 1) adds two event records per call. */
+int pcd_set_timing(pcd_decoder* d, int enable);
+int pcd_last_kernel_ms(pcd_decoder* d, float* ms);
+
+/* Diagnostics: decode ONE row (host float32[N]) with the list decoder and record, after every leaf of
+ * the decode tree, (1 + list_size) floats {live path count, path metrics...} into trace (host). */
+int pcd_scl_trace(pcd_decoder* d, const float* llr_row, float* trace, unsigned cap);
+
+const char* pcd_last_error(void);
+const char* pcd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLAR_AMD_H */

@@ -352,7 +352,18 @@ typedef struct {
     float* tmp;
     unsigned* tmpi;
     int leaves, inner;
+    float* trace; /* optional: after every leaf (1 + L) floats: path count, metrics */
+    int trace_cap, trace_n;
 } po_scl;
+
+static void scl_trace(po_scl* d)
+{
+    if (!d->trace || d->trace_n >= d->trace_cap) return;
+    float* t = d->trace + (size_t)d->trace_n * (1 + d->L);
+    t[0] = (float)d->n_paths;
+    for (unsigned p = 0; p < d->L; ++p) t[1 + p] = p < d->n_paths ? d->cur[p].metric : 0.0f;
+    d->trace_n++;
+}
 
 /* findWeakLlrs  include/polarcode/arrayfuncs.h:209-231 (swap-mutating selection, strict '<') */
 static void find_weak(unsigned* idx, float* val, unsigned size, unsigned n)
@@ -439,6 +450,7 @@ static void scl_node(po_scl* d, const uint32_t* F, unsigned c, unsigned n, unsig
             for (unsigned k = 0; k < d->nflips[src]; ++k) d->nxt[j].bit[o + d->flips[src][k]] ^= 1;
         }
         switch_to_next(d, np);
+        scl_trace(d);
         return;
     }
     if (c == n) { /* RateZeroDecoder::decode :316-337 */
@@ -450,6 +462,7 @@ static void scl_node(po_scl* d, const uint32_t* F, unsigned c, unsigned n, unsig
             }
             d->cur[p].metric = d->cur[p].metric + lanesum(d->tmp, n);
         }
+        scl_trace(d);
         return;
     }
     if (c == n - 1 && n < 8) { /* RepetitionDecoder::decode :428-481 */
@@ -477,6 +490,7 @@ static void scl_node(po_scl* d, const uint32_t* F, unsigned c, unsigned n, unsig
             memset(d->nxt[j].bit + o, (int)sb(d->rep_result[src]), n);
         }
         switch_to_next(d, np);
+        scl_trace(d);
         return;
     }
     if (c == 1) { /* SpcDecoder::decode :498-621 */
@@ -542,6 +556,7 @@ static void scl_node(po_scl* d, const uint32_t* F, unsigned c, unsigned n, unsig
             for (unsigned k = 0; k < d->nflips[src]; ++k) d->nxt[j].bit[o + d->flips[src][k]] ^= 1;
         }
         switch_to_next(d, np);
+        scl_trace(d);
         return;
     }
 
@@ -649,6 +664,18 @@ int po_scl_decode_paths(unsigned N, unsigned L, const uint32_t* frozen, unsigned
     }
     scl_free(d);
     return P;
+}
+
+int po_scl_trace(unsigned N, unsigned L, const uint32_t* frozen, unsigned nF, const float* llr,
+                 float* trace, int cap)
+{
+    po_scl* d = scl_new(N, L);
+    d->trace = trace;
+    d->trace_cap = cap;
+    scl_run(d, frozen, nF, llr);
+    const int n = d->trace_n;
+    scl_free(d);
+    return n;
 }
 
 int po_tree_stats(unsigned N, const uint32_t* frozen, unsigned nF, int list, unsigned counts[2])

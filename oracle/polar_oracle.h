@@ -49,6 +49,11 @@ int po_sc_decode_bits(unsigned N, const uint32_t* frozen, unsigned nF, const flo
 int po_scl_decode_paths(unsigned N, unsigned L, const uint32_t* frozen, unsigned nF,
                         const float* llr, uint8_t* bits_out, float* metrics);
 
+/* debugging aid: after every leaf of the SCL tree, (1 + L) floats {path count, metrics...};
+ * returns the number of leaves recorded (<= cap). */
+int po_scl_trace(unsigned N, unsigned L, const uint32_t* frozen, unsigned nF, const float* llr,
+                 float* trace, int cap);
+
 /* Decoder::decode_vector for type "float" (L==1 -> Fast-SSC, else Fast-SSCL) and "mixed"
  * (adaptive_float.cpp:33-45).  dectype: 0 float, 2 mixed.  out: (K+7)/8 bytes per row,
  * ok: 1 byte per row, metrics (nullable): L floats per row (best first, 0 padded),

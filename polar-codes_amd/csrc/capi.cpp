@@ -1,0 +1,536 @@
+// C ABI of the MI355X polar decoder (include/polar_amd.h).  Host logic only: argument checking in
+// the reference's terms, decode-program compilation, device table upload, launch geometry.
+#include "../../include/polar_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "program.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+unsigned ilog2(size_t n)
+{
+    unsigned s = 0;
+    while (((size_t)1 << s) < n) ++s;
+    return s;
+}
+
+constexpr size_t kMaxLds = 160 * 1024;  // LDS per CU on gfx950 (a single workgroup may use all of it)
+
+}  // namespace
+
+struct pcd_decoder {
+    unsigned N = 0, logN = 0, L = 1, K = 0, nb = 0;
+    int device = 0;
+    int dectype = 1;  // 1 float, 2 mixed
+    bool systematic = true;
+    std::vector<uint32_t> frozen;
+    pamd::Detector det;
+    pamd::Program sc_prog, scl_prog;
+    bool has_sc = false, has_scl = false;
+
+    // launch geometry
+    unsigned sc_wave_words = 0, sc_wpb = 4;
+    int lpl = 3;
+    unsigned lmax = 8, path_stride = 0, wpp = 0, scl_wave_words = 0, scl_wpb = 1;
+
+    // device state (created lazily by the first decode call)
+    bool dev_ready = false, det_dirty = true;
+    int num_cu = 0;
+    pamd::Ins* d_sc_prog = nullptr;
+    pamd::Ins* d_scl_prog = nullptr;
+    uint16_t* d_lut = nullptr;
+    uint32_t* d_syn = nullptr;
+    // staging for host-pointer calls and the mixed decoder
+    void* d_in = nullptr;
+    size_t d_in_cap = 0;
+    uint8_t* d_out = nullptr;
+    size_t d_out_cap = 0;
+    uint8_t* d_ok = nullptr;
+    size_t d_ok_cap = 0;
+    float* d_met = nullptr;
+    size_t d_met_cap = 0;
+    uint32_t* d_list = nullptr;
+    size_t d_list_cap = 0;
+    uint32_t* d_count = nullptr;
+    int sc_blocks_per_cu = 0, scl_blocks_per_cu = 0;
+
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(PCD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+template <typename T>
+int grow(T*& p, size_t& cap, size_t bytes)
+{
+    if (bytes <= cap && p) return PCD_OK;
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), bytes ? bytes : 1));
+    cap = bytes;
+    return PCD_OK;
+}
+
+void compute_geometry(pcd_decoder* d)
+{
+    const unsigned N = d->N;
+    const unsigned bitw = N >= 32 ? N / 32 : 1;
+    d->sc_wave_words = (2 * N + bitw + 3) & ~3u;
+    unsigned wpb = 4;
+    while (wpb > 1 && (size_t)wpb * d->sc_wave_words * 4 > kMaxLds / 2) wpb >>= 1;
+    d->sc_wpb = wpb;
+    if (d->L > 1) {
+        unsigned lmax = 2;
+        while (lmax < d->L) lmax <<= 1;
+        d->lmax = lmax;
+        d->lpl = 6 - (int)ilog2(lmax);
+        const unsigned LP = 64 / lmax;
+        d->path_stride = N + (LP < 32 ? LP : 0);
+        const unsigned woffN = d->logN <= 5 ? d->logN : ((1u << (d->logN - 5)) + 4u);
+        d->wpp = (woffN + bitw) | 1u;
+        d->scl_wave_words = (lmax * d->path_stride + 2 * lmax * d->wpp + 3) & ~3u;
+        d->scl_wpb = 1;
+    }
+}
+
+int ensure_device(pcd_decoder* d)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(PCD_ERR_NO_DEVICE,
+                    "no HIP device available: the decoder runs on the GPU only (there is no CPU fallback)");
+    if (d->device < 0 || d->device >= count) return fail(PCD_ERR_NO_DEVICE, "invalid HIP device ordinal");
+    HIP_TRY(hipSetDevice(d->device));
+    if (!d->dev_ready) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+        d->num_cu = prop.multiProcessorCount;
+        if (d->has_sc) {
+            const size_t b = d->sc_prog.ins.size() * sizeof(pamd::Ins);
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_sc_prog), b));
+            HIP_TRY(hipMemcpy(d->d_sc_prog, d->sc_prog.ins.data(), b, hipMemcpyHostToDevice));
+        }
+        if (d->has_scl) {
+            const size_t b = d->scl_prog.ins.size() * sizeof(pamd::Ins);
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_scl_prog), b));
+            HIP_TRY(hipMemcpy(d->d_scl_prog, d->scl_prog.ins.data(), b, hipMemcpyHostToDevice));
+        }
+        // information-bit LUT (BitContainer::calculateLUT bitcontainer.cpp:68-84)
+        std::vector<uint16_t> lut;
+        lut.reserve(d->K);
+        size_t fc = 0;
+        for (unsigned i = 0; i < d->N; ++i) {
+            if (fc < d->frozen.size() && d->frozen[fc] == i) {
+                ++fc;
+                continue;
+            }
+            lut.push_back((uint16_t)i);
+        }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_lut), std::max<size_t>(2, lut.size() * 2)));
+        if (!lut.empty()) HIP_TRY(hipMemcpy(d->d_lut, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_syn), std::max<size_t>(4, (size_t)d->K * 4)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_count), 4));
+        HIP_TRY(hipEventCreate(&d->ev0));
+        HIP_TRY(hipEventCreate(&d->ev1));
+        d->dev_ready = true;
+        d->det_dirty = true;
+    }
+    if (d->det_dirty) {
+        const std::vector<uint32_t> syn = d->det.syndrome_table(d->K);
+        if (!syn.empty()) HIP_TRY(hipMemcpy(d->d_syn, syn.data(), syn.size() * 4, hipMemcpyHostToDevice));
+        d->det_dirty = false;
+    }
+    return PCD_OK;
+}
+
+pamd::DecodeParams base_params(const pcd_decoder* d, const void* llr, size_t rows, uint8_t* out, uint8_t* ok,
+                               float* metrics)
+{
+    pamd::DecodeParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.llr = llr;
+    P.rowidx = nullptr;
+    P.rows = (uint32_t)rows;
+    P.N = d->N;
+    P.logN = d->logN;
+    P.K = d->K;
+    P.nb = d->nb;
+    P.L = d->L;
+    P.lut = d->d_lut;
+    P.syn = d->d_syn;
+    P.out = out;
+    P.ok = ok;
+    P.metrics = metrics;
+    P.det_on = d->det.size != 0;
+    P.systematic = d->systematic ? 1u : 0u;
+    return P;
+}
+
+int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
+{
+    P.prog = d->d_sc_prog;
+    P.wave_lds_words = d->sc_wave_words;
+    P.metrics = nullptr;
+    const size_t lds = (size_t)d->sc_wpb * d->sc_wave_words * 4;
+    if (d->sc_blocks_per_cu == 0) {
+        const size_t by_lds = kMaxLds / lds;
+        const size_t by_waves = 32 / d->sc_wpb;
+        d->sc_blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(by_lds, std::min<size_t>(by_waves, 16)));
+    }
+    const unsigned need = (unsigned)((P.rows + d->sc_wpb - 1) / d->sc_wpb);
+    const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->sc_blocks_per_cu)));
+    HIP_TRY(pamd::launch_sc(P, i8, grid, d->sc_wpb, lds, st));
+    return PCD_OK;
+}
+
+int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
+{
+    P.prog = d->d_scl_prog;
+    P.wave_lds_words = d->scl_wave_words;
+    P.path_stride = d->path_stride;
+    P.wpp = d->wpp;
+    const size_t lds = (size_t)d->scl_wpb * d->scl_wave_words * 4;
+    if (d->scl_blocks_per_cu == 0) {
+        const size_t by_lds = kMaxLds / lds;
+        const size_t by_waves = 32 / d->scl_wpb;
+        d->scl_blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(by_lds, std::min<size_t>(by_waves, 16)));
+    }
+    const unsigned need = (unsigned)((P.rows + d->scl_wpb - 1) / d->scl_wpb);
+    const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->scl_blocks_per_cu)));
+    HIP_TRY(pamd::launch_scl(P, d->lpl, i8, grid, d->scl_wpb, lds, st));
+    return PCD_OK;
+}
+
+// all pointers are device pointers here
+int decode_device(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t* out, uint8_t* ok,
+                  float* metrics, hipStream_t st)
+{
+    if (rows == 0) return PCD_OK;
+    if (rows > 0xFFFFFFFFull) return fail(PCD_ERR_INVALID_ARG, "rows must fit in 32 bits");
+    int rc;
+    if (d->timing) HIP_TRY(hipEventRecord(d->ev0, st));
+    if (d->L <= 1) {
+        if (metrics) HIP_TRY(hipMemsetAsync(metrics, 0, rows * sizeof(float), st));
+        if ((rc = run_sc(d, base_params(d, llr, rows, out, ok, nullptr), i8, st))) return rc;
+    } else if (d->dectype == 2) {
+        // AdaptiveFloat::decode adaptive_float.cpp:33-45: SC for every row, SCL only where the
+        // detector rejected the SC result
+        uint8_t* okbuf = ok;
+        if (!okbuf) {
+            if ((rc = grow(d->d_ok, d->d_ok_cap, rows))) return rc;
+            okbuf = d->d_ok;
+        }
+        if (metrics) HIP_TRY(hipMemsetAsync(metrics, 0, rows * d->L * sizeof(float), st));
+        if ((rc = run_sc(d, base_params(d, llr, rows, out, okbuf, nullptr), i8, st))) return rc;
+        if ((rc = grow(d->d_list, d->d_list_cap, rows * 4))) return rc;
+        HIP_TRY(hipMemsetAsync(d->d_count, 0, 4, st));
+        HIP_TRY(pamd::launch_collect_failed(okbuf, (uint32_t)rows, d->d_list, d->d_count, st));
+        uint32_t nfail = 0;
+        HIP_TRY(hipMemcpyAsync(&nfail, d->d_count, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (nfail) {
+            pamd::DecodeParams P = base_params(d, llr, nfail, out, okbuf, metrics);
+            P.rowidx = d->d_list;
+            if ((rc = run_scl(d, P, i8, st))) return rc;
+        }
+    } else {
+        if ((rc = run_scl(d, base_params(d, llr, rows, out, ok, metrics), i8, st))) return rc;
+    }
+    if (d->timing) {
+        HIP_TRY(hipEventRecord(d->ev1, st));
+        d->ev_valid = true;
+    }
+    return PCD_OK;
+}
+
+int decode_any(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t* out, uint8_t* ok, float* metrics,
+               int mem, void* stream)
+{
+    if (!d) return fail(PCD_ERR_INVALID_ARG, "null decoder");
+    if (rows && (!llr || !out)) return fail(PCD_ERR_INVALID_ARG, "null llr/out pointer");
+    if (d->det.size != 0 && d->nb < d->det.check_bytes())
+        return fail(PCD_ERR_INVALID_ARG, "information word shorter than the detector's checksum field");
+    if (d->det.size == 32 && d->nb < 4) return fail(PCD_ERR_INVALID_ARG, "CRC-32 needs at least 4 output bytes");
+    int rc = ensure_device(d);
+    if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (mem == PCD_MEM_DEVICE) return decode_device(d, llr, i8, rows, out, ok, metrics, st);
+    if (mem != PCD_MEM_HOST) return fail(PCD_ERR_INVALID_ARG, "mem must be PCD_MEM_HOST or PCD_MEM_DEVICE");
+    // host pointers: stage through device buffers, synchronous
+    const size_t esz = i8 ? 1 : 4;
+    const size_t in_bytes = rows * d->N * esz, out_bytes = rows * d->nb;
+    if ((rc = grow(d->d_in, d->d_in_cap, in_bytes))) return rc;
+    if ((rc = grow(d->d_out, d->d_out_cap, out_bytes))) return rc;
+    if ((rc = grow(d->d_ok, d->d_ok_cap, rows))) return rc;
+    float* dmet = nullptr;
+    if (metrics) {
+        if ((rc = grow(d->d_met, d->d_met_cap, rows * std::max(1u, d->L) * sizeof(float)))) return rc;
+        dmet = d->d_met;
+    }
+    HIP_TRY(hipMemcpyAsync(d->d_in, llr, in_bytes, hipMemcpyHostToDevice, st));
+    // the mixed path may use d_ok as its own scratch, so hand it a distinct verdict buffer
+    if ((rc = decode_device(d, d->d_in, i8, rows, d->d_out, d->d_ok, dmet, st))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d->d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    if (ok) HIP_TRY(hipMemcpyAsync(ok, d->d_ok, rows, hipMemcpyDeviceToHost, st));
+    if (metrics) HIP_TRY(hipMemcpyAsync(metrics, dmet, rows * std::max(1u, d->L) * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PCD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, size_t n_frozen, const char* type,
+               int device, pcd_decoder** out)
+{
+    if (!out) return fail(PCD_ERR_INVALID_ARG, "null output handle");
+    *out = nullptr;
+    if (!type) return fail(PCD_ERR_INVALID_ARG, "null decoder type");
+    // Decoding::create decoder.cpp:26-52
+    std::string t = type;
+    std::transform(t.begin(), t.end(), t.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+    int flag;
+    if (t.find("char") != std::string::npos)
+        flag = 0;
+    else if (t.find("float") != std::string::npos)
+        flag = 1;
+    else if (t.find("mixed") != std::string::npos)
+        flag = 2;
+    else if (t.find("scan") != std::string::npos)
+        flag = 3;
+    else
+        return fail(PCD_ERR_UNKNOWN_TYPE, "Unknown PolarDecoder type!");
+    if (list_size < 2 && flag != 0) flag = 1;
+    if (flag == 0)
+        return fail(PCD_ERR_UNSUPPORTED,
+                    "the int8 fixed-point (\"char\") decoders are not on the accelerated path; use \"float\" or \"mixed\"");
+    if (flag == 3) return fail(PCD_ERR_UNSUPPORTED, "the SCAN decoder is not on the accelerated path");
+
+    const size_t N = block_length;
+    if (N < 8 || (N & (N - 1)) != 0 || N > 32768)
+        return fail(PCD_ERR_INVALID_ARG, "blockLength must be a power of two in [8, 32768]");
+    if (list_size == 0) return fail(PCD_ERR_INVALID_ARG, "listSize must be >= 1");
+    if (list_size > 32) return fail(PCD_ERR_CAPACITY, "listSize > 32 does not fit one wavefront per codeword");
+    if (n_frozen > N) return fail(PCD_ERR_INVALID_ARG, "more frozen positions than code bits");
+    if (n_frozen && !frozen) return fail(PCD_ERR_INVALID_ARG, "null frozen set");
+    for (size_t i = 0; i < n_frozen; ++i) {
+        if (frozen[i] >= N) return fail(PCD_ERR_INVALID_ARG, "frozen position out of range");
+        if (i && frozen[i] <= frozen[i - 1])
+            return fail(PCD_ERR_INVALID_ARG, "frozen positions must be strictly ascending");
+    }
+
+    pcd_decoder* d = new pcd_decoder();
+    d->N = (unsigned)N;
+    d->logN = ilog2(N);
+    d->L = (unsigned)list_size;
+    d->K = (unsigned)(N - n_frozen);
+    d->nb = (d->K + 7) / 8;
+    d->device = device;
+    d->dectype = flag;
+    d->frozen.assign(frozen, frozen + n_frozen);
+    d->det.size = 8;  // makeDecoder: dec->setErrorDetection(new CRC8()) decoder.cpp:85
+    d->det.nr = false;
+
+    if (d->L == 1 || d->dectype == 2) {
+        const std::string e = pamd::compile_sc(d->N, d->frozen, d->sc_prog);
+        if (!e.empty()) {
+            delete d;
+            return fail(PCD_ERR_FROZEN_SET, e);
+        }
+        d->has_sc = true;
+    }
+    if (d->L > 1) {
+        pamd::compile_scl(d->N, d->frozen, d->scl_prog);
+        d->has_scl = true;
+    }
+    compute_geometry(d);
+    if ((size_t)d->sc_wave_words * 4 > kMaxLds && d->has_sc) {
+        delete d;
+        return fail(PCD_ERR_CAPACITY, "block length too large for the SC kernel's LDS layout");
+    }
+    if (d->has_scl) {
+        const unsigned fb = ilog2(d->lmax);
+        if (d->logN * fb > 64 || (size_t)d->scl_wave_words * 4 > kMaxLds) {
+            delete d;
+            return fail(PCD_ERR_CAPACITY,
+                        "(blockLength, listSize) does not fit the SCL kernel: needs " +
+                            std::to_string((size_t)d->scl_wave_words * 4) + " B of LDS per codeword (max 163840)");
+        }
+    }
+    *out = d;
+    return PCD_OK;
+}
+
+void pcd_destroy(pcd_decoder* d)
+{
+    if (!d) return;
+    if (d->dev_ready) {
+        (void)hipSetDevice(d->device);
+        (void)hipFree(d->d_sc_prog);
+        (void)hipFree(d->d_scl_prog);
+        (void)hipFree(d->d_lut);
+        (void)hipFree(d->d_syn);
+        (void)hipFree(d->d_count);
+        if (d->ev0) (void)hipEventDestroy(d->ev0);
+        if (d->ev1) (void)hipEventDestroy(d->ev1);
+    }
+    if (d->d_in) (void)hipFree(d->d_in);
+    if (d->d_out) (void)hipFree(d->d_out);
+    if (d->d_ok) (void)hipFree(d->d_ok);
+    if (d->d_met) (void)hipFree(d->d_met);
+    if (d->d_list) (void)hipFree(d->d_list);
+    delete d;
+}
+
+int pcd_set_error_detection(pcd_decoder* d, unsigned size, const char* type)
+{
+    if (!d || !type) return fail(PCD_ERR_INVALID_ARG, "null argument");
+    pamd::Detector det;
+    std::string err;
+    const int rc = pamd::make_detector(size, type, det, err);
+    if (rc) return fail(rc, err);
+    d->det = det;
+    d->det_dirty = true;
+    return PCD_OK;
+}
+
+int pcd_set_systematic(pcd_decoder* d, int systematic)
+{
+    if (!d) return fail(PCD_ERR_INVALID_ARG, "null decoder");
+    d->systematic = systematic != 0;
+    return PCD_OK;
+}
+
+int pcd_is_systematic(const pcd_decoder* d) { return d && d->systematic; }
+size_t pcd_block_length(const pcd_decoder* d) { return d ? d->N : 0; }
+size_t pcd_info_length(const pcd_decoder* d) { return d ? d->K : 0; }
+size_t pcd_list_size(const pcd_decoder* d) { return d ? d->L : 0; }
+size_t pcd_out_bytes(const pcd_decoder* d) { return d ? d->nb : 0; }
+
+size_t pcd_frozen_bits(const pcd_decoder* d, uint32_t* out, size_t cap)
+{
+    if (!d) return 0;
+    if (out) std::memcpy(out, d->frozen.data(), std::min(cap, d->frozen.size()) * sizeof(uint32_t));
+    return d->frozen.size();
+}
+
+int pcd_error_detection_mode(const pcd_decoder* d, char* buf, size_t cap)
+{
+    if (!d || !buf || !cap) return fail(PCD_ERR_INVALID_ARG, "null argument");
+    std::snprintf(buf, cap, "%s-%u", d->det.type_name().c_str(), d->det.size);
+    return PCD_OK;
+}
+
+int pcd_decode_f32(pcd_decoder* d, const float* llr, size_t rows, uint8_t* out, uint8_t* ok, float* metrics,
+                   int mem, void* stream)
+{
+    return decode_any(d, llr, false, rows, out, ok, metrics, mem, stream);
+}
+
+int pcd_decode_i8(pcd_decoder* d, const int8_t* llr, size_t rows, uint8_t* out, uint8_t* ok, float* metrics,
+                  int mem, void* stream)
+{
+    return decode_any(d, llr, true, rows, out, ok, metrics, mem, stream);
+}
+
+int pcd_program_stats(const pcd_decoder* d, int list, unsigned counts[2])
+{
+    if (!d || !counts) return fail(PCD_ERR_INVALID_ARG, "null argument");
+    const pamd::Program* p = list ? (d->has_scl ? &d->scl_prog : nullptr) : (d->has_sc ? &d->sc_prog : nullptr);
+    if (!p) return fail(PCD_ERR_INVALID_ARG, "this decoder has no such program");
+    counts[0] = p->leaves;
+    counts[1] = p->inner;
+    return PCD_OK;
+}
+
+int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4])
+{
+    if (!d || !info) return fail(PCD_ERR_INVALID_ARG, "null argument");
+    if (list) {
+        if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SCL program");
+        info[0] = d->scl_wave_words * 4;
+        info[1] = d->scl_wpb;
+        info[2] = 64u >> d->lpl;
+        info[3] = (unsigned)(kMaxLds / ((size_t)d->scl_wpb * d->scl_wave_words * 4));
+    } else {
+        if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
+        info[0] = d->sc_wave_words * 4;
+        info[1] = d->sc_wpb;
+        info[2] = 1;
+        info[3] = (unsigned)(kMaxLds / ((size_t)d->sc_wpb * d->sc_wave_words * 4));
+    }
+    return PCD_OK;
+}
+
+int pcd_set_timing(pcd_decoder* d, int enable)
+{
+    if (!d) return fail(PCD_ERR_INVALID_ARG, "null decoder");
+    d->timing = enable != 0;
+    return PCD_OK;
+}
+
+int pcd_last_kernel_ms(pcd_decoder* d, float* ms)
+{
+    if (!d || !ms) return fail(PCD_ERR_INVALID_ARG, "null argument");
+    if (!d->ev_valid) return fail(PCD_ERR_INVALID_ARG, "no timed decode call yet (pcd_set_timing)");
+    HIP_TRY(hipEventSynchronize(d->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, d->ev0, d->ev1));
+    return PCD_OK;
+}
+
+int pcd_scl_trace(pcd_decoder* d, const float* llr_row, float* trace, unsigned cap)
+{
+    if (!d || !llr_row || !trace) return fail(PCD_ERR_INVALID_ARG, "null argument");
+    if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "not a list decoder");
+    int rc = ensure_device(d);
+    if (rc) return rc;
+    float* dtrace = nullptr;
+    const size_t tb = (size_t)cap * (1 + d->L) * sizeof(float);
+    if ((rc = grow(d->d_in, d->d_in_cap, (size_t)d->N * 4))) return rc;
+    if ((rc = grow(d->d_out, d->d_out_cap, d->nb))) return rc;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dtrace), tb));
+    HIP_TRY(hipMemset(dtrace, 0, tb));
+    HIP_TRY(hipMemcpy(d->d_in, llr_row, (size_t)d->N * 4, hipMemcpyHostToDevice));
+    pamd::DecodeParams P = base_params(d, d->d_in, 1, d->d_out, nullptr, nullptr);
+    P.trace = dtrace;
+    P.trace_cap = cap;
+    rc = run_scl(d, P, false, nullptr);
+    if (!rc) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(trace, dtrace, tb, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dtrace);
+    return rc;
+}
+
+const char* pcd_last_error(void) { return g_err.c_str(); }
+const char* pcd_version(void) { return "polar_amd 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// Kernel parameter block and launchers shared by kernels.hip (device) and capi.cpp (host).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "program.h"
+
+namespace pamd {
+
+struct DecodeParams {
+    const void* llr;         // rows x N  float32 (or int8) channel LLRs, row-major, device memory
+    const uint32_t* rowidx;  // nullable: decode rows rowidx[0..rows) of the batch ("mixed" second pass)
+    uint32_t rows;
+    uint32_t N, logN, K, nb, L;
+    const Ins* prog;         // decode program (device)
+    const uint16_t* lut;     // K code-bit positions of the information bits, ascending
+    const uint32_t* syn;     // K detector syndrome words
+    uint8_t* out;            // rows x nb
+    uint8_t* ok;             // rows (nullable)
+    float* metrics;          // rows x L (nullable)
+    uint32_t det_on;         // 0 = dummy detector (always passes)
+    uint32_t systematic;
+    uint32_t path_stride;    // SCL: floats per path LLR buffer (N + bank padding)
+    uint32_t wpp;            // SCL: bit words per path and area (padded odd)
+    uint32_t wave_lds_words; // LDS words one wave (one codeword) owns
+    float* trace;            // diagnostics (nullable): row 0 only, (1 + L) floats after every SCL leaf
+    uint32_t trace_cap;
+};
+
+hipError_t launch_sc(const DecodeParams& P, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,
+                     hipStream_t st);
+hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, unsigned waves_per_block,
+                      size_t lds, hipStream_t st);
+hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,
+                                 hipStream_t st);
+
+}  // namespace pamd

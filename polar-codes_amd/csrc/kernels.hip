@@ -1,0 +1,1254 @@
+// Batched polar decoders for MI355X (gfx950, wave64).  One wavefront decodes one codeword:
+// every wave interprets the same flat decode program (program.h), so control flow is uniform
+// across the batch and there is no inter-wave synchronisation at all (no __syncthreads).
+//
+//   sc_decode_kernel   Fast-SSC  (reference: src/polarcode/decoding/fastssc_avx_float.cpp)
+//                      64 lanes work on one codeword; LLR stage buffers + packed partial sums in LDS.
+//   scl_decode_kernel  Fast-SSCL (reference: src/polarcode/decoding/scl_avx_float.cpp)
+//                      the wave is split into L' = 64/LP path groups of LP lanes (LP = 8 at L = 8,
+//                      the AVX width of the reference, so its summation order falls out naturally);
+//                      per-path LLR stage buffers in LDS, partial sums bit-packed, the reference's
+//                      DataPool lazy copy replaced by one 64-bit "slot word" per path that is moved
+//                      with a single cross-lane shuffle at every fork.
+//
+// Bit-exactness notes: f is exact; g is one fp32 add; the metric sums follow the
+// reference's "8 strided accumulators, then x0+..+x7" order; every selection reproduces the
+// reference's swap-mutating selection sorts (arrayfuncs.h:161-231) including their tie behaviour.
+// Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace pamd {
+
+#define WAVE_SYNC()                                            \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t sgn(float x) { return __float_as_uint(x) >> 31; }
+__device__ __forceinline__ float absf(float x) { return __uint_as_float(__float_as_uint(x) & 0x7FFFFFFFu); }
+
+// _mm256_polarf_ps avx_float.h:55-63 : sign = xor of signs, magnitude = min of magnitudes
+__device__ __forceinline__ float polar_f(float a, float b)
+{
+    const uint32_t ua = fbits(a), ub = fbits(b);
+    const uint32_t ma = ua & 0x7FFFFFFFu, mb = ub & 0x7FFFFFFFu;
+    const uint32_t m = ma < mb ? ma : mb;  // magnitudes of non-NaN floats order like their bits
+    return bitsf(((ua ^ ub) & 0x80000000u) | m);
+}
+// _mm256_polarg_ps avx_float.h:71-81 : (a ^ sign(u)) + b
+__device__ __forceinline__ float polar_g(float a, float b, uint32_t u)
+{
+    return bitsf(fbits(a) ^ (u << 31)) + b;
+}
+// _mm256_min_ps(x, 0) / _mm256_max_ps(x, 0): second operand on ties
+__device__ __forceinline__ float min0(float x) { return x < 0.0f ? x : 0.0f; }
+__device__ __forceinline__ float max0(float x) { return x > 0.0f ? x : 0.0f; }
+
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+
+__device__ __forceinline__ uint32_t shfl_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+__device__ __forceinline__ float shfl_f32(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
+{
+    const uint32_t lo = shfl_u32((uint32_t)v, src), hi = shfl_u32((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t shflx_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+__device__ __forceinline__ float shflx_f32(float v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ uint64_t shflx_u64(uint64_t v, int m)
+{
+    const uint32_t lo = shflx_u32((uint32_t)v, m), hi = shflx_u32((uint32_t)(v >> 32), m);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v ^= shflx_u32(v, m);
+    return v;
+}
+
+// _mm256_spc_right4_ps avx_float.h:289-302 on four wave-uniform values: returns the 4 output signs
+__device__ __forceinline__ uint32_t spc4_signs(const float in[4])
+{
+    float m = absf(in[0]);
+    uint32_t p = 0, out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = absf(in[i]);
+        m = a < m ? a : m;
+        p ^= sgn(in[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t flip = (p && absf(in[i]) == m) ? 1u : 0u;
+        out |= (sgn(in[i]) ^ flip) << i;
+    }
+    return out;
+}
+
+// =============================================================================================
+//  Fast-SSC
+// =============================================================================================
+// LDS per wave: llr[2N] floats (stage s at offset 1<<s; the channel row is stage logN at offset N)
+//               bits[max(1, N/32)] words, code bit i = word i>>5, bit i&31.
+
+// store `cnt` (<= 64) bits of `m` at code-bit offset `off` (off is a multiple of cnt when cnt < 32)
+__device__ __forceinline__ void sc_put_bits(uint32_t* bits, uint32_t off, uint32_t cnt, uint64_t m, int lane)
+{
+    if (cnt >= 64) {
+        if (lane < 2) bits[(off >> 5) + lane] = (uint32_t)(m >> (32 * lane));
+    } else if (cnt == 32) {
+        if (lane == 0) bits[off >> 5] = (uint32_t)m;
+    } else {
+        if (lane == 0) {
+            const uint32_t sh = off & 31u, mask = ((1u << cnt) - 1u) << sh;
+            const uint32_t w = bits[off >> 5];
+            bits[off >> 5] = (w & ~mask) | (((uint32_t)m << sh) & mask);
+        }
+    }
+}
+__device__ __forceinline__ void sc_flip_bit(uint32_t* bits, uint32_t pos, int lane)
+{
+    if (lane == 0) bits[pos >> 5] ^= 1u << (pos & 31u);
+}
+// fill n bits at off with a repeating 32-bit pattern (pattern period divides 32 and n)
+__device__ __forceinline__ void sc_fill_pattern(uint32_t* bits, uint32_t off, uint32_t n, uint32_t pat, int lane)
+{
+    if (n >= 32) {
+        for (uint32_t w = lane; w < (n >> 5); w += 64) bits[(off >> 5) + w] = pat;
+    } else {
+        sc_put_bits(bits, off, n, pat & ((1u << n) - 1u), lane);
+    }
+}
+
+// the reference's fold8 (8 strided AVX accumulators, acc = 0; acc += x[8k+v]); result broadcast
+__device__ __forceinline__ void sc_fold8(const float* x, uint32_t n, int lane, float a[8])
+{
+    float acc = 0.0f;
+    if (lane < 8) {
+        for (uint32_t i = lane; i < n; i += 8) acc = acc + x[i];
+        if ((uint32_t)lane >= n) acc = acc + 0.0f;
+    }
+#pragma unroll
+    for (int v = 0; v < 8; ++v) a[v] = shfl_f32(acc, v);
+}
+__device__ __forceinline__ float reduce_add8(const float a[8])
+{
+    return ((((((a[0] + a[1]) + a[2]) + a[3]) + a[4]) + a[5]) + a[6]) + a[7];
+}
+
+// first index of the minimum of |x[0..n)| (SpcDecoder::decode :342-373)
+__device__ __forceinline__ uint32_t sc_firstmin_abs(const float* x, uint32_t n, int lane)
+{
+    uint32_t best = 0x7F800000u, bidx = 0;  // +inf, index 0 (reference start values)
+    bool any = false;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t a = fbits(x[i]) & 0x7FFFFFFFu;
+        if (a < best) {
+            best = a;
+            bidx = i;
+            any = true;
+        }
+    }
+    // lexicographic (value, index) minimum over the wave
+    uint64_t key = any ? (((uint64_t)best << 32) | bidx) : (((uint64_t)0x7F800000u << 32) | 0xFFFFFFFFu);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint64_t o = shflx_u64(key, m);
+        key = o < key ? o : key;
+    }
+    const uint32_t idx = (uint32_t)key;
+    return idx == 0xFFFFFFFFu ? 0u : idx;
+}
+
+template <bool I8>
+__global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
+{
+    extern __shared__ uint32_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const uint32_t wpb = blockDim.x >> 6;
+    uint32_t* wl = smem + (size_t)wib * P.wave_lds_words;
+    float* llr = reinterpret_cast<float*>(wl);
+    uint32_t* bits = wl + 2u * P.N;
+    const uint32_t N = P.N;
+    const uint32_t nwords = N >= 32 ? (N >> 5) : 1u;
+    const uint32_t wave0 = blockIdx.x * wpb + wib, nwaves = gridDim.x * wpb;
+
+    for (uint32_t cw = wave0; cw < P.rows; cw += nwaves) {
+        const uint32_t row = P.rowidx ? P.rowidx[cw] : cw;
+        // ---- stage the channel row (FloatContainer::insertLlr bitcontainer.cpp:197-207) --------
+        if (I8) {
+            const int8_t* src = reinterpret_cast<const int8_t*>(P.llr) + (size_t)row * N;
+            for (uint32_t i = lane; i < N; i += 64) llr[N + i] = (float)src[i];
+        } else {
+            const float* src = reinterpret_cast<const float*>(P.llr) + (size_t)row * N;
+            if ((N & 255u) == 0) {
+                const float4* s4 = reinterpret_cast<const float4*>(src);
+                float4* d4 = reinterpret_cast<float4*>(llr + N);
+                for (uint32_t i = lane; i < (N >> 2); i += 64) d4[i] = s4[i];
+            } else {
+                for (uint32_t i = lane; i < N; i += 64) llr[N + i] = src[i];
+            }
+        }
+        WAVE_SYNC();
+
+        for (uint32_t pc = 0;; ++pc) {
+            const Ins ins = P.prog[pc];
+            if (ins.op == OP_END) break;
+            const uint32_t s = ins.stage, n = 1u << s, h = n >> 1, off = ins.off;
+            const float* x = llr + n;  // this block's input LLRs
+            switch (ins.op) {
+            case SC_F:
+                for (uint32_t i = lane; i < h; i += 64) llr[h + i] = polar_f(x[i], x[h + i]);
+                break;
+            case SC_G:
+                for (uint32_t i = lane; i < h; i += 64) {
+                    const uint32_t b = off + i;
+                    const uint32_t u = (bits[b >> 5] >> (b & 31u)) & 1u;
+                    llr[h + i] = polar_g(x[i], x[h + i], u);
+                }
+                break;
+            case SC_G0R:
+                for (uint32_t i = lane; i < h; i += 64) llr[h + i] = x[i] + x[h + i];
+                break;
+            case SC_COMBINE:
+            case SC_COMBINE0R: {
+                const bool copy = ins.op == SC_COMBINE0R;
+                if (h >= 32) {
+                    const uint32_t w0 = off >> 5, hw = h >> 5;
+                    for (uint32_t w = lane; w < hw; w += 64) {
+                        const uint32_t r = bits[w0 + hw + w];
+                        bits[w0 + w] = copy ? r : (bits[w0 + w] ^ r);
+                    }
+                } else if (lane == 0) {
+                    const uint32_t sh = off & 31u, mask = (1u << h) - 1u;
+                    uint32_t w = bits[off >> 5];
+                    const uint32_t r = (w >> (sh + h)) & mask;
+                    if (copy)
+                        w = (w & ~(mask << sh)) | (r << sh);
+                    else
+                        w ^= r << sh;
+                    bits[off >> 5] = w;
+                }
+                break;
+            }
+            case SC_RONE: {  // h >= 8
+                for (uint32_t i0 = 0; i0 < h; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const bool act = i < h;
+                    uint32_t u = 0, sl = 0;
+                    if (act) {
+                        const uint32_t b = off + i;
+                        u = (bits[b >> 5] >> (b & 31u)) & 1u;
+                        sl = sgn(polar_g(x[i], x[h + i], u));
+                    }
+                    const uint64_t mr = ballot64(act && sl);
+                    const uint64_t ml = ballot64(act && (sl ^ u));
+                    WAVE_SYNC();
+                    const uint32_t cnt = h < 64 ? h : 64;
+                    sc_put_bits(bits, off + i0, cnt, ml, lane);
+                    sc_put_bits(bits, off + h + i0, cnt, mr, lane);
+                }
+                break;
+            }
+            case SC_R0:
+                sc_fill_pattern(bits, off, n, 0u, lane);
+                break;
+            case SC_R1:
+                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const uint64_t m = ballot64(i < n && sgn(x[i < n ? i : 0]));
+                    sc_put_bits(bits, off + i0, n < 64 ? n : 64, m, lane);
+                }
+                break;
+            case SC_REP: {
+                float a[8];
+                sc_fold8(x, n, lane, a);
+                const float sum = reduce_add8(a);
+                sc_fill_pattern(bits, off, n, sgn(sum) ? 0xFFFFFFFFu : 0u, lane);
+                break;
+            }
+            case SC_SPC: {
+                uint32_t par = 0;
+                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const uint64_t m = ballot64(i < n && sgn(x[i < n ? i : 0]));
+                    par ^= (uint32_t)__popcll(m) & 1u;
+                    sc_put_bits(bits, off + i0, n < 64 ? n : 64, m, lane);
+                }
+                const uint32_t im = sc_firstmin_abs(x, n, lane);
+                if (par) sc_flip_bit(bits, off + im, lane);
+                break;
+            }
+            case SC_DREP: {
+                float a[8];
+                sc_fold8(x, n, lane, a);
+                float e, o;
+                if (n >= 8) {
+                    e = (a[0] + a[4]) + (a[2] + a[6]);
+                    o = (a[1] + a[5]) + (a[3] + a[7]);
+                } else {
+                    e = ((a[0] + a[2]) + a[4]) + a[6];
+                    o = ((a[1] + a[3]) + a[5]) + a[7];
+                }
+                sc_fill_pattern(bits, off, n, (sgn(e) ? 0x55555555u : 0u) | (sgn(o) ? 0xAAAAAAAAu : 0u), lane);
+                break;
+            }
+            case SC_DSPC8: {  // flip EVERY class member tied for the class minimum
+                const int l8 = lane & 7;
+                const float v = x[l8];
+                float m = absf(v);
+                uint32_t p = sgn(v);
+#pragma unroll
+                for (int k = 2; k < 8; k <<= 1) {
+                    const float om = shflx_f32(m, k);
+                    m = om < m ? om : m;
+                    p ^= shflx_u32(p, k);
+                }
+                const uint32_t bit = sgn(v) ^ ((p && absf(v) == m) ? 1u : 0u);
+                const uint64_t mk = ballot64(lane < 8 && bit);
+                sc_put_bits(bits, off, 8, mk, lane);
+                break;
+            }
+            case SC_DSPC: {  // n > 8: per AVX lane the LAST row with the lane minimum, lowest lane wins
+                float minv = 3.402823466e+38f;
+                uint32_t mini = 0;
+                if (lane < 8) {
+                    for (uint32_t i = lane; i < n; i += 8) {
+                        const float a = absf(x[i]);
+                        if (!(a > minv)) {
+                            minv = a;
+                            mini = i;
+                        }
+                    }
+                }
+                float cm = minv;  // class minimum over lanes of equal parity (within lanes 0..7)
+#pragma unroll
+                for (int k = 2; k < 8; k <<= 1) {
+                    const float om = shflx_f32(cm, k);
+                    cm = om < cm ? om : cm;
+                }
+                const uint64_t tie = ballot64(lane < 8 && minv == cm);
+                const int le = __ffsll((long long)(tie & 0x55ull)) - 1;
+                const int lo = __ffsll((long long)(tie & 0xAAull)) - 1;
+                const uint32_t ie = shfl_u32(mini, le < 0 ? 0 : le), io = shfl_u32(mini, lo < 0 ? 1 : lo);
+                uint32_t pe = 0, po = 0;
+                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const uint64_t m = ballot64(i < n && sgn(x[i < n ? i : 0]));
+                    pe ^= (uint32_t)__popcll(m & 0x5555555555555555ull) & 1u;
+                    po ^= (uint32_t)__popcll(m & 0xAAAAAAAAAAAAAAAAull) & 1u;
+                    sc_put_bits(bits, off + i0, n < 64 ? n : 64, m, lane);
+                }
+                if (pe) sc_flip_bit(bits, off + ie, lane);
+                if (po) sc_flip_bit(bits, off + io, lane);
+                break;
+            }
+            case SC_TREP: {
+                float a[8], t[4];
+                sc_fold8(x, n, lane, a);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = a[j] + a[j + 4];
+                const uint32_t r = spc4_signs(t);
+                sc_fill_pattern(bits, off, n, r * 0x11111111u, lane);
+                break;
+            }
+            case SC_TYPE5:
+            case SC_REPONE8: {
+                float l[8], q[4], gg[4];
+                if (ins.op == SC_TYPE5) {
+                    sc_fold8(x, n, lane, l);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) l[v] = x[v];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = polar_f(l[j], l[j + 4]);
+                const float rho = (q[0] + q[1]) + (q[2] + q[3]);
+                const uint32_t sr = sgn(rho);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gg[j] = polar_g(l[j], l[j + 4], sr);
+                uint32_t ss;
+                if (ins.op == SC_TYPE5) {
+                    ss = spc4_signs(gg);
+                } else {
+                    ss = sgn(gg[0]) | (sgn(gg[1]) << 1) | (sgn(gg[2]) << 2) | (sgn(gg[3]) << 3);
+                }
+                const uint32_t byte = ((sr ? (ss ^ 0xFu) : ss) & 0xFu) | (ss << 4);
+                sc_fill_pattern(bits, off, n, byte * 0x01010101u, lane);
+                break;
+            }
+            case SC_ZSPC8: {
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = x[j] + x[j + 4];
+                const uint32_t r = spc4_signs(t);
+                sc_put_bits(bits, off, 8, (uint64_t)(r | (r << 4)), lane);
+                break;
+            }
+            case SC_ZEROSPC: {  // n > 8; outputs the RIGHT half's signs
+                uint32_t par = 0;
+                uint32_t best = 0x7F800000u, bidx = 0;
+                bool any = false;
+                for (uint32_t i0 = 0; i0 < h; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const bool act = i < h;
+                    float y = 0.0f, r = 0.0f;
+                    if (act) {
+                        r = x[h + i];
+                        y = x[i] + r;
+                        const uint32_t a = fbits(y) & 0x7FFFFFFFu;
+                        if (a < best) {
+                            best = a;
+                            bidx = i;
+                            any = true;
+                        }
+                    }
+                    par ^= (uint32_t)__popcll(ballot64(act && sgn(y))) & 1u;
+                    const uint64_t m = ballot64(act && sgn(r));
+                    const uint32_t cnt = h < 64 ? h : 64;
+                    sc_put_bits(bits, off + i0, cnt, m, lane);
+                    sc_put_bits(bits, off + h + i0, cnt, m, lane);
+                }
+                uint64_t key = any ? (((uint64_t)best << 32) | bidx) : (((uint64_t)0x7F800000u << 32) | 0xFFFFFFFFu);
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    const uint64_t o = shflx_u64(key, m);
+                    key = o < key ? o : key;
+                }
+                uint32_t im = (uint32_t)key;
+                if (im == 0xFFFFFFFFu) im = 0;
+                if (par) {
+                    sc_flip_bit(bits, off + im, lane);
+                    sc_flip_bit(bits, off + h + im, lane);
+                }
+                break;
+            }
+            default: break;
+            }
+            WAVE_SYNC();
+        }
+
+        // ---- output: FastSscAvxFloat::decode :940-955 ------------------------------------------
+        if (!P.systematic) {  // re-encode (butterfly_fip.cpp:15-63) on the packed words
+            for (uint32_t w = lane; w < nwords; w += 64) {
+                uint32_t v = bits[w];
+                if (N >= 2) v ^= (v >> 1) & 0x55555555u;
+                if (N >= 4) v ^= (v >> 2) & 0x33333333u;
+                if (N >= 8) v ^= (v >> 4) & 0x0F0F0F0Fu;
+                if (N >= 16) v ^= (v >> 8) & 0x00FF00FFu;
+                if (N >= 32) v ^= (v >> 16) & 0x0000FFFFu;
+                bits[w] = v;
+            }
+            WAVE_SYNC();
+            for (uint32_t hw = 1; hw < nwords; hw <<= 1) {
+                for (uint32_t w = lane; w < nwords; w += 64)
+                    if (!(w & hw)) bits[w] ^= bits[w + hw];
+                WAVE_SYNC();
+            }
+        }
+        uint32_t syn = 0;
+        uint8_t* orow = P.out + (size_t)row * P.nb;
+        for (uint32_t t0 = 0; t0 < P.K; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            uint32_t bit = 0;
+            if (t < P.K) {
+                const uint32_t pos = P.lut[t];
+                bit = (bits[pos >> 5] >> (pos & 31u)) & 1u;
+                if (bit) syn ^= P.syn[t];
+            }
+            const uint64_t m = ballot64(bit != 0);
+            if (lane < 8) {
+                const uint32_t byte = (t0 >> 3) + lane;
+                if (byte < P.nb) orow[byte] = (uint8_t)(__brev((uint32_t)((m >> (8 * lane)) & 0xFFu)) >> 24);
+            }
+        }
+        syn = wave_xor_u32(syn);
+        if (lane == 0 && P.ok) P.ok[row] = (syn == 0) ? 1 : 0;
+        WAVE_SYNC();
+    }
+}
+
+// =============================================================================================
+//  Fast-SSCL
+// =============================================================================================
+// LDS per wave (one codeword):
+//   llr   : L' path buffers of path_stride floats; stage t (block 2^t) at offset 1<<t, t < logN
+//           (the channel row, stage logN, is read straight from global memory / L2)
+//   bitsL : L' x wpp words -- outputs of LEFT children (and of the root), per stage
+//   bitsR : L' x wpp words -- outputs of RIGHT children
+//           stage t lives at word woff(t): t <= 5 -> word t (low 2^t bits), else (1 << (t-5)) + 4
+// Per lane: p = lane / LP (own path), metric (replicated over the path's lanes) and the slot word:
+//   field s-1 (FB bits) = which path buffer holds  LLR[s]  while the path is inside the left
+//   subtree of its stage-s ancestor, or the LEFT child's bits of that ancestor while inside the
+//   right subtree.  Writers always use their own index (all paths sit on the same tree node, so
+//   the previous contents are dead for everyone); forks copy the word (PathList::duplicatePath).
+
+__device__ __forceinline__ uint32_t woff(uint32_t t) { return t <= 5 ? t : ((1u << (t - 5)) + 4u); }
+
+template <int LPL, bool I8, bool ROOT>
+struct LlrSrc {
+    const void* g;   // channel row (ROOT)
+    const float* l;  // LDS stage buffer (!ROOT)
+    __device__ __forceinline__ float operator[](uint32_t i) const
+    {
+        if (ROOT) {
+            if (I8) return (float)reinterpret_cast<const int8_t*>(g)[i];
+            return reinterpret_cast<const float*>(g)[i];
+        }
+        return l[i];
+    }
+};
+
+template <int LPL>
+struct SclCtx {
+    static constexpr int LP = 1 << LPL;     // lanes per path
+    static constexpr int LMAX = 64 >> LPL;  // path groups per wave
+    static constexpr int FB = 6 - LPL;      // bits per slot field
+    static constexpr int NACC = LP >= 8 ? 1 : 8 / LP;  // AVX-lane accumulators per lane
+
+    float* llr;
+    uint32_t* bitsL;
+    uint32_t* bitsR;
+    uint32_t path_stride, wpp;
+    int lane, p, j, base;
+    uint32_t P;      // live paths (wave uniform)
+    uint32_t L;      // list size limit
+    float metric;
+    uint64_t slot;
+
+    __device__ __forceinline__ float* path_llr(uint32_t q) const { return llr + (size_t)q * path_stride; }
+    __device__ __forceinline__ uint32_t* area(uint32_t side, uint32_t q) const
+    {
+        return (side ? bitsR : bitsL) + (size_t)q * wpp;
+    }
+    __device__ __forceinline__ uint32_t field(uint64_t sl, uint32_t s) const
+    {
+        return (uint32_t)(sl >> ((s - 1) * FB)) & (uint32_t)(LMAX - 1);
+    }
+    __device__ __forceinline__ void set_field(uint32_t s)
+    {
+        const uint32_t sh = (s - 1) * FB;
+        slot = (slot & ~((uint64_t)(LMAX - 1) << sh)) | ((uint64_t)p << sh);
+    }
+
+    // sum over the path of v(i), i < n, in the reference's order: 8 strided accumulators
+    // (acc[v] += x[8k+v], k ascending) then acc0+acc1+...+acc7 (avxconvenience.h:267).
+    // acc[] holds this lane's accumulators: virtual AVX lane v = j + LP*a  (LP < 8) or v = j (LP >= 8)
+    __device__ __forceinline__ float lanesum_finish(const float acc[NACC]) const
+    {
+        float s = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int a = LP >= 8 ? 0 : v / LP;
+            const int src = base + (LP >= 8 ? v : v % LP);
+            const float t = shfl_f32(acc[a], src);
+            s = (v == 0) ? t : s + t;
+        }
+        return s;
+    }
+};
+
+// ---- weakest-LLR search: findWeakLlrs(idx, |x|, n, CNT) arrayfuncs.h:209-231 ----------------------
+// Literal emulation of the swap-mutating selection: positions 0..CNT-1 of the working array are
+// kept in path-uniform registers H*, positions >= CNT in per-lane sorted candidate lists; when a
+// tail position k wins iteration i, the displaced element H[i] takes its place (at position k).
+template <int CNT>
+struct Weak {
+    uint32_t v[CNT];   // value bits (|x|), ascending selection result
+    uint32_t ix[CNT];  // original indices
+};
+
+template <int LPL, int CNT, typename SRC>
+__device__ __forceinline__ void find_weak(const SclCtx<LPL>& c, const SRC& x, uint32_t n, Weak<CNT>& out)
+{
+    constexpr int LP = SclCtx<LPL>::LP;
+    constexpr uint32_t INFB = 0xFFFFFFFFu;  // sentinel: larger than any |x| bit pattern
+    // head: positions 0..CNT-1 (uniform within the path)
+    uint32_t hv[CNT], ho[CNT];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        hv[i] = (uint32_t)i < n ? (fbits(x[(uint32_t)i < n ? i : 0]) & 0x7FFFFFFFu) : INFB;
+        ho[i] = i;
+    }
+    // tail: this lane's CNT best of positions >= CNT (ascending by (value, position))
+    uint32_t tv[CNT], tp[CNT], to[CNT];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        tv[i] = INFB;
+        tp[i] = INFB;
+        to[i] = 0;
+    }
+    for (uint32_t i = (uint32_t)CNT + (uint32_t)c.j; i < n; i += LP) {
+        uint32_t a = fbits(x[i]) & 0x7FFFFFFFu, ap = i, ao = i;
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) {  // sorted insert by (value, position); once the new element is
+                                         // placed the carried one keeps shifting (it precedes its successor)
+            const bool lt = (a < tv[k]) || (a == tv[k] && ap < tp[k]);
+            const uint32_t sv = lt ? tv[k] : a, sp = lt ? tp[k] : ap, so = lt ? to[k] : ao;
+            tv[k] = lt ? a : tv[k];
+            tp[k] = lt ? ap : tp[k];
+            to[k] = lt ? ao : to[k];
+            a = sv;
+            ap = sp;
+            ao = so;
+        }
+    }
+    const uint32_t lim = (n - 1 < (uint32_t)CNT) ? n - 1 : (uint32_t)CNT;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        if ((uint32_t)i < lim) {
+            // best tail candidate of the path: lexicographic (value, position) minimum over LP lanes
+            uint64_t key = ((uint64_t)tv[0] << 32) | tp[0];
+#pragma unroll
+            for (int m = 1; m < LP; m <<= 1) {
+                const uint64_t o = shflx_u64(key, m);
+                key = o < key ? o : key;
+            }
+            // best head candidate among positions i..CNT-1 (first occurrence)
+            int hk = i;
+#pragma unroll
+            for (int k = i + 1; k < CNT; ++k)
+                if (hv[k] < hv[hk]) hk = k;
+            const uint32_t tval = (uint32_t)(key >> 32), tpos = (uint32_t)key;
+            // owner lane / original index of the best tail candidate (shuffles kept unconditional)
+            const bool mine = (tv[0] == tval) && (tp[0] == tpos) && (tval != INFB);
+            const uint64_t bal = ballot64(mine) >> c.base;
+            const int wl = __ffsll((long long)(bal & ((LP == 64) ? ~0ull : ((1ull << LP) - 1ull)))) - 1;
+            const uint32_t worig = shfl_u32(to[0], c.base + (wl < 0 ? 0 : wl));
+            if (tval < hv[hk]) {  // a tail position wins (head positions precede on ties)
+                const uint32_t dv = hv[i], dorig = ho[i];
+                if (mine) {  // pop the winner, insert the displaced head element at position tpos
+                    uint32_t a = dv, ap = tpos, ao = dorig;
+#pragma unroll
+                    for (int k = 0; k < CNT - 1; ++k) {
+                        tv[k] = tv[k + 1];
+                        tp[k] = tp[k + 1];
+                        to[k] = to[k + 1];
+                    }
+                    tv[CNT - 1] = INFB;
+                    tp[CNT - 1] = INFB;
+                    to[CNT - 1] = 0;
+#pragma unroll
+                    for (int k = 0; k < CNT; ++k) {
+                        const bool lt = (a < tv[k]) || (a == tv[k] && ap < tp[k]);
+                        const uint32_t sv = lt ? tv[k] : a, sp = lt ? tp[k] : ap, so = lt ? to[k] : ao;
+                        tv[k] = lt ? a : tv[k];
+                        tp[k] = lt ? ap : tp[k];
+                        to[k] = lt ? ao : to[k];
+                        a = sv;
+                        ap = sp;
+                        ao = so;
+                    }
+                }
+                hv[i] = tval;
+                ho[i] = worig;
+            } else {  // swap head positions i and hk
+#pragma unroll
+                for (int k = 0; k < CNT; ++k) {
+                    if (k == hk) {
+                        const uint32_t a = hv[i], b = ho[i];
+                        hv[i] = hv[k];
+                        ho[i] = ho[k];
+                        hv[k] = a;
+                        ho[k] = b;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        out.v[i] = hv[i];
+        out.ix[i] = ho[i];
+    }
+}
+
+// ---- candidate selection: simplePartialSortDescending(idx, metrics, P', size) arrayfuncs.h:161-183 ----
+// Candidate position c = path * CPP + q is held by lane path*LP + q/CPL, register q%CPL.
+// Literal emulation: iteration i finds the first position >= i holding the maximum and swaps it
+// with position i.  On return every lane knows, for ITS OWN new path index p, the winning
+// candidate's metric (nval) and original position (nidx).
+template <int LPL, int CPP>
+__device__ __forceinline__ void select_paths(const SclCtx<LPL>& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
+                                             uint32_t newP, float& nval, uint32_t& nidx)
+{
+    constexpr int LP = SclCtx<LPL>::LP;
+    constexpr int CPL = (CPP >> LPL) ? (CPP >> LPL) : 1;
+    const uint32_t size = c.P * CPP;
+    uint32_t idx[CPL], pos[CPL];
+    bool valid[CPL];
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) {
+        const uint32_t q = (uint32_t)c.j * CPL + r;
+        valid[r] = (q < (uint32_t)CPP) && ((uint32_t)c.p < c.P);
+        pos[r] = (uint32_t)c.p * CPP + q;
+        idx[r] = pos[r];
+    }
+    const uint32_t lim = (size - 1 < newP) ? size - 1 : newP;
+    for (uint32_t i = 0; i < lim; ++i) {
+        // lane-local first maximum among eligible positions (>= i)
+        float lv = 0.0f;
+        int lr = -1;
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            const bool el = valid[r] && pos[r] >= i;
+            if (el && (lr < 0 || val[r] > lv)) {
+                lv = val[r];
+                lr = r;
+            }
+        }
+        const bool has = lr >= 0;
+        // wave maximum
+        float m = has ? lv : -__builtin_inff();
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) {
+            const float o = shflx_f32(m, k);
+            m = o > m ? o : m;
+        }
+        const uint64_t bal = ballot64(has && lv == m);
+        const int wl = __ffsll((long long)bal) - 1;  // lowest lane = lowest position
+        // the element currently at position i
+        const uint32_t li = (i / CPP) * LP + ((i % CPP) / CPL), ri = (i % CPP) % CPL;
+        float vi = val[0];
+        uint32_t xi = idx[0];
+#pragma unroll
+        for (int r = 1; r < CPL; ++r)
+            if ((uint32_t)r == ri) {
+                vi = val[r];
+                xi = idx[r];
+            }
+        vi = shfl_f32(vi, (int)li);
+        xi = shfl_u32(xi, (int)li);
+        // the winner
+        uint32_t xw = idx[0];
+#pragma unroll
+        for (int r = 1; r < CPL; ++r)
+            if (r == lr) xw = idx[r];
+        const int lrw = __shfl(lr, wl, 64);
+        xw = shfl_u32(xw, wl);
+        // swap: winner's slot receives (vi, xi); position i receives (m, xw)
+        if (c.lane == wl) {
+#pragma unroll
+            for (int r = 0; r < CPL; ++r)
+                if (r == lrw) {
+                    val[r] = vi;
+                    idx[r] = xi;
+                }
+        }
+        if ((uint32_t)c.lane == li) {
+#pragma unroll
+            for (int r = 0; r < CPL; ++r)
+                if ((uint32_t)r == ri) {
+                    val[r] = m;
+                    idx[r] = xw;
+                }
+        }
+    }
+    // new path p takes the candidate now sitting at position p
+    const uint32_t np = (uint32_t)c.p;
+    const uint32_t ln = (np / CPP) * LP + ((np % CPP) / CPL), rn = (np % CPP) % CPL;
+    // fetch register rn of lane ln (rn varies per lane -> select after shuffling every register)
+    float v = shfl_f32(val[0], (int)ln);
+    uint32_t x = shfl_u32(idx[0], (int)ln);
+#pragma unroll
+    for (int r = 1; r < CPL; ++r) {
+        const float vr = shfl_f32(val[r], (int)ln);
+        const uint32_t xr = shfl_u32(idx[r], (int)ln);
+        if ((uint32_t)r == rn) {
+            v = vr;
+            x = xr;
+        }
+    }
+    nval = v;
+    nidx = x;
+}
+
+// write the n leaf bits of every (new) path: sign(x_src[i]) ^ flips, packed, into area(side)[stage]
+// flips: up to 4 positions (fmask bit k enables fpos[k]);  REP passes n_from_llr = false
+template <int LPL, typename SRC>
+__device__ __forceinline__ void write_leaf_bits(const SclCtx<LPL>& c, const SRC& x, uint32_t s, uint32_t side,
+                                                bool active, uint32_t fmask, const uint32_t fpos[4])
+{
+    constexpr int LP = SclCtx<LPL>::LP;
+    const uint32_t n = 1u << s;
+    uint32_t* dst = c.area(side, c.p) + woff(s);
+    uint32_t acc = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += LP) {
+        const uint32_t i = i0 + c.j;
+        uint32_t b = 0;
+        if (active && i < n) {
+            b = sgn(x[i]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b ^= (((fmask >> k) & 1u) && fpos[k] == i) ? 1u : 0u;
+        }
+        const uint64_t bal = ballot64(b != 0);
+        const uint32_t chunk = (uint32_t)(bal >> c.base) & (LP == 32 ? 0xFFFFFFFFu : ((1u << LP) - 1u));
+        acc |= chunk << (i0 & 31u);
+        if (((i0 + LP) & 31u) == 0 || i0 + LP >= n) {
+            if (active && c.j == 0) dst[i0 >> 5] = acc;
+            acc = 0;
+        }
+    }
+}
+
+template <int LPL, bool I8>
+__global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
+{
+    using Ctx = SclCtx<LPL>;
+    constexpr int LP = Ctx::LP;
+    constexpr int LMAX = Ctx::LMAX;
+    constexpr int NACC = Ctx::NACC;
+    extern __shared__ uint32_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const uint32_t wpb = blockDim.x >> 6;
+    uint32_t* wl = smem + (size_t)wib * P.wave_lds_words;
+
+    Ctx c;
+    c.llr = reinterpret_cast<float*>(wl);
+    c.bitsL = wl + (size_t)LMAX * P.path_stride;
+    c.bitsR = c.bitsL + (size_t)LMAX * P.wpp;
+    c.path_stride = P.path_stride;
+    c.wpp = P.wpp;
+    c.lane = lane;
+    c.p = lane >> LPL;
+    c.j = lane & (LP - 1);
+    c.base = lane & ~(LP - 1);
+    c.L = P.L;
+    const uint32_t N = P.N, logN = P.logN;
+    const uint32_t wave0 = blockIdx.x * wpb + wib, nwaves = gridDim.x * wpb;
+
+    for (uint32_t cw = wave0; cw < P.rows; cw += nwaves) {
+        const uint32_t row = P.rowidx ? P.rowidx[cw] : cw;
+        const void* chan = I8 ? (const void*)(reinterpret_cast<const int8_t*>(P.llr) + (size_t)row * N)
+                              : (const void*)(reinterpret_cast<const float*>(P.llr) + (size_t)row * N);
+        // makeInitialPathList :705-709 -- one path, metric 0 (fresh decoder)
+        c.P = 1;
+        c.metric = 0.0f;
+        c.slot = 0;
+        uint32_t trace_n = 0;
+
+        for (uint32_t pc = 0;; ++pc) {
+            const Ins ins = P.prog[pc];
+            if (ins.op == OP_END) break;
+            const uint32_t s = ins.stage, n = 1u << s, h = n >> 1, side = ins.side;
+            const bool root = (s == logN);
+            const bool active = (uint32_t)c.p < c.P;
+
+            switch (ins.op) {
+            // ------------------------------------------------------------------ inner node ops
+            case SCL_F: {  // RateRNode::decode :233-238 -- reads the path's own (identity) buffer
+                if (h >= 64) {
+                    for (uint32_t q = 0; q < c.P; ++q) {
+                        float* dst = c.path_llr(q) + h;
+                        if (root) {
+                            LlrSrc<LPL, I8, true> x{ chan, nullptr };
+                            for (uint32_t i = lane; i < h; i += 64) dst[i] = polar_f(x[i], x[h + i]);
+                        } else {
+                            const float* x = c.path_llr(q) + n;
+                            for (uint32_t i = lane; i < h; i += 64) dst[i] = polar_f(x[i], x[h + i]);
+                        }
+                    }
+                } else if (active) {
+                    float* dst = c.path_llr(c.p) + h;
+                    if (root) {
+                        LlrSrc<LPL, I8, true> x{ chan, nullptr };
+                        for (uint32_t i = c.j; i < h; i += LP) dst[i] = polar_f(x[i], x[h + i]);
+                    } else {
+                        const float* x = c.path_llr(c.p) + n;
+                        for (uint32_t i = c.j; i < h; i += LP) dst[i] = polar_f(x[i], x[h + i]);
+                    }
+                }
+                c.set_field(s);
+                break;
+            }
+            case SCL_G: {  // :242-249 -- LLR[s] through the slot word, left bits at identity
+                const uint32_t wo = woff(s - 1);
+                if (h >= 64) {
+                    for (uint32_t q = 0; q < c.P; ++q) {
+                        const uint32_t srcq = c.field(shfl_u64(c.slot, (int)(q << LPL)), s);
+                        float* dst = c.path_llr(q) + h;
+                        const uint32_t* lb = c.area(0, q) + wo;
+                        if (root) {
+                            LlrSrc<LPL, I8, true> x{ chan, nullptr };
+                            for (uint32_t i = lane; i < h; i += 64)
+                                dst[i] = polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u);
+                        } else {
+                            const float* x = c.path_llr(srcq) + n;
+                            for (uint32_t i = lane; i < h; i += 64)
+                                dst[i] = polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u);
+                        }
+                    }
+                } else if (active) {
+                    const uint32_t srcq = c.field(c.slot, s);
+                    float* dst = c.path_llr(c.p) + h;
+                    const uint32_t* lb = c.area(0, c.p) + wo;
+                    if (root) {
+                        LlrSrc<LPL, I8, true> x{ chan, nullptr };
+                        for (uint32_t i = c.j; i < h; i += LP)
+                            dst[i] = polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u);
+                    } else {
+                        const float* x = c.path_llr(srcq) + n;
+                        for (uint32_t i = c.j; i < h; i += LP)
+                            dst[i] = polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u);
+                    }
+                }
+                c.set_field(s);  // from now on the field names the holder of the LEFT bits
+                break;
+            }
+            case SCL_COMBINE: {  // :253-260 CombineBitsLong / CombineBitsShort
+                if (active) {
+                    const uint32_t lq = c.field(c.slot, s);
+                    const uint32_t* lb = c.area(0, lq) + woff(s - 1);
+                    const uint32_t* rb = c.area(1, c.p) + woff(s - 1);
+                    uint32_t* ob = c.area(side, c.p) + woff(s);
+                    if (h >= 32) {
+                        const uint32_t hw = h >> 5;
+                        for (uint32_t w = c.j; w < hw; w += LP) {
+                            const uint32_t r = rb[w];
+                            ob[w] = lb[w] ^ r;
+                            ob[hw + w] = r;
+                        }
+                    } else if (c.j == 0) {
+                        const uint32_t mask = (1u << h) - 1u;
+                        const uint32_t r = rb[0] & mask;
+                        ob[0] = ((lb[0] ^ r) & mask) | (r << h);
+                    }
+                }
+                break;
+            }
+            // ------------------------------------------------------------------ leaves
+            case SCL_R0: {  // RateZeroDecoder::decode :316-337
+                float acc[NACC];
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+                if (active && (LP < 8 || c.j < 8)) {
+                    auto body = [&](auto x) {
+#pragma unroll
+                        for (int a = 0; a < NACC; ++a) {
+                            const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
+                            for (uint32_t i = v; i < n; i += 8) acc[a] = acc[a] + min0(x[i]);
+                            if (v >= n) acc[a] = acc[a] + 0.0f;
+                        }
+                    };
+                    if (root)
+                        body(LlrSrc<LPL, I8, true>{ chan, nullptr });
+                    else
+                        body(LlrSrc<LPL, I8, false>{ nullptr, c.path_llr(c.p) + n });
+                }
+                const float sum = c.lanesum_finish(acc);
+                if (active) {
+                    c.metric = c.metric + sum;
+                    uint32_t* ob = c.area(side, c.p) + woff(s);
+                    const uint32_t nw = n >= 32 ? (n >> 5) : 1u;
+                    for (uint32_t w = c.j; w < nw; w += LP) ob[w] = 0u;
+                }
+                break;
+            }
+            case SCL_REP: {  // RepetitionDecoder::decode :428-481 (n = 2 or 4)
+                float az[NACC], ao[NACC];
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) az[a] = ao[a] = 0.0f;
+                if (active && (LP < 8 || c.j < 8)) {
+                    auto body = [&](auto x) {
+#pragma unroll
+                        for (int a = 0; a < NACC; ++a) {
+                            const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
+                            const float xv = v < n ? x[v < n ? v : 0] : 0.0f;
+                            az[a] = az[a] + min0(xv);
+                            ao[a] = ao[a] + max0(xv);
+                        }
+                    };
+                    if (root)
+                        body(LlrSrc<LPL, I8, true>{ chan, nullptr });
+                    else
+                        body(LlrSrc<LPL, I8, false>{ nullptr, c.path_llr(c.p) + n });
+                }
+                const float z = c.lanesum_finish(az), o = c.lanesum_finish(ao);
+                constexpr int CPL = (2 >> LPL) ? (2 >> LPL) : 1;
+                float val[CPL];
+#pragma unroll
+                for (int r = 0; r < CPL; ++r) {
+                    const uint32_t q = (uint32_t)c.j * CPL + r;
+                    val[r] = (q == 0) ? c.metric + z : c.metric - o;
+                }
+                const uint32_t newP = (c.P * 2 < c.L) ? c.P * 2 : c.L;
+                float nval;
+                uint32_t nidx;
+                select_paths<LPL, 2>(c, val, newP, nval, nidx);
+                const uint32_t srcp = nidx >> 1, q = nidx & 1u;
+                const uint64_t nslot = shfl_u64(c.slot, (int)(srcp << LPL));
+                c.P = newP;
+                if ((uint32_t)c.p < c.P) {
+                    c.metric = nval;
+                    c.slot = nslot;
+                    if (c.j == 0) (c.area(side, c.p) + woff(s))[0] = q ? ((1u << n) - 1u) : 0u;
+                }
+                break;
+            }
+            case SCL_R1:     // RateOneDecoder::decode :353-413
+            case SCL_SPC: {  // SpcDecoder::decode     :498-621
+                const bool spc = ins.op == SCL_SPC;
+                Weak<4> wk;
+                uint32_t par = 0;
+                auto search = [&](auto x) {
+                    if (spc) {
+                        find_weak<LPL, 4>(c, x, n, wk);
+                        uint32_t pb = 0;
+                        for (uint32_t i = c.j; i < n; i += LP) pb ^= sgn(x[i]);
+#pragma unroll
+                        for (int m = 1; m < LP; m <<= 1) pb ^= shflx_u32(pb, m);
+                        par = pb & 1u;
+                    } else {
+                        Weak<2> w2;
+                        find_weak<LPL, 2>(c, x, n, w2);
+                        wk.v[0] = w2.v[0];
+                        wk.v[1] = w2.v[1];
+                        wk.ix[0] = w2.ix[0];
+                        wk.ix[1] = w2.ix[1];
+                        wk.v[2] = wk.v[3] = 0;
+                        wk.ix[2] = wk.ix[3] = 0;
+                    }
+                };
+                if (root)
+                    search(LlrSrc<LPL, I8, true>{ chan, nullptr });
+                else
+                    search(LlrSrc<LPL, I8, false>{ nullptr, c.path_llr(c.p) + n });
+                const float v0 = bitsf(wk.v[0]), v1 = bitsf(wk.v[1]), v2 = bitsf(wk.v[2]), v3 = bitsf(wk.v[3]);
+                uint32_t nidx;
+                float nval;
+                uint32_t newP;
+                if (spc) {
+                    constexpr int CPL = (8 >> LPL) ? (8 >> LPL) : 1;
+                    float val[CPL];
+                    const float m = par ? c.metric - v0 : c.metric;
+                    const float beta = par ? m - 0.0f : m - v0;
+#pragma unroll
+                    for (int r = 0; r < CPL; ++r) {
+                        const uint32_t q = (uint32_t)c.j * CPL + r;
+                        float t;
+                        switch (q) {
+                        case 0: t = m; break;
+                        case 1: t = beta - v1; break;
+                        case 2: t = beta - v2; break;
+                        case 3: t = beta - v3; break;
+                        case 4: t = (m - v1) - v2; break;
+                        case 5: t = (m - v1) - v3; break;
+                        case 6: t = (m - v2) - v3; break;
+                        default: t = ((beta - v1) - v2) - v3; break;
+                        }
+                        val[r] = t;
+                    }
+                    newP = (c.P * 8 < c.L) ? c.P * 8 : c.L;
+                    select_paths<LPL, 8>(c, val, newP, nval, nidx);
+                } else {
+                    constexpr int CPL = (4 >> LPL) ? (4 >> LPL) : 1;
+                    float val[CPL];
+                    const float m = c.metric;
+#pragma unroll
+                    for (int r = 0; r < CPL; ++r) {
+                        const uint32_t q = (uint32_t)c.j * CPL + r;
+                        float t;
+                        switch (q) {
+                        case 0: t = m; break;
+                        case 1: t = m - v0; break;
+                        case 2: t = m - v1; break;
+                        default: t = (m - v0) - v1; break;
+                        }
+                        val[r] = t;
+                    }
+                    newP = (c.P * 4 < c.L) ? c.P * 4 : c.L;
+                    select_paths<LPL, 4>(c, val, newP, nval, nidx);
+                }
+                const uint32_t srcp = spc ? (nidx >> 3) : (nidx >> 2);
+                const uint32_t q = spc ? (nidx & 7u) : (nidx & 3u);
+                const int sl = (int)(srcp << LPL);
+                const uint64_t nslot = shfl_u64(c.slot, sl);
+                uint32_t fpos[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fpos[k] = shfl_u32(wk.ix[k], sl);
+                const uint32_t spar = shfl_u32(par, sl);
+                uint32_t fmask;
+                if (spc) {
+                    // flip sets :533-585 as bit masks over {i0,i1,i2,i3}; odd parity toggles i0
+                    const uint32_t even = (0xFCA69530u >> (4 * q)) & 0xFu;
+                    fmask = even ^ (spar ? 1u : 0u);
+                } else {
+                    fmask = q;
+                }
+                c.P = newP;
+                const bool nact = (uint32_t)c.p < c.P;
+                if (nact) {
+                    c.metric = nval;
+                    c.slot = nslot;
+                }
+                // bits of the new path = signs of the SOURCE path's LLRs (identity buffer) with flips
+                if (root)
+                    write_leaf_bits<LPL>(c, LlrSrc<LPL, I8, true>{ chan, nullptr }, s, side, nact, fmask, fpos);
+                else
+                    write_leaf_bits<LPL>(c, LlrSrc<LPL, I8, false>{ nullptr, c.path_llr(srcp) + n }, s, side, nact,
+                                         fmask, fpos);
+                break;
+            }
+            default: break;
+            }
+            WAVE_SYNC();
+            if (P.trace && cw == 0 && ins.op >= SCL_R0) {
+                if (trace_n < P.trace_cap) {
+                    float* t = P.trace + (size_t)trace_n * (1 + P.L);
+                    if (lane == 0) t[0] = (float)c.P;
+                    if (c.j == 0 && (uint32_t)c.p < P.L) t[1 + c.p] = ((uint32_t)c.p < c.P) ? c.metric : 0.0f;
+                }
+                ++trace_n;
+            }
+        }
+
+        // ---- SclAvxFloat::extractBestPath :711-750 ---------------------------------------------
+        const bool active = (uint32_t)c.p < c.P;
+        uint32_t* cwbits = c.area(0, c.p) + woff(logN);
+        const uint32_t nwords = N >= 32 ? (N >> 5) : 1u;
+        if (!P.systematic) {  // re-encode every candidate (:731-746)
+            if (active) {
+                for (uint32_t w = c.j; w < nwords; w += LP) {
+                    uint32_t v = cwbits[w];
+                    if (N >= 2) v ^= (v >> 1) & 0x55555555u;
+                    if (N >= 4) v ^= (v >> 2) & 0x33333333u;
+                    if (N >= 8) v ^= (v >> 4) & 0x0F0F0F0Fu;
+                    if (N >= 16) v ^= (v >> 8) & 0x00FF00FFu;
+                    if (N >= 32) v ^= (v >> 16) & 0x0000FFFFu;
+                    cwbits[w] = v;
+                }
+            }
+            WAVE_SYNC();
+            for (uint32_t hw = 1; hw < nwords; hw <<= 1) {
+                if (active)
+                    for (uint32_t w = c.j; w < nwords; w += LP)
+                        if (!(w & hw)) cwbits[w] ^= cwbits[w + hw];
+                WAVE_SYNC();
+            }
+        }
+        // detector verdict of every path in parallel (syndrome XOR), first passing path wins
+        uint32_t winner = 0, okflag = 1;
+        if (P.det_on) {
+            uint32_t syn = 0;
+            if (active) {
+                for (uint32_t t = c.j; t < P.K; t += LP) {
+                    const uint32_t pos = P.lut[t];
+                    if ((cwbits[pos >> 5] >> (pos & 31u)) & 1u) syn ^= P.syn[t];
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < LP; m <<= 1) syn ^= shflx_u32(syn, m);
+            const uint64_t pass = ballot64(active && c.j == 0 && syn == 0);
+            if (pass) {
+                winner = (uint32_t)(__ffsll((long long)pass) - 1) >> LPL;
+            } else {
+                winner = 0;
+                okflag = 0;
+            }
+        }
+        {
+            const uint32_t* wb = c.area(0, winner) + woff(logN);
+            uint8_t* orow = P.out + (size_t)row * P.nb;
+            for (uint32_t t0 = 0; t0 < P.K; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                uint32_t bit = 0;
+                if (t < P.K) {
+                    const uint32_t pos = P.lut[t];
+                    bit = (wb[pos >> 5] >> (pos & 31u)) & 1u;
+                }
+                const uint64_t m = ballot64(bit != 0);
+                if (lane < 8) {
+                    const uint32_t byte = (t0 >> 3) + lane;
+                    if (byte < P.nb) orow[byte] = (uint8_t)(__brev((uint32_t)((m >> (8 * lane)) & 0xFFu)) >> 24);
+                }
+            }
+        }
+        if (lane == 0 && P.ok) P.ok[row] = (uint8_t)okflag;
+        if (P.metrics) {
+            if (c.j == 0 && (uint32_t)c.p < P.L) P.metrics[(size_t)row * P.L + c.p] = active ? c.metric : 0.0f;
+        }
+        WAVE_SYNC();
+    }
+}
+
+// =============================================================================================
+//  small helper kernels
+// =============================================================================================
+// "mixed" (AdaptiveFloat::decode adaptive_float.cpp:33-45): gather the rows the SC pass failed on
+__global__ void collect_failed_kernel(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows && !ok[i]) {
+        const uint32_t k = atomicAdd(count, 1u);
+        list[k] = i;
+    }
+}
+
+// =============================================================================================
+//  launchers
+// =============================================================================================
+template <int LPL>
+static hipError_t launch_scl_t(const DecodeParams& P, bool i8, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+{
+    if (i8) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((scl_decode_kernel<LPL, true>), grid, block, lds, st, P);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((scl_decode_kernel<LPL, false>), grid, block, lds, st, P);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sc(const DecodeParams& P, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,
+                     hipStream_t st)
+{
+    dim3 g(grid), b(64 * waves_per_block);
+    if (i8) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((sc_decode_kernel<true>), g, b, lds, st, P);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((sc_decode_kernel<false>), g, b, lds, st, P);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, unsigned waves_per_block,
+                      size_t lds, hipStream_t st)
+{
+    dim3 g(grid), b(64 * waves_per_block);
+    switch (lpl) {
+    case 1: return launch_scl_t<1>(P, i8, g, b, lds, st);
+    case 2: return launch_scl_t<2>(P, i8, g, b, lds, st);
+    case 3: return launch_scl_t<3>(P, i8, g, b, lds, st);
+    case 4: return launch_scl_t<4>(P, i8, g, b, lds, st);
+    case 5: return launch_scl_t<5>(P, i8, g, b, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,
+                                 hipStream_t st)
+{
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(collect_failed_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, ok, rows, list, count);
+    return hipGetLastError();
+}
+
+}  // namespace pamd

@@ -1,0 +1,81 @@
+// Decode "program": the reference builds a tree of polymorphic node objects per decoder
+// (FastSscAvx::createDecoder fastssc_avx_float.cpp:797-896, SclAvx::createDecoder
+// scl_avx_float.cpp:624-651) and walks it with virtual calls.  Here the same node-selection
+// rules are applied once on the host and flattened into a linear list of 8-byte instructions
+// that every wave of the decode kernels interprets in lock-step (the tree depends only on
+// (N, frozen set), so control flow is uniform across the whole batch).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace pamd {
+
+enum Op : uint8_t {
+    OP_END = 0,
+    // ---- Fast-SSC (L = 1) ------------------------------------------------------------------
+    SC_F = 1,      // llr[s-1] = f(llr[s])                         RateRNode::decode :148-155
+    SC_G,          // llr[s-1] = g(llr[s], bits[off .. off+h))
+    SC_G0R,        // llr[s-1] = a + b                             ZeroRNode::decode :232-237
+    SC_COMBINE,    // bits[off..off+h) ^= bits[off+h..off+2h)      Combine avx_float.h:190-197
+    SC_COMBINE0R,  // bits[off..off+h)  = bits[off+h..off+2h)      Combine_0R :199-204
+    SC_RONE,       // fused g + hard decision + combine            ROneNode::rightDecode :205-219
+    SC_R0,         // leaves, stage = log2(block), off = first bit
+    SC_R1,
+    SC_REP,
+    SC_SPC,
+    SC_DREP,
+    SC_DSPC,
+    SC_DSPC8,
+    SC_TREP,
+    SC_TYPE5,
+    SC_REPONE8,
+    SC_ZSPC8,
+    SC_ZEROSPC,
+    // ---- Fast-SSCL (L > 1) -----------------------------------------------------------------
+    SCL_F = 32,    // per path: llr[s-1] = f(llr[s])               RateRNode::decode :229-263
+    SCL_G,         // per path: llr[s-1] = g(llr[s], left bits)
+    SCL_COMBINE,   // per path: bit[s] = [left ^ right | right]    CombineBitsLong/Short
+    SCL_R0,        // RateZeroDecoder::decode :316-337
+    SCL_R1,        // RateOneDecoder::decode  :353-413
+    SCL_REP,       // RepetitionDecoder::decode :428-481
+    SCL_SPC,       // SpcDecoder::decode      :498-621
+};
+
+struct Ins {
+    uint8_t op;
+    uint8_t stage;  // log2 of the block length the op works on (parent block for F/G/COMBINE)
+    uint8_t side;   // SCL: 0 = this node is a left child (or the root), 1 = right child
+    uint8_t pad;
+    uint32_t off;   // first code-bit index of the block (SC bit array); unused by SCL ops
+};
+static_assert(sizeof(Ins) == 8, "Ins must be 8 bytes");
+
+struct Program {
+    std::vector<Ins> ins;
+    unsigned leaves = 0, inner = 0;
+};
+
+// Returns "" on success, otherwise the text of the std::invalid_argument the reference throws
+// (SURVEY Q6).  frozen: strictly ascending indices < N.
+std::string compile_sc(unsigned N, const std::vector<uint32_t>& frozen, Program& out);
+std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program& out);
+
+// ---- error detection -------------------------------------------------------------------------
+// All supported detectors are linear over GF(2) with a zero initial value, so
+//   check(bytes) == true  <=>  XOR over the set info bits t of syndrome[t] == 0.
+struct Detector {
+    unsigned size = 8;       // check bits (0 = dummy)
+    bool nr = false;         // 5G NR flavour (type string contained "nr")
+    std::string type_name() const;       // Detector::getType()
+    unsigned check_bytes() const;        // bytes the checksum field occupies at the end
+    // mirrors Detector::check(void*, int bytes) of the selected reference class
+    bool check(const uint8_t* data, int bytes) const;
+    // syndrome word for info bit t (MSB-first bit t of the packed output), K info bits
+    std::vector<uint32_t> syndrome_table(unsigned K) const;
+};
+
+// returns 0 or a pcd_status-compatible negative code; fills det
+int make_detector(unsigned size, const std::string& type, Detector& det, std::string& err);
+
+}  // namespace pamd

@@ -1,0 +1,277 @@
+"""pypolar_amd -- drop-in for the decode path of ``pypolar`` (ant-uni-bremen/polar-codes) on MI355X.
+
+Mirrors ``pypolar.PolarDecoder`` (reference: python/bindings/decoder_python.cc:17-75): same constructor
+arguments, method names, overload behaviour of ``decode_vector`` (float32 first, then int8) and the same
+exception types/messages, and adds ``decode_batch`` (B codewords per call, one HIP kernel launch).
+
+All decoding happens in hand-written HIP kernels behind the C ABI of ``include/polar_amd.h``
+(``polar-codes_amd/lib/libpolar_amd.so``).  There is no CPU fallback: without the library or without
+a GPU, decoding raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["PolarDecoder", "PolarAmdError", "library_path", "load_library", "C_SYMBOLS"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpolar_amd.so")
+_lib = None
+
+PCD_MEM_HOST, PCD_MEM_DEVICE = 0, 1
+
+# every symbol include/polar_amd.h declares
+C_SYMBOLS = [
+    "pcd_create", "pcd_destroy", "pcd_set_error_detection", "pcd_set_systematic", "pcd_is_systematic",
+    "pcd_block_length", "pcd_info_length", "pcd_list_size", "pcd_frozen_bits", "pcd_error_detection_mode",
+    "pcd_out_bytes", "pcd_decode_f32", "pcd_decode_i8", "pcd_program_stats", "pcd_launch_info",
+    "pcd_set_timing", "pcd_last_kernel_ms", "pcd_scl_trace", "pcd_last_error", "pcd_version",
+]
+
+
+class PolarAmdError(RuntimeError):
+    """Raised for failures that have no counterpart in the reference (no GPU, HIP errors, capacity)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[pcd {code}] {msg}")
+        self.code = code
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libpolar_amd.so (fails loudly if it has not been built: ``make -C polar-codes_amd``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} is missing: build it with `make -C polar-codes_amd` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(_LIB_PATH)
+    vp, u32p = C.c_void_p, C.POINTER(C.c_uint32)
+    lib.pcd_create.restype = C.c_int
+    lib.pcd_create.argtypes = [C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.pcd_destroy.restype = None
+    lib.pcd_destroy.argtypes = [vp]
+    lib.pcd_set_error_detection.restype = C.c_int
+    lib.pcd_set_error_detection.argtypes = [vp, C.c_uint, C.c_char_p]
+    lib.pcd_set_systematic.restype = C.c_int
+    lib.pcd_set_systematic.argtypes = [vp, C.c_int]
+    lib.pcd_is_systematic.restype = C.c_int
+    lib.pcd_is_systematic.argtypes = [vp]
+    for f in ("pcd_block_length", "pcd_info_length", "pcd_list_size", "pcd_out_bytes"):
+        getattr(lib, f).restype = C.c_size_t
+        getattr(lib, f).argtypes = [vp]
+    lib.pcd_frozen_bits.restype = C.c_size_t
+    lib.pcd_frozen_bits.argtypes = [vp, vp, C.c_size_t]
+    lib.pcd_error_detection_mode.restype = C.c_int
+    lib.pcd_error_detection_mode.argtypes = [vp, C.c_char_p, C.c_size_t]
+    for f in ("pcd_decode_f32", "pcd_decode_i8"):
+        getattr(lib, f).restype = C.c_int
+        getattr(lib, f).argtypes = [vp, vp, C.c_size_t, vp, vp, vp, C.c_int, vp]
+    lib.pcd_program_stats.restype = C.c_int
+    lib.pcd_program_stats.argtypes = [vp, C.c_int, u32p]
+    lib.pcd_launch_info.restype = C.c_int
+    lib.pcd_launch_info.argtypes = [vp, C.c_int, u32p]
+    lib.pcd_set_timing.restype = C.c_int
+    lib.pcd_set_timing.argtypes = [vp, C.c_int]
+    lib.pcd_last_kernel_ms.restype = C.c_int
+    lib.pcd_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pcd_scl_trace.restype = C.c_int
+    lib.pcd_scl_trace.argtypes = [vp, vp, vp, C.c_uint]
+    lib.pcd_last_error.restype = C.c_char_p
+    lib.pcd_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _raise(code):
+    """Translate a pcd_status into the exception pybind11 would surface for the reference."""
+    msg = load_library().pcd_last_error().decode()
+    if code == -2:      # std::logic_error("Unknown PolarDecoder type!")  -> RuntimeError via pybind11
+        raise RuntimeError(msg)
+    if code == -4:      # std::invalid_argument from createDecoder          -> ValueError
+        raise ValueError(msg)
+    if code == -5:      # std::logic_error("CRC INVALID SIZE!")
+        raise RuntimeError(msg)
+    if code == -6:      # std::runtime_error("Unknown Error detector requested!")
+        raise RuntimeError(msg)
+    if code == -1:
+        raise ValueError(msg)
+    if code == -3:
+        raise NotImplementedError(msg)
+    raise PolarAmdError(code, msg)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class PolarDecoder:
+    """``pypolar.PolarDecoder(blockLength, listSize, frozenBitPositions, decoderType)``."""
+
+    def __init__(self, blockLength, listSize, frozenBitPositions, decoderType, device=0):
+        lib = load_library()
+        frozen = np.ascontiguousarray(np.asarray(frozenBitPositions, dtype=np.int64).astype(np.uint32))
+        self._h = C.c_void_p()
+        rc = lib.pcd_create(int(blockLength), int(listSize), frozen.ctypes.data_as(C.c_void_p), frozen.size,
+                            str(decoderType).encode(), int(device), C.byref(self._h))
+        if rc:
+            self._h = None
+            _raise(rc)
+        self._lib = lib
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.pcd_destroy(h)
+            self._h = None
+
+    # ---- accessors (decoder_python.cc:27-33) ---------------------------------------------------
+    def blockLength(self):
+        return int(self._lib.pcd_block_length(self._h))
+
+    def infoLength(self):
+        return int(self._lib.pcd_info_length(self._h))
+
+    def listSize(self):
+        return int(self._lib.pcd_list_size(self._h))
+
+    def setSystematic(self, sys):
+        self._lib.pcd_set_systematic(self._h, int(bool(sys)))
+
+    def isSystematic(self):
+        return bool(self._lib.pcd_is_systematic(self._h))
+
+    def frozenBits(self):
+        n = self._lib.pcd_frozen_bits(self._h, None, 0)
+        out = np.zeros(n, np.uint32)
+        self._lib.pcd_frozen_bits(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return [int(x) for x in out]
+
+    def getErrorDetectionMode(self):
+        buf = C.create_string_buffer(64)
+        self._lib.pcd_error_detection_mode(self._h, buf, 64)
+        return buf.value.decode()
+
+    def setErrorDetection(self, size=0, type="crc"):
+        rc = self._lib.pcd_set_error_detection(self._h, int(size), str(type).encode())
+        if rc:
+            _raise(rc)
+
+    # ---- decode_vector (decoder_python.cc:41-74) -----------------------------------------------
+    def decode_vector(self, array):
+        """One codeword.  int8 ndarray -> the int8 overload, anything else is cast to float32
+        (pybind11 tries the float overload first and only the exact dtype skips conversion)."""
+        a = np.asarray(array)
+        i8 = a.dtype == np.int8
+        a = np.ascontiguousarray(a, dtype=np.int8 if i8 else np.float32)
+        if a.ndim != 1:
+            raise RuntimeError("Only ONE-dimensional vectors allowed!")
+        if a.size != self.blockLength():
+            raise RuntimeError("Input vector size != blockSize // 8!")
+        out, _, _ = self._decode_host(a.reshape(1, -1), i8, False)
+        # the reference returns infoLength()//8 bytes (decoder_python.cc:52)
+        return out[0, : self.infoLength() // 8].copy()
+
+    # ---- batched entry point (no reference counterpart) ----------------------------------------
+    def decode_batch(self, llr, return_metrics=False, out=None, ok=None, metrics=None, stream=None):
+        """Decode B codewords.
+
+        ``llr``: ``[B, N]`` float32 / int8, either a numpy array (host: staged + synchronous) or a
+        torch tensor on the decoder's GPU (device pointers, asynchronous on ``stream`` / the current
+        torch stream).  Returns ``(bytes[B, ceil(K/8)], ok[B])`` (+ ``metrics[B, L]``).
+        """
+        if _is_torch(llr):
+            return self._decode_torch(llr, return_metrics, out, ok, metrics, stream)
+        a = np.asarray(llr)
+        i8 = a.dtype == np.int8
+        a = np.ascontiguousarray(a, dtype=np.int8 if i8 else np.float32)
+        if a.ndim != 2 or a.shape[1] != self.blockLength():
+            raise ValueError("llr must have shape [B, blockLength]")
+        o, k, m = self._decode_host(a, i8, return_metrics)
+        return (o, k.astype(bool), m) if return_metrics else (o, k.astype(bool))
+
+    def _decode_host(self, a, i8, want_metrics):
+        B = a.shape[0]
+        nb = int(self._lib.pcd_out_bytes(self._h))
+        L = max(1, self.listSize())
+        out = np.zeros((B, nb), np.uint8)
+        ok = np.zeros(B, np.uint8)
+        met = np.zeros((B, L), np.float32) if want_metrics else None
+        fn = self._lib.pcd_decode_i8 if i8 else self._lib.pcd_decode_f32
+        rc = fn(self._h, a.ctypes.data_as(C.c_void_p), B, out.ctypes.data_as(C.c_void_p),
+                ok.ctypes.data_as(C.c_void_p), met.ctypes.data_as(C.c_void_p) if want_metrics else None,
+                PCD_MEM_HOST, None)
+        if rc:
+            _raise(rc)
+        return out, ok, met
+
+    def _decode_torch(self, llr, want_metrics, out, ok, metrics, stream):
+        import torch
+
+        if not llr.is_cuda:
+            res = self.decode_batch(llr.numpy(), want_metrics)
+            return tuple(torch.from_numpy(np.ascontiguousarray(r)) for r in res)
+        i8 = llr.dtype == torch.int8
+        if not i8 and llr.dtype != torch.float32:
+            llr = llr.float()
+        llr = llr.contiguous()
+        if llr.dim() != 2 or llr.shape[1] != self.blockLength():
+            raise ValueError("llr must have shape [B, blockLength]")
+        B = llr.shape[0]
+        nb = int(self._lib.pcd_out_bytes(self._h))
+        L = max(1, self.listSize())
+        if out is None:
+            out = torch.empty((B, nb), dtype=torch.uint8, device=llr.device)
+        if ok is None:
+            ok = torch.empty((B,), dtype=torch.uint8, device=llr.device)
+        if want_metrics and metrics is None:
+            metrics = torch.empty((B, L), dtype=torch.float32, device=llr.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(llr.device).cuda_stream
+        fn = self._lib.pcd_decode_i8 if i8 else self._lib.pcd_decode_f32
+        rc = fn(self._h, C.c_void_p(llr.data_ptr()), B, C.c_void_p(out.data_ptr()), C.c_void_p(ok.data_ptr()),
+                C.c_void_p(metrics.data_ptr()) if want_metrics else None, PCD_MEM_DEVICE, C.c_void_p(stream))
+        if rc:
+            _raise(rc)
+        return (out, ok, metrics) if want_metrics else (out, ok)
+
+    # ---- introspection ---------------------------------------------------------------------------
+    def program_stats(self, list_program):
+        cnt = (C.c_uint32 * 2)()
+        rc = self._lib.pcd_program_stats(self._h, int(bool(list_program)), cnt)
+        if rc:
+            _raise(rc)
+        return int(cnt[0]), int(cnt[1])
+
+    def launch_info(self, list_program):
+        info = (C.c_uint32 * 4)()
+        rc = self._lib.pcd_launch_info(self._h, int(bool(list_program)), info)
+        if rc:
+            _raise(rc)
+        return {"lds_bytes_per_codeword": int(info[0]), "codewords_per_workgroup": int(info[1]),
+                "path_groups": int(info[2]), "workgroups_per_cu_by_lds": int(info[3])}
+
+    def scl_trace(self, llr_row, cap=4096):
+        """diagnostics: per-leaf (path count, metrics) trace of one row -> float32[n, 1 + L]"""
+        a = np.ascontiguousarray(llr_row, dtype=np.float32)
+        L = self.listSize()
+        tr = np.zeros((cap, 1 + L), np.float32)
+        rc = self._lib.pcd_scl_trace(self._h, a.ctypes.data_as(C.c_void_p), tr.ctypes.data_as(C.c_void_p), cap)
+        if rc:
+            _raise(rc)
+        return tr
+
+    def set_timing(self, enable=True):
+        self._lib.pcd_set_timing(self._h, int(bool(enable)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        rc = self._lib.pcd_last_kernel_ms(self._h, C.byref(ms))
+        if rc:
+            _raise(rc)
+        return float(ms.value)

@@ -40,6 +40,8 @@ def lib():
         _lib.po_scl_decode_paths.restype = C.c_int
         _lib.po_scl_decode_paths.argtypes = [C.c_uint, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p,
                                              C.c_void_p, C.c_void_p]
+        _lib.po_scl_trace.restype = C.c_int
+        _lib.po_scl_trace.argtypes = [C.c_uint, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int]
     return _lib
 
 
@@ -93,3 +95,11 @@ def tree_stats(N, frozen, list_decoder):
     cnt = np.zeros(2, np.uint32)
     rc = lib().po_tree_stats(N, _p(frozen), frozen.size, int(list_decoder), _p(cnt))
     return rc, int(cnt[0]), int(cnt[1])
+
+
+def scl_trace(N, L, frozen, llr_row, cap=4096):
+    frozen = np.ascontiguousarray(frozen, dtype=np.uint32)
+    a = np.ascontiguousarray(llr_row, dtype=np.float32)
+    tr = np.zeros((cap, 1 + L), np.float32)
+    n = lib().po_scl_trace(N, L, _p(frozen), frozen.size, _p(a), _p(tr), cap)
+    return tr[:n]

@@ -1,0 +1,206 @@
+"""GPU suite (-m gpu): the HIP decoders, called through the C ABI (pypolar_amd -> libpolar_amd.so),
+against (a) the committed golden vectors of the unmodified reference, (b) the oracle on seeded
+inputs, (c) size-independent properties at BASELINE.json's full batch sizes.
+
+Bar: decoded bytes and detector verdicts bit-exact; path metrics within 1e-5 relative (north star)
+-- in practice they are bit-identical and the test also reports that."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_io as gio
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+FILES = gio.all_files()
+METRIC_RTOL = 1e-5
+
+
+def _decoder(fx, device=0):
+    import pypolar_amd
+    d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, fx.dectype, device=device)
+    d.setErrorDetection(fx.crc_size, fx.crc_type)
+    return d
+
+
+def _check_metrics(got, ref, npaths, name):
+    for r in range(ref.shape[0]):
+        p = int(npaths[r])
+        g, e = got[r, :p].astype(np.float64), ref[r, :p].astype(np.float64)
+        assert np.all(np.abs(g - e) <= METRIC_RTOL * np.maximum(1.0, np.abs(e))), (name, r, g, e)
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_hip_matches_reference_vectors(built_library, path):
+    for fx in gio.load(path):
+        d = _decoder(fx)
+        want_m = fx.L > 1 and fx.dectype == "float"
+        res = d.decode_batch(fx.llr, return_metrics=want_m)
+        assert np.array_equal(res[0], fx.out), fx.name
+        assert np.array_equal(res[1].astype(np.uint8), fx.ok), fx.name
+        if want_m:
+            _check_metrics(res[2], fx.metrics, fx.npaths, fx.name)
+
+
+def test_metrics_are_bit_identical_on_cfg3(built_library):
+    fx = gio.load_named("cfg3_n1024_k512_l8_crc24_awgn.bin")
+    _, _, met = _decoder(fx).decode_batch(fx.llr, return_metrics=True)
+    assert np.array_equal(met.view(np.uint32), fx.metrics.view(np.uint32))
+
+
+def test_decode_vector_surface(built_library):
+    """pypolar.PolarDecoder.decode_vector drop-in: README example + qa_pypolar_decoder.py:94-132"""
+    import pypolar_amd
+    fx = gio.load_named("cfg1_n64_k40_sc_awgn.bin")
+    d = pypolar_amd.PolarDecoder(64, 1, fx.frozen, "float")
+    d.setErrorDetection(0, "crc")
+    for r in range(8):
+        out = d.decode_vector(fx.llr[r])
+        assert out.dtype == np.uint8 and out.shape == (5,)
+        assert np.array_equal(out, fx.out[r])
+        # float64 / python lists are force-cast to float32 like pybind11's forcecast
+        assert np.array_equal(d.decode_vector(fx.llr[r].astype(np.float64).tolist()), fx.out[r])
+
+
+def test_n8_known_answer(built_library):
+    """decodingtest.cpp:1143-1173: N=8, frozen {0,1,2,4}, SCL-float L=4 and SC => high nibble 0xF"""
+    import pypolar_amd
+    llr = np.array([-5, -6, -4, 1, -4, -5, -7, 2], np.float32)
+    for L in (1, 4):
+        d = pypolar_amd.PolarDecoder(8, L, [0, 1, 2, 4], "float")
+        d.setErrorDetection(0, "crc")
+        out, _ = d.decode_batch(llr.reshape(1, 8))
+        assert (out[0, 0] & 0xF0) == 0xF0
+
+
+@pytest.mark.parametrize("name", ["cfg2_n1024_k512_sc_quant.bin", "cfg3_n1024_k512_l8_crc24_quant.bin",
+                                  "cfg4_n1024_k176_l8_crc11_quant.bin"])
+def test_int8_input_path(built_library, name):
+    """decode_vector(np.int8): int8 LLRs widened to float (bitcontainer.cpp:202-207). The quant fixtures
+    hold integer-valued float LLRs, so the int8 overload must give the reference's float result."""
+    fx = gio.load_named(name)
+    d = _decoder(fx)
+    q = fx.llr.astype(np.int8)
+    assert np.array_equal(q.astype(np.float32), fx.llr)
+    out, ok = d.decode_batch(q)
+    assert np.array_equal(out, fx.out) and np.array_equal(ok.astype(np.uint8), fx.ok)
+    assert np.array_equal(d.decode_vector(q[0]), fx.out[0, : fx.K // 8])
+
+
+@pytest.mark.parametrize("N,L,det", [(64, 1, 0), (256, 1, 8), (256, 4, 8), (1024, 8, 24), (512, 32, 32), (128, 16, 8),
+                                     (2048, 2, 11)])
+def test_random_inputs_vs_oracle(built_library, N, L, det):
+    """seeded random inputs (pure noise, low SNR, ties) the fixtures do not contain, systematic and
+    non-systematic output, checked row by row against the oracle."""
+    import pypolar_amd
+    rng = np.random.default_rng(N * 131 + L * 7 + det)
+    src = {64: "cfg1_n64_k40_sc_awgn.bin", 256: "sweep_n256.bin", 1024: "cfg3_n1024_k512_l8_crc24_awgn.bin",
+           512: "sweep_n512.bin", 128: "sweep_n128.bin", 2048: "sweep_n2048.bin"}[N]
+    cands = [f for f in gio.load(os.path.join(gio.GOLDEN_DIR, src))]
+    frozen = cands[len(cands) // 2].frozen
+    K = N - frozen.size
+    if det and K // 8 < 6:
+        det = 0
+    B = 48 if N <= 512 else 24
+    rows = []
+    for i in range(B):
+        mode = i % 3
+        if mode == 0:
+            rows.append(rng.normal(0, 1, N))
+        elif mode == 1:
+            info = rng.integers(0, 256, (K + 7) // 8, dtype=np.uint8)
+            if K % 8:
+                info[-1] &= (0xFF << (8 - K % 8)) & 0xFF
+            _, cw = ob.encode(N, frozen, det, info)
+            rows.append(1.0 - 2.0 * np.unpackbits(cw)[:N] + rng.normal(0, 0.9, N))
+        else:
+            rows.append(rng.choice([-1.0, 1.0], N) * rng.choice([1.0, 2.0], N))
+    llr = np.asarray(rows, np.float32)
+    for systematic in (True, False):
+        d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
+        d.setErrorDetection(det, "crcnr" if det in (11, 24) else "crc")
+        d.setSystematic(systematic)
+        res = d.decode_batch(llr, return_metrics=L > 1)
+        e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, det, llr, systematic, "float")
+        assert np.array_equal(res[0], e_out), (N, L, det, systematic)
+        assert np.array_equal(res[1].astype(np.uint8), e_ok)
+        if L > 1:
+            assert np.allclose(res[2], e_met, rtol=METRIC_RTOL, atol=0)
+
+
+def test_mixed_decoder_vs_oracle(built_library):
+    import pypolar_amd
+    fx = gio.load_named("mix_n1024_k512_l8_crc24_awgn.bin")
+    rng = np.random.default_rng(5)
+    llr = np.concatenate([fx.llr, rng.normal(0, 1, (16, fx.N)).astype(np.float32)])
+    d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, "mixed")
+    d.setErrorDetection(24, "crcnr")
+    out, ok = d.decode_batch(llr)
+    e_out, e_ok, _ = ob.decode_batch(fx.N, fx.L, fx.frozen, 24, llr, True, "mixed")
+    assert np.array_equal(out, e_out) and np.array_equal(ok.astype(np.uint8), e_ok)
+
+
+def test_device_pointer_path_and_ragged_batches(built_library):
+    """torch CUDA tensors go through PCD_MEM_DEVICE (no staging); batch sizes that do not divide the
+    grid, a single row and an empty batch."""
+    import torch
+    fx = gio.load_named("cfg3_n1024_k512_l8_crc24_awgn.bin")
+    d = _decoder(fx)
+    dev = torch.device("cuda:0")
+    for B in (0, 1, 3, 65, fx.count):
+        x = torch.from_numpy(fx.llr[:B].copy()).to(dev)
+        out, ok = d.decode_batch(x)
+        torch.cuda.synchronize()
+        assert out.shape == (B, 64)
+        assert np.array_equal(out.cpu().numpy(), fx.out[:B])
+        assert np.array_equal(ok.cpu().numpy(), fx.ok[:B])
+
+
+def _systematic_codewords(N, frozen, det, B, rng):
+    """B valid systematic codewords (oracle encoder) -> (info_with_crc[B, nb], bits[B, N])"""
+    K = N - frozen.size
+    infos, cws = [], []
+    for _ in range(B):
+        info = rng.integers(0, 256, K // 8, dtype=np.uint8)
+        i2, cw = ob.encode(N, frozen, det, info)
+        infos.append(i2)
+        cws.append(np.unpackbits(cw))
+    return np.asarray(infos), np.asarray(cws)
+
+
+@pytest.mark.parametrize("name,L,det,ebn0", [("cfg2_n1024_k512_sc_awgn.bin", 1, 0, 4.0),
+                                             ("cfg3_n1024_k512_l8_crc24_awgn.bin", 8, 24, 3.0)])
+def test_full_batch_properties(built_library, name, L, det, ebn0):
+    """BASELINE batch size 2^20 (device resident): encode -> AWGN -> decode round trip on a tiled
+    set of distinct codewords; every replica of a row must decode identically (determinism across
+    waves), high-SNR rows must return their payload with ok=1, and a sample of rows must equal the oracle."""
+    import pypolar_amd
+    import torch
+    fx = gio.load_named(name)
+    N, frozen = fx.N, fx.frozen
+    K = N - frozen.size
+    rng = np.random.default_rng(99)
+    U = 512
+    infos, bits = _systematic_codewords(N, frozen, det, U, rng)
+    sigma = 1.0 / np.sqrt(2.0 * 10 ** (ebn0 / 10.0) * K / N)
+    llr_u = (1.0 - 2.0 * bits + sigma * rng.normal(0, 1, bits.shape)).astype(np.float32)
+    B = 1 << 20
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(llr_u).to(dev).repeat(B // U, 1)
+    d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
+    d.setErrorDetection(det, "crcnr" if det == 24 else "crc")
+    out, ok = d.decode_batch(x)
+    torch.cuda.synchronize()
+    out = out.view(B // U, U, -1)
+    assert bool((out == out[0:1]).all()), "replicas of the same row decoded differently"
+    ok = ok.view(B // U, U)
+    assert bool((ok == ok[0:1]).all())
+    o0, k0 = out[0].cpu().numpy(), ok[0].cpu().numpy()
+    e_out, e_ok, _ = ob.decode_batch(N, L, frozen, det, llr_u[:64], True, "float")
+    assert np.array_equal(o0[:64], e_out) and np.array_equal(k0[:64], e_ok)
+    good = (o0 == infos).all(axis=1)
+    assert good.mean() > 0.97, good.mean()
+    if det:
+        assert np.array_equal(k0.astype(bool) & good, good)

