@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X polar decoder (BASELINE.json):
+codewords/s (+ info-Gbit/s) of Fast-SSCL decoding, N=1024 K=512 L=8 + CRC-24C, batch 2^20 per GPU,
+synthetic AWGN LLRs (Eb/N0 = 2 dB, systematic codewords with valid checksums), inputs resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over the whole resident batch: pcd_decode_f32 on device pointers
+(+ for N > 1 the all-gather of the decoded bytes and verdicts over RCCL).  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "polar-codes_amd"))
+
+import pypolar_amd  # noqa: E402
+from pypolar_amd import detector as pdet  # noqa: E402
+from pypolar_amd import sharding  # noqa: E402
+from pypolar_amd.construction import frozen_bits  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+CONFIGS = {
+    # SURVEY section 8(d)
+    "cfg2": dict(N=1024, K=512, L=1, dsnr=0.0, crc=0, crc_type="crc", ebn0=2.5, log2_batch=20,
+                 name="N=1024 K=512 SC, batch=2^20"),
+    "cfg3": dict(N=1024, K=512, L=8, dsnr=0.0, crc=24, crc_type="crcnr", ebn0=2.0, log2_batch=20,
+                 name="N=1024 K=512 SCL L=8 + CRC-24C, batch=2^20"),
+}
+
+
+def polar_transform_(x):
+    """in-place x = u G (natural order, parent = [a^b | b]) on a [B, N] uint8 tensor"""
+    B, N = x.shape
+    h = 1
+    while h < N:
+        v = x.view(B, N // (2 * h), 2, h)
+        v[:, :, 0, :] ^= v[:, :, 1, :]
+        h *= 2
+    return x
+
+
+def make_batch(cfg, frozen, B, device, seed):
+    """synthetic traffic: random payload -> checksum -> systematic polar encoding -> BPSK + AWGN.
+    returns (llr float32 [B, N], info bytes uint8 [B, nb])"""
+    N, K = cfg["N"], cfg["K"]
+    nb = (K + 7) // 8
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    info_pos = torch.from_numpy(np.setdiff1d(np.arange(N), frozen).astype(np.int64)).to(device)
+    frozen_t = torch.from_numpy(frozen.astype(np.int64)).to(device)
+    fb = pdet.field_bytes(cfg["crc"])
+    M = torch.from_numpy(pdet.checksum_bit_matrix(cfg["crc"], nb).astype(np.float32)).to(device) if fb else None
+    sigma = 1.0 / np.sqrt(2.0 * 10 ** (cfg["ebn0"] / 10.0) * K / N)
+    llr = torch.empty((B, N), dtype=torch.float32, device=device)
+    info = torch.empty((B, nb), dtype=torch.uint8, device=device)
+    weights = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.int32, device=device)
+    chunk = 1 << 17
+    for lo in range(0, B, chunk):
+        n = min(chunk, B - lo)
+        msg = torch.randint(0, 2, (n, 8 * (nb - fb)), generator=g, device=device, dtype=torch.uint8)
+        if fb:
+            chk = (msg.float() @ M).to(torch.int32).remainder_(2).to(torch.uint8)
+            bits = torch.cat([msg, chk], dim=1)
+        else:
+            bits = msg
+        info[lo:lo + n] = (bits.view(n, nb, 8).to(torch.int32) * weights).sum(dim=2).to(torch.uint8)
+        u = torch.zeros((n, N), dtype=torch.uint8, device=device)
+        u[:, info_pos] = bits[:, :K]
+        polar_transform_(u)
+        u[:, frozen_t] = 0
+        polar_transform_(u)
+        noise = torch.randn((n, N), generator=g, device=device, dtype=torch.float32)
+        llr[lo:lo + n] = (1.0 - 2.0 * u.float()) + sigma * noise
+        del u, noise, bits, msg
+    return llr, info
+
+
+def cpu_baseline(cfg, seconds):
+    """the reference's own CPU decoder (oracle/_ref, unmodified library) if it travelled with the repo,
+    else the oracle port -- on a bounded sample of the same workload; reported, never the target."""
+    cores = len(os.sched_getaffinity(0))
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    rows = 4096
+    if os.path.exists(harness):
+        try:
+            out = subprocess.run([harness, "time", str(cfg["N"]), str(cfg["K"]), str(cfg["L"]), "BB", str(cfg["dsnr"]),
+                                  str(cfg["crc"]), cfg["crc_type"], str(cfg["ebn0"]), str(rows), str(cores), str(seconds)],
+                                 capture_output=True, text=True, timeout=seconds * 6 + 120, check=True)
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+            return {"value": r["cw_per_s"], "unit": "codewords/s", "cores": cores, "kind": "reference",
+                    "sample": f"{rows} distinct AWGN codewords cycled for {r['seconds']:.1f} s, one reference "
+                              f"decoder object per thread ({cores} threads), {r['codewords']} decodes"}
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] reference harness unavailable ({e}); timing the oracle port", file=sys.stderr)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    frozen = frozen_bits(cfg["N"], cfg["K"], cfg["dsnr"])
+    rng = np.random.default_rng(0)
+    llr = rng.normal(1.0, 0.8, (256, cfg["N"])).astype(np.float32)
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds:
+        ob.decode_batch(cfg["N"], cfg["L"], frozen, cfg["crc"], llr)
+        n += llr.shape[0]
+    el = time.time() - t0
+    return {"value": n / el, "unit": "codewords/s", "cores": 1, "kind": "port",
+            "sample": f"{n} decodes of 256 noisy rows by the scalar C oracle in {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--log2-batch", type=int, default=None, help="codewords per GPU = 2^this (default: BASELINE's 20)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    cfg = dict(CONFIGS[args.config])
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    log2b = args.log2_batch if args.log2_batch is not None else cfg["log2_batch"]
+    B = 1 << log2b                                   # per GPU (weak scaling: fixed work per GPU)
+    N, K, L = cfg["N"], cfg["K"], cfg["L"]
+    nb = (K + 7) // 8
+    frozen = frozen_bits(N, K, cfg["dsnr"], "BB")
+    dec = pypolar_amd.PolarDecoder(N, L, frozen, "float", device=local_rank)
+    dec.setErrorDetection(cfg["crc"], cfg["crc_type"])
+
+    llr, info = make_batch(cfg, frozen, B, dev, seed=1234 + rank)
+    out = torch.empty((B, nb), dtype=torch.uint8, device=dev)
+    ok = torch.empty((B,), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        dec.decode_batch(llr, out=out, ok=ok)
+        if world > 1:
+            return sharding.gather_decoded(sharding.pack_result(out, ok))
+        return None
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dec.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kms = dec.kernel_times_ms()
+    dec.set_timing(False)
+
+    # sanity outside the timed region: decoded payloads vs what was sent
+    okf = float(ok.float().mean().item())
+    match = float((out == info).all(dim=1).float().mean().item())
+
+    if rank == 0:
+        total_cw = B * world * args.steps
+        cw_s = total_cw / elapsed
+        payload_bits = K - cfg["crc"] if cfg["crc"] != 11 else K - 16
+        k_ms = float(np.mean(kms)) if len(kms) else float("nan")
+        bytes_per_cw = 4 * N + nb                    # fp32 row in + packed bytes out
+        achieved = bytes_per_cw * B / (k_ms * 1e-3) / 1e9
+        res = {
+            "metric": "codewords/sec + info-Gbit/s, N=1024 K=512 SCL L=8, batch=2^20" if args.config == "cfg3"
+                      else f"codewords/sec + info-Gbit/s, {cfg['name']}",
+            "value": cw_s, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["name"] + (" per GPU" if world > 1 else ""), "block_length": N,
+                       "info_bits": K, "list_size": L, "detector": f"{cfg['crc_type']}-{cfg['crc']}",
+                       "ebn0_db": cfg["ebn0"], "codewords_per_gpu": B, "frozen_set": f"BB dSNR {cfg['dsnr']} dB",
+                       "parallelism": f"rows sharded over {world} GPU(s), all-gather of decoded bytes" if world > 1
+                                      else "single GPU"},
+            "info_gbit_per_s": cw_s * K / 1e9, "payload_gbit_per_s": cw_s * payload_bits / 1e9,
+            "detector_pass_fraction": okf, "payload_match_fraction": match,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "scl_decode_kernel" if L > 1 else "sc_decode_kernel",
+                         "kernel_ms_avg": k_ms, "algorithmic_bytes_per_codeword": bytes_per_cw,
+                         "codewords_per_launch": B},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,10 +87,11 @@ int pcd_decode_i8(pcd_decoder* d, const int8_t* llr, size_t rows, uint8_t* out, 
 int pcd_program_stats(const pcd_decoder* d, int list, unsigned counts[2]);
 /* LDS bytes per codeword and codewords (waves) per workgroup the launch will use; 0 if n/a */
 int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4]);
-/* Time (ms) the most recent pcd_decode_* kernel(s) took, measured with HIP events on the launch
- * stream when timing is enabled.  pcd_set_timing(d, 1) adds two event records per call. */
+/* Kernel timing with HIP events recorded on the launch stream around the kernel(s) of every decode call
+ * (up to 512 calls after pcd_set_timing(d, 1), which also resets the list).  pcd_kernel_times waits for
+ * the recorded events and returns the per-call durations in ms; *count = number of calls recorded. */
 int pcd_set_timing(pcd_decoder* d, int enable);
-int pcd_last_kernel_ms(pcd_decoder* d, float* ms);
+int pcd_kernel_times(pcd_decoder* d, float* ms, size_t cap, size_t* count);
 
 /* Diagnostics: decode ONE row (host float32[N]) with the list decoder and record, after every leaf of
  * the decode tree, (1 + list_size) floats {live path count, path metrics...} into trace (host). */

@@ -70,10 +70,13 @@ struct pcd_decoder {
     uint32_t* d_count = nullptr;
     int sc_blocks_per_cu = 0, scl_blocks_per_cu = 0;
 
+    // kernel timing: a ring of HIP event pairs recorded on the launch stream around the kernel(s) of
+    // each decode call; resolved lazily by pcd_kernel_times so the timed calls never synchronise
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    std::vector<hipEvent_t> ev;  // 2 * kTimingSlots events
+    unsigned ev_count = 0;       // calls recorded since pcd_set_timing(d, 1)
 };
+constexpr unsigned kTimingSlots = 512;
 
 namespace {
 
@@ -156,8 +159,6 @@ int ensure_device(pcd_decoder* d)
         if (!lut.empty()) HIP_TRY(hipMemcpy(d->d_lut, lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_syn), std::max<size_t>(4, (size_t)d->K * 4)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_count), 4));
-        HIP_TRY(hipEventCreate(&d->ev0));
-        HIP_TRY(hipEventCreate(&d->ev1));
         d->dev_ready = true;
         d->det_dirty = true;
     }
@@ -234,7 +235,14 @@ int decode_device(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t
     if (rows == 0) return PCD_OK;
     if (rows > 0xFFFFFFFFull) return fail(PCD_ERR_INVALID_ARG, "rows must fit in 32 bits");
     int rc;
-    if (d->timing) HIP_TRY(hipEventRecord(d->ev0, st));
+    const bool timed = d->timing && d->ev_count < kTimingSlots;
+    if (timed) {
+        if (d->ev.empty()) {
+            d->ev.resize(2 * kTimingSlots, nullptr);
+            for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
+        }
+        HIP_TRY(hipEventRecord(d->ev[2 * d->ev_count], st));
+    }
     if (d->L <= 1) {
         if (metrics) HIP_TRY(hipMemsetAsync(metrics, 0, rows * sizeof(float), st));
         if ((rc = run_sc(d, base_params(d, llr, rows, out, ok, nullptr), i8, st))) return rc;
@@ -262,9 +270,9 @@ int decode_device(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t
     } else {
         if ((rc = run_scl(d, base_params(d, llr, rows, out, ok, metrics), i8, st))) return rc;
     }
-    if (d->timing) {
-        HIP_TRY(hipEventRecord(d->ev1, st));
-        d->ev_valid = true;
+    if (timed) {
+        HIP_TRY(hipEventRecord(d->ev[2 * d->ev_count + 1], st));
+        d->ev_count++;
     }
     return PCD_OK;
 }
@@ -398,8 +406,8 @@ void pcd_destroy(pcd_decoder* d)
         (void)hipFree(d->d_lut);
         (void)hipFree(d->d_syn);
         (void)hipFree(d->d_count);
-        if (d->ev0) (void)hipEventDestroy(d->ev0);
-        if (d->ev1) (void)hipEventDestroy(d->ev1);
+        for (auto e : d->ev)
+            if (e) (void)hipEventDestroy(e);
     }
     if (d->d_in) (void)hipFree(d->d_in);
     if (d->d_out) (void)hipFree(d->d_out);
@@ -493,15 +501,19 @@ int pcd_set_timing(pcd_decoder* d, int enable)
 {
     if (!d) return fail(PCD_ERR_INVALID_ARG, "null decoder");
     d->timing = enable != 0;
+    d->ev_count = 0;
     return PCD_OK;
 }
 
-int pcd_last_kernel_ms(pcd_decoder* d, float* ms)
+int pcd_kernel_times(pcd_decoder* d, float* ms, size_t cap, size_t* count)
 {
-    if (!d || !ms) return fail(PCD_ERR_INVALID_ARG, "null argument");
-    if (!d->ev_valid) return fail(PCD_ERR_INVALID_ARG, "no timed decode call yet (pcd_set_timing)");
-    HIP_TRY(hipEventSynchronize(d->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, d->ev0, d->ev1));
+    if (!d || !count) return fail(PCD_ERR_INVALID_ARG, "null argument");
+    *count = d->ev_count;
+    if (!ms) return PCD_OK;
+    for (unsigned i = 0; i < d->ev_count && i < cap; ++i) {
+        HIP_TRY(hipEventSynchronize(d->ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms[i], d->ev[2 * i], d->ev[2 * i + 1]));
+    }
     return PCD_OK;
 }
 

@@ -26,7 +26,7 @@ C_SYMBOLS = [
     "pcd_create", "pcd_destroy", "pcd_set_error_detection", "pcd_set_systematic", "pcd_is_systematic",
     "pcd_block_length", "pcd_info_length", "pcd_list_size", "pcd_frozen_bits", "pcd_error_detection_mode",
     "pcd_out_bytes", "pcd_decode_f32", "pcd_decode_i8", "pcd_program_stats", "pcd_launch_info",
-    "pcd_set_timing", "pcd_last_kernel_ms", "pcd_scl_trace", "pcd_last_error", "pcd_version",
+    "pcd_set_timing", "pcd_kernel_times", "pcd_scl_trace", "pcd_last_error", "pcd_version",
 ]
 
 
@@ -78,8 +78,8 @@ def load_library():
     lib.pcd_launch_info.argtypes = [vp, C.c_int, u32p]
     lib.pcd_set_timing.restype = C.c_int
     lib.pcd_set_timing.argtypes = [vp, C.c_int]
-    lib.pcd_last_kernel_ms.restype = C.c_int
-    lib.pcd_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pcd_kernel_times.restype = C.c_int
+    lib.pcd_kernel_times.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.pcd_scl_trace.restype = C.c_int
     lib.pcd_scl_trace.argtypes = [vp, vp, vp, C.c_uint]
     lib.pcd_last_error.restype = C.c_char_p
@@ -269,9 +269,14 @@ class PolarDecoder:
     def set_timing(self, enable=True):
         self._lib.pcd_set_timing(self._h, int(bool(enable)))
 
-    def last_kernel_ms(self):
-        ms = C.c_float()
-        rc = self._lib.pcd_last_kernel_ms(self._h, C.byref(ms))
+    def kernel_times_ms(self):
+        """per-call kernel durations (HIP events on the launch stream) since set_timing(True)"""
+        n = C.c_size_t()
+        rc = self._lib.pcd_kernel_times(self._h, None, 0, C.byref(n))
         if rc:
             _raise(rc)
-        return float(ms.value)
+        ms = np.zeros(max(1, n.value), np.float32)
+        rc = self._lib.pcd_kernel_times(self._h, ms.ctypes.data_as(C.c_void_p), ms.size, C.byref(n))
+        if rc:
+            _raise(rc)
+        return ms[: n.value].copy()
