@@ -97,6 +97,11 @@ int pcd_kernel_times(pcd_decoder* d, float* ms, size_t cap, size_t* count);
  * the decode tree, (1 + list_size) floats {live path count, path metrics...} into trace (host). */
 int pcd_scl_trace(pcd_decoder* d, const float* llr_row, float* trace, unsigned cap);
 
+/* Diagnostics: shader-clock cycles one wave spends in every instruction of the SCL decode program while
+ * decoding ONE row on an otherwise idle GPU (ops[i]/stages[i] describe instruction i; *count = program length). */
+int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
+                    unsigned cap, unsigned* count);
+
 const char* pcd_last_error(void);
 const char* pcd_version(void);
 

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,7 +48,10 @@ struct pcd_decoder {
     // launch geometry
     unsigned sc_wave_words = 0, sc_wpb = 4;
     int lpl = 3;
-    unsigned lmax = 8, path_stride = 0, wpp = 0, scl_wave_words = 0, scl_wpb = 1;
+    unsigned lmax = 8, path_stride = 0, wppL = 0, wppR = 0, scl_wave_words = 0, scl_wpb = 1;
+    unsigned s0 = 0, arena_path_stride = 0, arena_wave_words = 0;
+    float* d_arena = nullptr;
+    size_t d_arena_cap = 0;
 
     // device state (created lazily by the first decode call)
     bool dev_ready = false, det_dirty = true;
@@ -113,10 +117,32 @@ void compute_geometry(pcd_decoder* d)
         d->lmax = lmax;
         d->lpl = 6 - (int)ilog2(lmax);
         const unsigned LP = 64 / lmax;
-        d->path_stride = N + (LP < 32 ? LP : 0);
-        const unsigned woffN = d->logN <= 5 ? d->logN : ((1u << (d->logN - 5)) + 4u);
-        d->wpp = (woffN + bitw) | 1u;
-        d->scl_wave_words = (lmax * d->path_stride + 2 * lmax * d->wpp + 3) & ~3u;
+        const unsigned pad = LP < 32 ? LP : 0;
+        auto woff = [](unsigned t) { return t <= 5 ? t : ((1u << (t - 5)) + 4u); };
+        const unsigned topw = d->logN >= 6 ? (1u << (d->logN - 6)) : 1u;  // words of a stage logN-1 block
+        d->wppL = (woff(d->logN) + bitw) | 1u;                             // left children + the root output
+        d->wppR = (woff(d->logN ? d->logN - 1 : 0) + topw) | 1u;           // right children: stages < logN
+        // LLR stages [s0, logN) go to a global arena; pick s0 for the best occupancy (ties: the most LDS)
+        auto lds_words = [&](unsigned s0) {
+            return (lmax * ((1u << s0) + pad) + lmax * (d->wppL + d->wppR) + 3) & ~3u;
+        };
+        unsigned best_s0 = d->logN, best_waves = 0;
+        const unsigned lo = d->logN < 6 ? d->logN : 6;
+        for (unsigned s0 = d->logN; s0 + 1 > lo; --s0) {
+            const size_t bytes = (size_t)lds_words(s0) * 4;
+            const unsigned waves = bytes > kMaxLds ? 0u : (unsigned)std::min<size_t>(8, kMaxLds / bytes);
+            if (waves > best_waves) {
+                best_waves = waves;
+                best_s0 = s0;
+            }
+            if (s0 == 0) break;
+        }
+        if (const char* dbg = std::getenv("PCD_S0")) best_s0 = (unsigned)std::atoi(dbg);  // experiments
+        d->s0 = best_s0;
+        d->path_stride = (1u << d->s0) + pad;
+        d->scl_wave_words = lds_words(d->s0);
+        d->arena_path_stride = d->s0 < d->logN ? ((1u << d->logN) - (1u << d->s0)) : 0;
+        d->arena_wave_words = lmax * d->arena_path_stride;
         d->scl_wpb = 1;
     }
 }
@@ -215,7 +241,11 @@ int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     P.prog = d->d_scl_prog;
     P.wave_lds_words = d->scl_wave_words;
     P.path_stride = d->path_stride;
-    P.wpp = d->wpp;
+    P.wppL = d->wppL;
+    P.wppR = d->wppR;
+    P.s0 = d->s0;
+    P.arena_path_stride = d->arena_path_stride;
+    P.arena_wave_words = d->arena_wave_words;
     const size_t lds = (size_t)d->scl_wpb * d->scl_wave_words * 4;
     if (d->scl_blocks_per_cu == 0) {
         const size_t by_lds = kMaxLds / lds;
@@ -224,6 +254,11 @@ int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     }
     const unsigned need = (unsigned)((P.rows + d->scl_wpb - 1) / d->scl_wpb);
     const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->scl_blocks_per_cu)));
+    if (d->arena_wave_words) {
+        int rc = grow(d->d_arena, d->d_arena_cap, (size_t)grid * d->scl_wpb * d->arena_wave_words * sizeof(float));
+        if (rc) return rc;
+    }
+    P.arena = d->d_arena;
     HIP_TRY(pamd::launch_scl(P, d->lpl, i8, grid, d->scl_wpb, lds, st));
     return PCD_OK;
 }
@@ -414,6 +449,7 @@ void pcd_destroy(pcd_decoder* d)
     if (d->d_ok) (void)hipFree(d->d_ok);
     if (d->d_met) (void)hipFree(d->d_met);
     if (d->d_list) (void)hipFree(d->d_list);
+    if (d->d_arena) (void)hipFree(d->d_arena);
     delete d;
 }
 
@@ -539,6 +575,38 @@ int pcd_scl_trace(pcd_decoder* d, const float* llr_row, float* trace, unsigned c
         HIP_TRY(hipMemcpy(trace, dtrace, tb, hipMemcpyDeviceToHost));
     }
     (void)hipFree(dtrace);
+    return rc;
+}
+
+int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
+                    unsigned cap, unsigned* count)
+{
+    if (!d || !llr_row || !cycles || !count) return fail(PCD_ERR_INVALID_ARG, "null argument");
+    if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "not a list decoder");
+    int rc = ensure_device(d);
+    if (rc) return rc;
+    const unsigned n = (unsigned)d->scl_prog.ins.size();
+    *count = n;
+    uint32_t* dcyc = nullptr;
+    if ((rc = grow(d->d_in, d->d_in_cap, (size_t)d->N * 4))) return rc;
+    if ((rc = grow(d->d_out, d->d_out_cap, d->nb))) return rc;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dcyc), (size_t)n * 4));
+    HIP_TRY(hipMemset(dcyc, 0, (size_t)n * 4));
+    HIP_TRY(hipMemcpy(d->d_in, llr_row, (size_t)d->N * 4, hipMemcpyHostToDevice));
+    pamd::DecodeParams P = base_params(d, d->d_in, 1, d->d_out, nullptr, nullptr);
+    P.cycles = dcyc;
+    for (int rep = 0; rep < 2 && !rc; ++rep) rc = run_scl(d, P, false, nullptr);  // second run: warm caches
+    if (!rc) {
+        HIP_TRY(hipDeviceSynchronize());
+        std::vector<uint32_t> h(n);
+        HIP_TRY(hipMemcpy(h.data(), dcyc, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (unsigned i = 0; i < n && i < cap; ++i) {
+            cycles[i] = h[i];
+            if (ops) ops[i] = d->scl_prog.ins[i].op;
+            if (stages) stages[i] = d->scl_prog.ins[i].stage;
+        }
+    }
+    (void)hipFree(dcyc);
     return rc;
 }
 

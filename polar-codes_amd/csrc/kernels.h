@@ -21,10 +21,14 @@ struct DecodeParams {
     uint32_t det_on;         // 0 = dummy detector (always passes)
     uint32_t systematic;
     uint32_t path_stride;    // SCL: floats per path LLR buffer (N + bank padding)
-    uint32_t wpp;            // SCL: bit words per path and area (padded odd)
+    uint32_t wppL, wppR;     // SCL: bit words per path in the left-child / right-child output areas
+    float* arena;            // SCL: global scratch for LLR stages >= s0 (one slice per resident wave)
+    uint32_t arena_wave_words, arena_path_stride;
+    uint32_t s0;             // SCL: first LLR stage kept in the arena (logN = none)
     uint32_t wave_lds_words; // LDS words one wave (one codeword) owns
     float* trace;            // diagnostics (nullable): row 0 only, (1 + L) floats after every SCL leaf
     uint32_t trace_cap;
+    uint32_t* cycles;        // diagnostics (nullable): row 0 only, s_memtime cycles spent per program instruction
 };
 
 hipError_t launch_sc(const DecodeParams& P, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,

@@ -29,6 +29,10 @@ namespace pamd {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
+// the decode program is read-only for the whole launch: reading it through the constant address space lets
+// the compiler use scalar loads (s_load_dwordx2 through the scalar cache) instead of per-lane vector loads
+typedef const uint64_t __attribute__((address_space(4))) * const_u64_ptr;
+
 __device__ __forceinline__ uint32_t fbits(float x) { return __float_as_uint(x); }
 __device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t sgn(float x) { return __float_as_uint(x) >> 31; }
@@ -67,6 +71,71 @@ __device__ __forceinline__ uint64_t shflx_u64(uint64_t v, int m)
     const uint32_t lo = shflx_u32((uint32_t)v, m), hi = shflx_u32((uint32_t)(v >> 32), m);
     return ((uint64_t)hi << 32) | lo;
 }
+
+// ---- cross-lane primitives that stay on the VALU (DPP / readlane) -------------------------------------
+// ds_bpermute (__shfl) takes an LDS round trip (~100+ cycles, and this kernel runs ~1 wave per SIMD, so
+// nothing hides it); DPP modifiers and v_readlane cost a VALU slot.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+// partner value for an all-reduce step over 2M-lane groups.  M = 1, 2: lane ^ M (quad_perm);
+// M = 4: row_half_mirror, M = 8: row_mirror -- the mirrored lane sits in the other half, which is all an
+// all-reduce needs once the halves are uniform; M = 16, 32: ds_bpermute.
+template <int M>
+__device__ __forceinline__ uint32_t partner_u32(uint32_t v)
+{
+    if constexpr (M == 1)
+        return dpp_u32<0xB1>(v);
+    else if constexpr (M == 2)
+        return dpp_u32<0x4E>(v);
+    else if constexpr (M == 4)
+        return dpp_u32<0x141>(v);
+    else if constexpr (M == 8)
+        return dpp_u32<0x140>(v);
+    else
+        return shflx_u32(v, M);
+}
+template <int M>
+__device__ __forceinline__ uint64_t partner_u64(uint64_t v)
+{
+    return ((uint64_t)partner_u32<M>((uint32_t)(v >> 32)) << 32) | partner_u32<M>((uint32_t)v);
+}
+#define PAMD_GROUP_REDUCE(T, NAME, PARTNER, EXPR)                          \
+    template <int G>                                                       \
+    __device__ __forceinline__ T NAME(T v)                                 \
+    {                                                                      \
+        if constexpr (G > 1) { const T o = PARTNER<1>(v); v = (EXPR); }    \
+        if constexpr (G > 2) { const T o = PARTNER<2>(v); v = (EXPR); }    \
+        if constexpr (G > 4) { const T o = PARTNER<4>(v); v = (EXPR); }    \
+        if constexpr (G > 8) { const T o = PARTNER<8>(v); v = (EXPR); }    \
+        if constexpr (G > 16) { const T o = PARTNER<16>(v); v = (EXPR); }  \
+        if constexpr (G > 32) { const T o = PARTNER<32>(v); v = (EXPR); }  \
+        return v;                                                          \
+    }
+PAMD_GROUP_REDUCE(uint32_t, group_xor_u32, partner_u32, v ^ o)
+PAMD_GROUP_REDUCE(uint32_t, group_or_u32, partner_u32, v | o)
+PAMD_GROUP_REDUCE(uint32_t, group_max_u32, partner_u32, o > v ? o : v)
+PAMD_GROUP_REDUCE(uint64_t, group_min_u64, partner_u64, o < v ? o : v)
+
+// wave-wide maximum of a u32 as a wave-uniform value: DPP inside the 16-lane rows, then 4 readlanes
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = group_max_u32<16>(v);
+    const uint32_t a = readlane_u32(v, 0), b = readlane_u32(v, 16), c = readlane_u32(v, 32), d = readlane_u32(v, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+// order-preserving map float -> u32 (and back); -0.0 is folded onto +0.0 (they compare equal)
+__device__ __forceinline__ uint32_t okey(float f)
+{
+    uint32_t b = fbits(f);
+    b = (b == 0x80000000u) ? 0u : b;
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unkey(uint32_t k) { return bitsf((k >> 31) ? (k ^ 0x80000000u) : ~k); }
 
 __device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
 {
@@ -182,6 +251,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
     const uint32_t N = P.N;
     const uint32_t nwords = N >= 32 ? (N >> 5) : 1u;
     const uint32_t wave0 = blockIdx.x * wpb + wib, nwaves = gridDim.x * wpb;
+    const const_u64_ptr prog64 = (const_u64_ptr)(uintptr_t)P.prog;
 
     for (uint32_t cw = wave0; cw < P.rows; cw += nwaves) {
         const uint32_t row = P.rowidx ? P.rowidx[cw] : cw;
@@ -201,9 +271,16 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
         }
         WAVE_SYNC();
 
+        uint64_t iw_next = prog64[0];
         for (uint32_t pc = 0;; ++pc) {
-            const Ins ins = P.prog[pc];
+            const uint64_t iw = iw_next;
+            Ins ins;
+            ins.op = (uint8_t)(iw & 0xFF);
             if (ins.op == OP_END) break;
+            iw_next = prog64[pc + 1];  // scalar load, in flight while this instruction executes
+            ins.stage = (uint8_t)((iw >> 8) & 0xFF);
+            ins.side = (uint8_t)((iw >> 16) & 0xFF);
+            ins.off = (uint32_t)(iw >> 32);
             const uint32_t s = ins.stage, n = 1u << s, h = n >> 1, off = ins.off;
             const float* x = llr + n;  // this block's input LLRs
             switch (ins.op) {
@@ -495,17 +572,30 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
 
 __device__ __forceinline__ uint32_t woff(uint32_t t) { return t <= 5 ? t : ((1u << (t - 5)) + 4u); }
 
-template <int LPL, bool I8, bool ROOT>
-struct LlrSrc {
-    const void* g;   // channel row (ROOT)
-    const float* l;  // LDS stage buffer (!ROOT)
+// LLR sources / destinations by memory space.  Stage buffers live in LDS for stages < s0, in the per-wave
+// global "arena" (L2-resident scratch) for s0 <= stage < logN, and stage logN is the channel row itself.
+typedef float __attribute__((address_space(3))) lds_f32;
+enum { K_LDS = 0, K_GF32 = 1, K_GI8 = 2, K_ARENA = 3 };
+template <int KIND>
+struct Rd {
+    const void* p;
     __device__ __forceinline__ float operator[](uint32_t i) const
     {
-        if (ROOT) {
-            if (I8) return (float)reinterpret_cast<const int8_t*>(g)[i];
-            return reinterpret_cast<const float*>(g)[i];
-        }
-        return l[i];
+        if constexpr (KIND == K_LDS) return ((const lds_f32*)(uintptr_t)p)[i];
+        else if constexpr (KIND == K_GI8) return (float)reinterpret_cast<const int8_t*>(p)[i];
+        else if constexpr (KIND == K_ARENA)
+            // written earlier by other lanes of this wave: read at L2 (sc1), never from a stale L1 line
+            return __hip_atomic_load(reinterpret_cast<const float*>(p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return reinterpret_cast<const float*>(p)[i];
+    }
+};
+template <int KIND>
+struct Wr {
+    void* p;
+    __device__ __forceinline__ void set(uint32_t i, float v) const
+    {
+        if constexpr (KIND == K_LDS) ((lds_f32*)(uintptr_t)p)[i] = v;
+        else reinterpret_cast<float*>(p)[i] = v;
     }
 };
 
@@ -519,7 +609,10 @@ struct SclCtx {
     float* llr;
     uint32_t* bitsL;
     uint32_t* bitsR;
-    uint32_t path_stride, wpp;
+    uint32_t path_stride, wppL, wppR;
+    float* arena;  // this wave's global scratch (stages >= s0)
+    uint32_t arena_path_stride, s0, logN;
+    const void* chan;
     int lane, p, j, base;
     uint32_t P;      // live paths (wave uniform)
     uint32_t L;      // list size limit
@@ -529,7 +622,34 @@ struct SclCtx {
     __device__ __forceinline__ float* path_llr(uint32_t q) const { return llr + (size_t)q * path_stride; }
     __device__ __forceinline__ uint32_t* area(uint32_t side, uint32_t q) const
     {
-        return (side ? bitsR : bitsL) + (size_t)q * wpp;
+        return side ? bitsR + (size_t)q * wppR : bitsL + (size_t)q * wppL;
+    }
+    __device__ __forceinline__ float* arena_stage(uint32_t q, uint32_t t) const
+    {
+        return arena + (size_t)q * arena_path_stride + ((1u << t) - (1u << s0));
+    }
+    // call fn(accessor) with the reader for the stage-t LLRs of path buffer q
+    template <bool I8, typename F>
+    __device__ __forceinline__ void with_src(uint32_t t, uint32_t q, F&& fn) const
+    {
+        if (t == logN) {
+            if constexpr (I8)
+                fn(Rd<K_GI8>{ chan });
+            else
+                fn(Rd<K_GF32>{ chan });
+        } else if (t >= s0) {
+            fn(Rd<K_ARENA>{ arena_stage(q, t) });
+        } else {
+            fn(Rd<K_LDS>{ path_llr(q) + (1u << t) });
+        }
+    }
+    template <typename F>
+    __device__ __forceinline__ void with_dst(uint32_t t, uint32_t q, F&& fn) const
+    {
+        if (t >= s0)
+            fn(Wr<K_GF32>{ arena_stage(q, t) });
+        else
+            fn(Wr<K_LDS>{ path_llr(q) + (1u << t) });
     }
     __device__ __forceinline__ uint32_t field(uint64_t sl, uint32_t s) const
     {
@@ -546,6 +666,18 @@ struct SclCtx {
     // acc[] holds this lane's accumulators: virtual AVX lane v = j + LP*a  (LP < 8) or v = j (LP >= 8)
     __device__ __forceinline__ float lanesum_finish(const float acc[NACC]) const
     {
+        if constexpr (LP == 8) {
+            // own quad's four accumulators by quad_perm broadcast, the other quad's by row_half_mirror
+            const uint32_t a = fbits(acc[0]);
+            const uint32_t b0 = dpp_u32<0x00>(a), b1 = dpp_u32<0x55>(a), b2 = dpp_u32<0xAA>(a), b3 = dpp_u32<0xFF>(a);
+            const uint32_t o0 = dpp_u32<0x141>(b0), o1 = dpp_u32<0x141>(b1), o2 = dpp_u32<0x141>(b2),
+                           o3 = dpp_u32<0x141>(b3);
+            const bool hi = (j & 4) != 0;
+            const float x0 = bitsf(hi ? o0 : b0), x1 = bitsf(hi ? o1 : b1), x2 = bitsf(hi ? o2 : b2),
+                        x3 = bitsf(hi ? o3 : b3), x4 = bitsf(hi ? b0 : o0), x5 = bitsf(hi ? b1 : o1),
+                        x6 = bitsf(hi ? b2 : o2), x7 = bitsf(hi ? b3 : o3);
+            return ((((((x0 + x1) + x2) + x3) + x4) + x5) + x6) + x7;
+        }
         float s = 0.0f;
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
@@ -608,12 +740,7 @@ __device__ __forceinline__ void find_weak(const SclCtx<LPL>& c, const SRC& x, ui
     for (int i = 0; i < CNT; ++i) {
         if ((uint32_t)i < lim) {
             // best tail candidate of the path: lexicographic (value, position) minimum over LP lanes
-            uint64_t key = ((uint64_t)tv[0] << 32) | tp[0];
-#pragma unroll
-            for (int m = 1; m < LP; m <<= 1) {
-                const uint64_t o = shflx_u64(key, m);
-                key = o < key ? o : key;
-            }
+            const uint64_t key = group_min_u64<LP>(((uint64_t)tv[0] << 32) | tp[0]);
             // best head candidate among positions i..CNT-1 (first occurrence)
             int hk = i;
 #pragma unroll
@@ -622,9 +749,7 @@ __device__ __forceinline__ void find_weak(const SclCtx<LPL>& c, const SRC& x, ui
             const uint32_t tval = (uint32_t)(key >> 32), tpos = (uint32_t)key;
             // owner lane / original index of the best tail candidate (shuffles kept unconditional)
             const bool mine = (tv[0] == tval) && (tp[0] == tpos) && (tval != INFB);
-            const uint64_t bal = ballot64(mine) >> c.base;
-            const int wl = __ffsll((long long)(bal & ((LP == 64) ? ~0ull : ((1ull << LP) - 1ull)))) - 1;
-            const uint32_t worig = shfl_u32(to[0], c.base + (wl < 0 ? 0 : wl));
+            const uint32_t worig = group_or_u32<LP>(mine ? to[0] : 0u);
             if (tval < hv[hk]) {  // a tail position wins (head positions precede on ties)
                 const uint32_t dv = hv[i], dorig = ho[i];
                 if (mine) {  // pop the winner, insert the displaced head element at position tpos
@@ -773,6 +898,65 @@ __device__ __forceinline__ void select_paths(const SclCtx<LPL>& c, float (&val)[
     nidx = x;
 }
 
+// Same selection for the common case of at most one candidate per lane (CPP <= LP): everything that is
+// wave-uniform (maximum, winner lane, the lane holding position i) lives in SGPRs via DPP + v_readlane, and the
+// winner of iteration i IS what new path i inherits, so no permute is needed afterwards.
+template <int LPL, int CPP>
+__device__ __forceinline__ void select_paths_1(const SclCtx<LPL>& c, float val, uint32_t newP, float& nval,
+                                               uint32_t& nidx)
+{
+    constexpr int LP = SclCtx<LPL>::LP;
+    static_assert(CPP <= LP, "one candidate per lane");
+    constexpr int CS = CPP == 8 ? 3 : (CPP == 4 ? 2 : 1);
+    const uint32_t size = c.P * CPP;
+    const bool valid = ((uint32_t)c.j < (uint32_t)CPP) && ((uint32_t)c.p < c.P);
+    const uint32_t pos = ((uint32_t)c.p << CS) + (uint32_t)c.j;
+    uint32_t key = valid ? okey(val) : 0u;
+    uint32_t idx = pos;
+    uint32_t rkey = 0, ridx = 0;
+    const uint32_t lim = (size - 1 < newP) ? size - 1 : newP;
+    for (uint32_t i = 0; i < lim; ++i) {
+        const bool el = valid && pos >= i;
+        const uint32_t m = wave_max_u32(el ? key : 0u);
+        const uint64_t bal = ballot64(el && key == m);
+        const int wl = __ffsll((long long)bal) - 1;                  // lowest lane = lowest position
+        const int li = (int)(((i >> CS) << LPL) + (i & (CPP - 1)));   // lane holding position i
+        const uint32_t ki = readlane_u32(key, li), xi = readlane_u32(idx, li), xw = readlane_u32(idx, wl);
+        if (c.lane == wl) {
+            key = ki;
+            idx = xi;
+        }
+        if (c.lane == li) {
+            key = m;
+            idx = xw;
+        }
+        if ((uint32_t)c.p == i) {
+            rkey = m;
+            ridx = xw;
+        }
+    }
+    if (lim < newP) {  // every candidate survives: the last position keeps what is left there
+        const int ll = (int)(((lim >> CS) << LPL) + (lim & (CPP - 1)));
+        const uint32_t kl = readlane_u32(key, ll), xl = readlane_u32(idx, ll);
+        if ((uint32_t)c.p == lim) {
+            rkey = kl;
+            ridx = xl;
+        }
+    }
+    nval = unkey(rkey);
+    nidx = ridx;
+}
+
+template <int LPL, int CPP>
+__device__ __forceinline__ void select_dispatch(const SclCtx<LPL>& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
+                                                uint32_t newP, float& nval, uint32_t& nidx)
+{
+    if constexpr (CPP <= (1 << LPL))
+        select_paths_1<LPL, CPP>(c, val[0], newP, nval, nidx);
+    else
+        select_paths<LPL, CPP>(c, val, newP, nval, nidx);
+}
+
 // write the n leaf bits of every (new) path: sign(x_src[i]) ^ flips, packed, into area(side)[stage]
 // flips: up to 4 positions (fmask bit k enables fpos[k]);  REP passes n_from_llr = false
 template <int LPL, typename SRC>
@@ -817,9 +1001,14 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
     Ctx c;
     c.llr = reinterpret_cast<float*>(wl);
     c.bitsL = wl + (size_t)LMAX * P.path_stride;
-    c.bitsR = c.bitsL + (size_t)LMAX * P.wpp;
+    c.bitsR = c.bitsL + (size_t)LMAX * P.wppL;
     c.path_stride = P.path_stride;
-    c.wpp = P.wpp;
+    c.wppL = P.wppL;
+    c.wppR = P.wppR;
+    c.arena = P.arena + (size_t)(blockIdx.x * wpb + wib) * P.arena_wave_words;
+    c.arena_path_stride = P.arena_path_stride;
+    c.s0 = P.s0;
+    c.logN = P.logN;
     c.lane = lane;
     c.p = lane >> LPL;
     c.j = lane & (LP - 1);
@@ -827,47 +1016,49 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
     c.L = P.L;
     const uint32_t N = P.N, logN = P.logN;
     const uint32_t wave0 = blockIdx.x * wpb + wib, nwaves = gridDim.x * wpb;
+    const const_u64_ptr prog64 = (const_u64_ptr)(uintptr_t)P.prog;
 
     for (uint32_t cw = wave0; cw < P.rows; cw += nwaves) {
         const uint32_t row = P.rowidx ? P.rowidx[cw] : cw;
         const void* chan = I8 ? (const void*)(reinterpret_cast<const int8_t*>(P.llr) + (size_t)row * N)
                               : (const void*)(reinterpret_cast<const float*>(P.llr) + (size_t)row * N);
+        c.chan = chan;
         // makeInitialPathList :705-709 -- one path, metric 0 (fresh decoder)
         c.P = 1;
         c.metric = 0.0f;
         c.slot = 0;
         uint32_t trace_n = 0;
 
+        uint64_t iw_next = prog64[0];
         for (uint32_t pc = 0;; ++pc) {
-            const Ins ins = P.prog[pc];
+            const uint64_t iw = iw_next;
+            Ins ins;
+            ins.op = (uint8_t)(iw & 0xFF);
             if (ins.op == OP_END) break;
+            iw_next = prog64[pc + 1];  // scalar load, in flight while this instruction executes
+            ins.stage = (uint8_t)((iw >> 8) & 0xFF);
+            ins.side = (uint8_t)((iw >> 16) & 0xFF);
             const uint32_t s = ins.stage, n = 1u << s, h = n >> 1, side = ins.side;
-            const bool root = (s == logN);
             const bool active = (uint32_t)c.p < c.P;
+            uint64_t t_start = 0;
+            if (P.cycles && cw == 0) t_start = __builtin_amdgcn_s_memtime();
 
             switch (ins.op) {
             // ------------------------------------------------------------------ inner node ops
             case SCL_F: {  // RateRNode::decode :233-238 -- reads the path's own (identity) buffer
                 if (h >= 64) {
-                    for (uint32_t q = 0; q < c.P; ++q) {
-                        float* dst = c.path_llr(q) + h;
-                        if (root) {
-                            LlrSrc<LPL, I8, true> x{ chan, nullptr };
-                            for (uint32_t i = lane; i < h; i += 64) dst[i] = polar_f(x[i], x[h + i]);
-                        } else {
-                            const float* x = c.path_llr(q) + n;
-                            for (uint32_t i = lane; i < h; i += 64) dst[i] = polar_f(x[i], x[h + i]);
-                        }
-                    }
+                    for (uint32_t q = 0; q < c.P; ++q)
+                        c.template with_src<I8>(s, q, [&](auto x) {
+                            c.with_dst(s - 1, q, [&](auto d) {
+                                for (uint32_t i = lane; i < h; i += 64) d.set(i, polar_f(x[i], x[h + i]));
+                            });
+                        });
                 } else if (active) {
-                    float* dst = c.path_llr(c.p) + h;
-                    if (root) {
-                        LlrSrc<LPL, I8, true> x{ chan, nullptr };
-                        for (uint32_t i = c.j; i < h; i += LP) dst[i] = polar_f(x[i], x[h + i]);
-                    } else {
-                        const float* x = c.path_llr(c.p) + n;
-                        for (uint32_t i = c.j; i < h; i += LP) dst[i] = polar_f(x[i], x[h + i]);
-                    }
+                    c.template with_src<I8>(s, c.p, [&](auto x) {
+                        c.with_dst(s - 1, c.p, [&](auto d) {
+                            for (uint32_t i = c.j; i < h; i += LP) d.set(i, polar_f(x[i], x[h + i]));
+                        });
+                    });
                 }
                 c.set_field(s);
                 break;
@@ -876,32 +1067,25 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                 const uint32_t wo = woff(s - 1);
                 if (h >= 64) {
                     for (uint32_t q = 0; q < c.P; ++q) {
-                        const uint32_t srcq = c.field(shfl_u64(c.slot, (int)(q << LPL)), s);
-                        float* dst = c.path_llr(q) + h;
+                        const uint32_t srcq = c.field(((uint64_t)readlane_u32((uint32_t)(c.slot >> 32), (int)(q << LPL)) << 32) |
+                                                          readlane_u32((uint32_t)c.slot, (int)(q << LPL)), s);
                         const uint32_t* lb = c.area(0, q) + wo;
-                        if (root) {
-                            LlrSrc<LPL, I8, true> x{ chan, nullptr };
-                            for (uint32_t i = lane; i < h; i += 64)
-                                dst[i] = polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u);
-                        } else {
-                            const float* x = c.path_llr(srcq) + n;
-                            for (uint32_t i = lane; i < h; i += 64)
-                                dst[i] = polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u);
-                        }
+                        c.template with_src<I8>(s, srcq, [&](auto x) {
+                            c.with_dst(s - 1, q, [&](auto d) {
+                                for (uint32_t i = lane; i < h; i += 64)
+                                    d.set(i, polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u));
+                            });
+                        });
                     }
                 } else if (active) {
                     const uint32_t srcq = c.field(c.slot, s);
-                    float* dst = c.path_llr(c.p) + h;
                     const uint32_t* lb = c.area(0, c.p) + wo;
-                    if (root) {
-                        LlrSrc<LPL, I8, true> x{ chan, nullptr };
-                        for (uint32_t i = c.j; i < h; i += LP)
-                            dst[i] = polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u);
-                    } else {
-                        const float* x = c.path_llr(srcq) + n;
-                        for (uint32_t i = c.j; i < h; i += LP)
-                            dst[i] = polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u);
-                    }
+                    c.template with_src<I8>(s, srcq, [&](auto x) {
+                        c.with_dst(s - 1, c.p, [&](auto d) {
+                            for (uint32_t i = c.j; i < h; i += LP)
+                                d.set(i, polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u));
+                        });
+                    });
                 }
                 c.set_field(s);  // from now on the field names the holder of the LEFT bits
                 break;
@@ -941,10 +1125,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                             if (v >= n) acc[a] = acc[a] + 0.0f;
                         }
                     };
-                    if (root)
-                        body(LlrSrc<LPL, I8, true>{ chan, nullptr });
-                    else
-                        body(LlrSrc<LPL, I8, false>{ nullptr, c.path_llr(c.p) + n });
+                    c.template with_src<I8>(s, c.p, body);
                 }
                 const float sum = c.lanesum_finish(acc);
                 if (active) {
@@ -969,10 +1150,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                             ao[a] = ao[a] + max0(xv);
                         }
                     };
-                    if (root)
-                        body(LlrSrc<LPL, I8, true>{ chan, nullptr });
-                    else
-                        body(LlrSrc<LPL, I8, false>{ nullptr, c.path_llr(c.p) + n });
+                    c.template with_src<I8>(s, c.p, body);
                 }
                 const float z = c.lanesum_finish(az), o = c.lanesum_finish(ao);
                 constexpr int CPL = (2 >> LPL) ? (2 >> LPL) : 1;
@@ -985,7 +1163,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                 const uint32_t newP = (c.P * 2 < c.L) ? c.P * 2 : c.L;
                 float nval;
                 uint32_t nidx;
-                select_paths<LPL, 2>(c, val, newP, nval, nidx);
+                select_dispatch<LPL, 2>(c, val, newP, nval, nidx);
                 const uint32_t srcp = nidx >> 1, q = nidx & 1u;
                 const uint64_t nslot = shfl_u64(c.slot, (int)(srcp << LPL));
                 c.P = newP;
@@ -1006,9 +1184,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                         find_weak<LPL, 4>(c, x, n, wk);
                         uint32_t pb = 0;
                         for (uint32_t i = c.j; i < n; i += LP) pb ^= sgn(x[i]);
-#pragma unroll
-                        for (int m = 1; m < LP; m <<= 1) pb ^= shflx_u32(pb, m);
-                        par = pb & 1u;
+                        par = group_xor_u32<LP>(pb) & 1u;
                     } else {
                         Weak<2> w2;
                         find_weak<LPL, 2>(c, x, n, w2);
@@ -1020,10 +1196,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                         wk.ix[2] = wk.ix[3] = 0;
                     }
                 };
-                if (root)
-                    search(LlrSrc<LPL, I8, true>{ chan, nullptr });
-                else
-                    search(LlrSrc<LPL, I8, false>{ nullptr, c.path_llr(c.p) + n });
+                c.template with_src<I8>(s, c.p, search);
                 const float v0 = bitsf(wk.v[0]), v1 = bitsf(wk.v[1]), v2 = bitsf(wk.v[2]), v3 = bitsf(wk.v[3]);
                 uint32_t nidx;
                 float nval;
@@ -1050,7 +1223,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                         val[r] = t;
                     }
                     newP = (c.P * 8 < c.L) ? c.P * 8 : c.L;
-                    select_paths<LPL, 8>(c, val, newP, nval, nidx);
+                    select_dispatch<LPL, 8>(c, val, newP, nval, nidx);
                 } else {
                     constexpr int CPL = (4 >> LPL) ? (4 >> LPL) : 1;
                     float val[CPL];
@@ -1068,16 +1241,17 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                         val[r] = t;
                     }
                     newP = (c.P * 4 < c.L) ? c.P * 4 : c.L;
-                    select_paths<LPL, 4>(c, val, newP, nval, nidx);
+                    select_dispatch<LPL, 4>(c, val, newP, nval, nidx);
                 }
                 const uint32_t srcp = spc ? (nidx >> 3) : (nidx >> 2);
                 const uint32_t q = spc ? (nidx & 7u) : (nidx & 3u);
                 const int sl = (int)(srcp << LPL);
                 const uint64_t nslot = shfl_u64(c.slot, sl);
-                uint32_t fpos[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) fpos[k] = shfl_u32(wk.ix[k], sl);
-                const uint32_t spar = shfl_u32(par, sl);
+                // flip positions (< 2^15 each) and the parity travel packed in two registers
+                const uint32_t pk0 = shfl_u32(wk.ix[0] | (wk.ix[1] << 16), sl);
+                const uint32_t pk1 = shfl_u32(wk.ix[2] | (wk.ix[3] << 16) | (par << 31), sl);
+                const uint32_t fpos[4] = { pk0 & 0xFFFFu, pk0 >> 16, pk1 & 0xFFFFu, (pk1 >> 16) & 0x7FFFu };
+                const uint32_t spar = pk1 >> 31;
                 uint32_t fmask;
                 if (spc) {
                     // flip sets :533-585 as bit masks over {i0,i1,i2,i3}; odd parity toggles i0
@@ -1093,16 +1267,22 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                     c.slot = nslot;
                 }
                 // bits of the new path = signs of the SOURCE path's LLRs (identity buffer) with flips
-                if (root)
-                    write_leaf_bits<LPL>(c, LlrSrc<LPL, I8, true>{ chan, nullptr }, s, side, nact, fmask, fpos);
-                else
-                    write_leaf_bits<LPL>(c, LlrSrc<LPL, I8, false>{ nullptr, c.path_llr(srcp) + n }, s, side, nact,
-                                         fmask, fpos);
+                c.template with_src<I8>(s, srcp, [&](auto x) { write_leaf_bits<LPL>(c, x, s, side, nact, fmask, fpos); });
                 break;
             }
             default: break;
             }
+            if (ins.op <= SCL_G && s - 1 >= c.s0) {
+                // this op stored LLRs to the global arena: wait for the stores (L2 is the meeting point; the
+                // arena is read back with sc1 loads)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             WAVE_SYNC();
+            if (P.cycles && cw == 0) {
+                const uint64_t t_end = __builtin_amdgcn_s_memtime();
+                if (lane == 0) P.cycles[pc] = (uint32_t)(t_end - t_start);
+            }
             if (P.trace && cw == 0 && ins.op >= SCL_R0) {
                 if (trace_n < P.trace_cap) {
                     float* t = P.trace + (size_t)trace_n * (1 + P.L);

@@ -26,7 +26,7 @@ C_SYMBOLS = [
     "pcd_create", "pcd_destroy", "pcd_set_error_detection", "pcd_set_systematic", "pcd_is_systematic",
     "pcd_block_length", "pcd_info_length", "pcd_list_size", "pcd_frozen_bits", "pcd_error_detection_mode",
     "pcd_out_bytes", "pcd_decode_f32", "pcd_decode_i8", "pcd_program_stats", "pcd_launch_info",
-    "pcd_set_timing", "pcd_kernel_times", "pcd_scl_trace", "pcd_last_error", "pcd_version",
+    "pcd_set_timing", "pcd_kernel_times", "pcd_scl_trace", "pcd_scl_profile", "pcd_last_error", "pcd_version",
 ]
 
 
@@ -82,6 +82,8 @@ def load_library():
     lib.pcd_kernel_times.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.pcd_scl_trace.restype = C.c_int
     lib.pcd_scl_trace.argtypes = [vp, vp, vp, C.c_uint]
+    lib.pcd_scl_profile.restype = C.c_int
+    lib.pcd_scl_profile.argtypes = [vp, vp, vp, vp, vp, C.c_uint, C.POINTER(C.c_uint)]
     lib.pcd_last_error.restype = C.c_char_p
     lib.pcd_version.restype = C.c_char_p
     _lib = lib
@@ -265,6 +267,18 @@ class PolarDecoder:
         if rc:
             _raise(rc)
         return tr
+
+    def scl_profile(self, llr_row, cap=8192):
+        """diagnostics: (ops, stages, cycles) per SCL program instruction for one row"""
+        a = np.ascontiguousarray(llr_row, dtype=np.float32)
+        ops = np.zeros(cap, np.uint8); st = np.zeros(cap, np.uint8); cyc = np.zeros(cap, np.uint32)
+        n = C.c_uint()
+        rc = self._lib.pcd_scl_profile(self._h, a.ctypes.data_as(C.c_void_p), ops.ctypes.data_as(C.c_void_p),
+                                       st.ctypes.data_as(C.c_void_p), cyc.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+        if rc:
+            _raise(rc)
+        k = min(cap, n.value)
+        return ops[:k], st[:k], cyc[:k]
 
     def set_timing(self, enable=True):
         self._lib.pcd_set_timing(self._h, int(bool(enable)))
