@@ -590,16 +590,25 @@ int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t*
     uint32_t* dcyc = nullptr;
     if ((rc = grow(d->d_in, d->d_in_cap, (size_t)d->N * 4))) return rc;
     if ((rc = grow(d->d_out, d->d_out_cap, d->nb))) return rc;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dcyc), (size_t)n * 4));
-    HIP_TRY(hipMemset(dcyc, 0, (size_t)n * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dcyc), (size_t)n * 5 * 4));
+    HIP_TRY(hipMemset(dcyc, 0, (size_t)n * 5 * 4));
     HIP_TRY(hipMemcpy(d->d_in, llr_row, (size_t)d->N * 4, hipMemcpyHostToDevice));
     pamd::DecodeParams P = base_params(d, d->d_in, 1, d->d_out, nullptr, nullptr);
     P.cycles = dcyc;
+    P.prog_len = n;
     for (int rep = 0; rep < 2 && !rc; ++rep) rc = run_scl(d, P, false, nullptr);  // second run: warm caches
     if (!rc) {
         HIP_TRY(hipDeviceSynchronize());
-        std::vector<uint32_t> h(n);
-        HIP_TRY(hipMemcpy(h.data(), dcyc, (size_t)n * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> h((size_t)n * 5);
+        HIP_TRY(hipMemcpy(h.data(), dcyc, (size_t)n * 5 * 4, hipMemcpyDeviceToHost));
+        if (const char* dump = std::getenv("PCD_SUBPROFILE")) {  // leaf phase stamps (diagnostics)
+            if (FILE* f = std::fopen(dump, "w")) {
+                for (unsigned i = 0; i < n; ++i)
+                    std::fprintf(f, "%u %u %u %u %u %u %u\n", (unsigned)d->scl_prog.ins[i].op, (unsigned)d->scl_prog.ins[i].stage,
+                                 h[i], h[n + 4 * i], h[n + 4 * i + 1], h[n + 4 * i + 2], h[n + 4 * i + 3]);
+                std::fclose(f);
+            }
+        }
         for (unsigned i = 0; i < n && i < cap; ++i) {
             cycles[i] = h[i];
             if (ops) ops[i] = d->scl_prog.ins[i].op;

@@ -28,6 +28,7 @@ struct DecodeParams {
     uint32_t wave_lds_words; // LDS words one wave (one codeword) owns
     float* trace;            // diagnostics (nullable): row 0 only, (1 + L) floats after every SCL leaf
     uint32_t trace_cap;
+    uint32_t prog_len;
     uint32_t* cycles;        // diagnostics (nullable): row 0 only, s_memtime cycles spent per program instruction
 };
 

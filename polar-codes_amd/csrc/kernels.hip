@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace pamd {
@@ -78,7 +80,9 @@ __device__ __forceinline__ uint64_t shflx_u64(uint64_t v, int m)
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+    // every control used here (quad_perm, row_mirror, row_half_mirror) reads a valid lane, so the
+    // bound_ctrl form is exact and lets the compiler fold the move into the consuming VALU op (v_max_u32_dpp ...)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 // partner value for an all-reduce step over 2M-lane groups.  M = 1, 2: lane ^ M (quad_perm);
@@ -118,6 +122,7 @@ __device__ __forceinline__ uint64_t partner_u64(uint64_t v)
 PAMD_GROUP_REDUCE(uint32_t, group_xor_u32, partner_u32, v ^ o)
 PAMD_GROUP_REDUCE(uint32_t, group_or_u32, partner_u32, v | o)
 PAMD_GROUP_REDUCE(uint32_t, group_max_u32, partner_u32, o > v ? o : v)
+PAMD_GROUP_REDUCE(uint32_t, group_min_u32, partner_u32, o < v ? o : v)
 PAMD_GROUP_REDUCE(uint64_t, group_min_u64, partner_u64, o < v ? o : v)
 
 // wave-wide maximum of a u32 as a wave-uniform value: DPP inside the 16-lane rows, then 4 readlanes
@@ -127,6 +132,24 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     const uint32_t a = readlane_u32(v, 0), b = readlane_u32(v, 16), c = readlane_u32(v, 32), d = readlane_u32(v, 48);
     const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
     return ab > cd ? ab : cd;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = group_min_u32<16>(v);
+    const uint32_t a = readlane_u32(v, 0), b = readlane_u32(v, 16), c = readlane_u32(v, 32), d = readlane_u32(v, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+// value held by lane I of each 8-lane group, delivered to all 8 lanes (two DPP moves and a select)
+template <int I>
+__device__ __forceinline__ uint32_t group8_bcast(uint32_t v, int j)
+{
+    const uint32_t t = dpp_u32<(I & 3) * 0x55>(v);  // lane I&3 of each quad
+    const uint32_t u = dpp_u32<0x141>(t);           // ... of the other quad (row_half_mirror)
+    if constexpr (I < 4)
+        return (j < 4) ? t : u;
+    else
+        return (j < 4) ? u : t;
 }
 // order-preserving map float -> u32 (and back); -0.0 is folded onto +0.0 (they compare equal)
 __device__ __forceinline__ uint32_t okey(float f)
@@ -691,9 +714,13 @@ struct SclCtx {
 };
 
 // ---- weakest-LLR search: findWeakLlrs(idx, |x|, n, CNT) arrayfuncs.h:209-231 ----------------------
-// Literal emulation of the swap-mutating selection: positions 0..CNT-1 of the working array are
-// kept in path-uniform registers H*, positions >= CNT in per-lane sorted candidate lists; when a
-// tail position k wins iteration i, the displaced element H[i] takes its place (at position k).
+// The reference runs a swap-mutating selection: iteration i takes the first minimum among positions >= i
+// and SWAPS it with position i.  Only the elements that start at positions 0..CNT-1 ("head") can ever be
+// moved (to the position of a winner); everything else ("tail") stays where it is until it is selected.
+// So: head elements live in path-uniform registers together with their CURRENT position, each lane keeps
+// the CNT smallest (value, position) of its strided tail positions, and an iteration is
+//   winner = lexicographic min over {alive head (value, current position)} U {lane fronts};
+//   the head element sitting at position i moves to the winner's position; the winner leaves.
 template <int CNT>
 struct Weak {
     uint32_t v[CNT];   // value bits (|x|), ascending selection result
@@ -704,97 +731,90 @@ template <int LPL, int CNT, typename SRC>
 __device__ __forceinline__ void find_weak(const SclCtx<LPL>& c, const SRC& x, uint32_t n, Weak<CNT>& out)
 {
     constexpr int LP = SclCtx<LPL>::LP;
-    constexpr uint32_t INFB = 0xFFFFFFFFu;  // sentinel: larger than any |x| bit pattern
-    // head: positions 0..CNT-1 (uniform within the path)
-    uint32_t hv[CNT], ho[CNT];
+    constexpr uint32_t INFB = 0xFFFFFFFFu;  // larger than any |x| bit pattern / any position
+    uint32_t hv[CNT], hp[CNT];
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) {
-        hv[i] = (uint32_t)i < n ? (fbits(x[(uint32_t)i < n ? i : 0]) & 0x7FFFFFFFu) : INFB;
-        ho[i] = i;
+    for (int e = 0; e < CNT; ++e) {
+        const bool in = (uint32_t)e < n;
+        hv[e] = in ? (fbits(x[in ? e : 0]) & 0x7FFFFFFFu) : INFB;
+        hp[e] = in ? (uint32_t)e : INFB;
     }
-    // tail: this lane's CNT best of positions >= CNT (ascending by (value, position))
-    uint32_t tv[CNT], tp[CNT], to[CNT];
+    uint32_t tv[CNT], tp[CNT];
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) {
-        tv[i] = INFB;
-        tp[i] = INFB;
-        to[i] = 0;
+    for (int k = 0; k < CNT; ++k) {
+        tv[k] = INFB;
+        tp[k] = INFB;
     }
-    for (uint32_t i = (uint32_t)CNT + (uint32_t)c.j; i < n; i += LP) {
-        uint32_t a = fbits(x[i]) & 0x7FFFFFFFu, ap = i, ao = i;
+    const bool has_tail = n > (uint32_t)CNT;  // wave uniform
+    if (has_tail) {
+        for (uint32_t i = (uint32_t)CNT + (uint32_t)c.j; i < n; i += LP) {
+            uint32_t a = fbits(x[i]) & 0x7FFFFFFFu, ap = i;
+            bool placed = false;
 #pragma unroll
-        for (int k = 0; k < CNT; ++k) {  // sorted insert by (value, position); once the new element is
-                                         // placed the carried one keeps shifting (it precedes its successor)
-            const bool lt = (a < tv[k]) || (a == tv[k] && ap < tp[k]);
-            const uint32_t sv = lt ? tv[k] : a, sp = lt ? tp[k] : ap, so = lt ? to[k] : ao;
-            tv[k] = lt ? a : tv[k];
-            tp[k] = lt ? ap : tp[k];
-            to[k] = lt ? ao : to[k];
-            a = sv;
-            ap = sp;
-            ao = so;
+            for (int k = 0; k < CNT; ++k) {  // positions arrive ascending: strict '<' keeps earlier ones first
+                const bool lt = placed || (a < tv[k]);
+                const uint32_t sv = lt ? tv[k] : a, sp = lt ? tp[k] : ap;
+                tv[k] = lt ? a : tv[k];
+                tp[k] = lt ? ap : tp[k];
+                a = sv;
+                ap = sp;
+                placed = lt;
+            }
         }
     }
     const uint32_t lim = (n - 1 < (uint32_t)CNT) ? n - 1 : (uint32_t)CNT;
 #pragma unroll
     for (int i = 0; i < CNT; ++i) {
+        out.v[i] = hv[i];  // (only reached for i >= lim: what is left at position i)
+        out.ix[i] = i;
         if ((uint32_t)i < lim) {
-            // best tail candidate of the path: lexicographic (value, position) minimum over LP lanes
-            const uint64_t key = group_min_u64<LP>(((uint64_t)tv[0] << 32) | tp[0]);
-            // best head candidate among positions i..CNT-1 (first occurrence)
-            int hk = i;
+            uint32_t tvmin = INFB, tpmin = INFB;
+            if (has_tail) {
+                tvmin = group_min_u32<LP>(tv[0]);
+                tpmin = group_min_u32<LP>(tv[0] == tvmin ? tp[0] : INFB);
+            }
+            uint32_t bv = hv[0], bp = hp[0], be = 0;
 #pragma unroll
-            for (int k = i + 1; k < CNT; ++k)
-                if (hv[k] < hv[hk]) hk = k;
-            const uint32_t tval = (uint32_t)(key >> 32), tpos = (uint32_t)key;
-            // owner lane / original index of the best tail candidate (shuffles kept unconditional)
-            const bool mine = (tv[0] == tval) && (tp[0] == tpos) && (tval != INFB);
-            const uint32_t worig = group_or_u32<LP>(mine ? to[0] : 0u);
-            if (tval < hv[hk]) {  // a tail position wins (head positions precede on ties)
-                const uint32_t dv = hv[i], dorig = ho[i];
-                if (mine) {  // pop the winner, insert the displaced head element at position tpos
-                    uint32_t a = dv, ap = tpos, ao = dorig;
+            for (int e = 1; e < CNT; ++e) {
+                const bool lt = (hv[e] < bv) || (hv[e] == bv && hp[e] < bp);
+                bv = lt ? hv[e] : bv;
+                bp = lt ? hp[e] : bp;
+                be = lt ? (uint32_t)e : be;
+            }
+            const bool tail_wins = (tvmin < bv) || (tvmin == bv && tpmin < bp);
+            const uint32_t wv = tail_wins ? tvmin : bv, wp = tail_wins ? tpmin : bp;
+            out.v[i] = wv;
+            out.ix[i] = tail_wins ? wp : be;  // tail elements never move: original index = position
 #pragma unroll
-                    for (int k = 0; k < CNT - 1; ++k) {
-                        tv[k] = tv[k + 1];
-                        tp[k] = tp[k + 1];
-                        to[k] = to[k + 1];
-                    }
-                    tv[CNT - 1] = INFB;
-                    tp[CNT - 1] = INFB;
-                    to[CNT - 1] = 0;
+            for (int e = 0; e < CNT; ++e) {
+                const bool is_w = !tail_wins && be == (uint32_t)e;
+                const bool at_i = hp[e] == (uint32_t)i;
+                hp[e] = is_w ? INFB : (at_i ? wp : hp[e]);
+                hv[e] = is_w ? INFB : hv[e];
+            }
+            if (has_tail) {
+                const bool pop = tail_wins && tp[0] == wp;
 #pragma unroll
-                    for (int k = 0; k < CNT; ++k) {
-                        const bool lt = (a < tv[k]) || (a == tv[k] && ap < tp[k]);
-                        const uint32_t sv = lt ? tv[k] : a, sp = lt ? tp[k] : ap, so = lt ? to[k] : ao;
-                        tv[k] = lt ? a : tv[k];
-                        tp[k] = lt ? ap : tp[k];
-                        to[k] = lt ? ao : to[k];
-                        a = sv;
-                        ap = sp;
-                        ao = so;
-                    }
+                for (int k = 0; k < CNT - 1; ++k) {
+                    tv[k] = pop ? tv[k + 1] : tv[k];
+                    tp[k] = pop ? tp[k + 1] : tp[k];
                 }
-                hv[i] = tval;
-                ho[i] = worig;
-            } else {  // swap head positions i and hk
-#pragma unroll
-                for (int k = 0; k < CNT; ++k) {
-                    if (k == hk) {
-                        const uint32_t a = hv[i], b = ho[i];
-                        hv[i] = hv[k];
-                        ho[i] = ho[k];
-                        hv[k] = a;
-                        ho[k] = b;
-                    }
-                }
+                tv[CNT - 1] = pop ? INFB : tv[CNT - 1];
+                tp[CNT - 1] = pop ? INFB : tp[CNT - 1];
             }
         }
     }
+    // positions >= lim keep whatever sits there: the head element whose current position is i
 #pragma unroll
     for (int i = 0; i < CNT; ++i) {
-        out.v[i] = hv[i];
-        out.ix[i] = ho[i];
+        if ((uint32_t)i >= lim && (uint32_t)i < n) {
+#pragma unroll
+            for (int e = 0; e < CNT; ++e)
+                if (hp[e] == (uint32_t)i) {
+                    out.v[i] = hv[e];
+                    out.ix[i] = e;
+                }
+        }
     }
 }
 
@@ -947,11 +967,93 @@ __device__ __forceinline__ void select_paths_1(const SclCtx<LPL>& c, float val, 
     nidx = ridx;
 }
 
+// ---- LP == 8: block of n = 2^S <= 8 LLRs, one per lane (lane j holds |x_j| bits, INFB beyond n) ----------
+// findWeakLlrs emulated literally with "array position = lane": iteration i finds the first minimum among
+// lanes >= i and swaps it with lane i, all with DPP reductions / broadcasts inside the 8-lane path group.
+template <int S, int CNT>
+__device__ __forceinline__ void find_weak_small(uint32_t a, int j, Weak<CNT>& out)
+{
+    constexpr uint32_t INFB = 0xFFFFFFFFu;
+    constexpr int n = 1 << S;
+    constexpr int lim = (n - 1 < CNT) ? n - 1 : CNT;
+    uint32_t o = (uint32_t)j;  // original index travelling with the value
+    auto step = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < lim) {
+            const bool el = j >= i;
+            const uint32_t m = group_min_u32<8>(el ? a : INFB);
+            const uint32_t pk = group_min_u32<8>((el && a == m) ? (((uint32_t)j << 3) | o) : INFB);
+            const int k = (int)(pk >> 3);
+            const uint32_t ok = pk & 7u;
+            const uint32_t ai = group8_bcast<i>(a, j), oi = group8_bcast<i>(o, j);
+            if (j == k) {
+                a = ai;
+                o = oi;
+            }
+            if (j == i) {
+                a = m;
+                o = ok;
+            }
+            out.v[i] = m;
+            out.ix[i] = ok;
+        } else if constexpr (i < n) {
+            out.v[i] = group8_bcast<i>(a, j);
+            out.ix[i] = group8_bcast<i>(o, j);
+        } else {
+            out.v[i] = 0;
+            out.ix[i] = 0;
+        }
+    };
+    step(std::integral_constant<int, 0>{});
+    if constexpr (CNT > 1) step(std::integral_constant<int, 1>{});
+    if constexpr (CNT > 2) step(std::integral_constant<int, 2>{});
+    if constexpr (CNT > 3) step(std::integral_constant<int, 3>{});
+}
+
+// ---- LP == 8 candidate selection by rank -------------------------------------------------------------------
+// When no two candidates that matter carry the same metric, the reference's selection sort simply yields the
+// newP largest in descending order, so candidate c becomes new path  rank(c) = #{d : metric_d > metric_c}.
+// The rank is counted against every candidate slot with fully unrolled v_readlane / v_cmp / v_addc triples
+// (constant lane numbers, no scalar loop bookkeeping).  Candidates with equal metrics get equal ranks and
+// collide in the scatter below; that is detected and handed to the literal emulation (select_paths_1), which
+// reproduces the reference's swap-order tie behaviour.
+template <int CPP>
+__device__ __forceinline__ void select_ranked8(const SclCtx<3>& c, float val, uint32_t newP, float& nval,
+                                               uint32_t& nidx)
+{
+    constexpr int CS = CPP == 8 ? 3 : (CPP == 4 ? 2 : 1);
+    const bool valid = ((uint32_t)c.j < (uint32_t)CPP) && ((uint32_t)c.p < c.P);
+    const uint32_t key = valid ? okey(val) : 0u;  // 0 is below every real key
+    uint32_t gt = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if ((uint32_t)q < c.P) {  // wave uniform
+#pragma unroll
+            for (int r = 0; r < CPP; ++r) gt += (readlane_u32(key, q * 8 + r) > key) ? 1u : 0u;
+        }
+    }
+    const bool sel = valid && gt < newP;
+    // new path r inherits the candidate of rank r: scatter the lane ids (ds_permute), spread over the group
+    const uint32_t dst = sel ? (gt << 3) : 1u;  // losers dump into lane 1, which nobody reads
+    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), c.lane);
+    const uint32_t srcl = group8_bcast<0>(got, c.j);
+    // a selected lane whose id did not arrive lost a collision: two winners share a rank = an exact tie
+    const uint32_t back = shfl_u32(got, (int)dst);
+    if (ballot64(sel && back != (uint32_t)c.lane) != 0) {
+        select_paths_1<3, CPP>(c, val, newP, nval, nidx);
+        return;
+    }
+    nval = unkey(shfl_u32(key, (int)srcl));
+    nidx = ((srcl >> 3) << CS) + (srcl & 7u);
+}
+
 template <int LPL, int CPP>
 __device__ __forceinline__ void select_dispatch(const SclCtx<LPL>& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
-                                                uint32_t newP, float& nval, uint32_t& nidx)
+                                                float pathbest, uint32_t newP, float& nval, uint32_t& nidx)
 {
-    if constexpr (CPP <= (1 << LPL))
+    if constexpr (LPL == 3)
+        select_ranked8<CPP>(c, val[0], newP, nval, nidx);
+    else if constexpr (CPP <= (1 << LPL))
         select_paths_1<LPL, CPP>(c, val[0], newP, nval, nidx);
     else
         select_paths<LPL, CPP>(c, val, newP, nval, nidx);
@@ -1042,6 +1144,11 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
             const bool active = (uint32_t)c.p < c.P;
             uint64_t t_start = 0;
             if (P.cycles && cw == 0) t_start = __builtin_amdgcn_s_memtime();
+#define PAMD_STAMP(k)                                                                             \
+    if (P.cycles && cw == 0) {                                                                    \
+        const uint64_t t_ = __builtin_amdgcn_s_memtime();                                         \
+        if (lane == 0) P.cycles[P.prog_len + pc * 4 + (k)] = (uint32_t)(t_ - t_start);            \
+    }
 
             switch (ins.op) {
             // ------------------------------------------------------------------ inner node ops
@@ -1053,6 +1160,12 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                                 for (uint32_t i = lane; i < h; i += 64) d.set(i, polar_f(x[i], x[h + i]));
                             });
                         });
+                } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case)
+                    if (active) {
+                        const float* x = c.path_llr(c.p) + n;
+                        float* d = c.path_llr(c.p) + h;
+                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_f(x[i], x[h + i]);
+                    }
                 } else if (active) {
                     c.template with_src<I8>(s, c.p, [&](auto x) {
                         c.with_dst(s - 1, c.p, [&](auto d) {
@@ -1076,6 +1189,13 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                                     d.set(i, polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u));
                             });
                         });
+                    }
+                } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case); h <= 32: one bit word
+                    if (active) {
+                        const float* x = c.path_llr(c.field(c.slot, s)) + n;
+                        float* d = c.path_llr(c.p) + h;
+                        const uint32_t lw = (c.area(0, c.p) + wo)[0];
+                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
                     }
                 } else if (active) {
                     const uint32_t srcq = c.field(c.slot, s);
@@ -1125,7 +1245,10 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                             if (v >= n) acc[a] = acc[a] + 0.0f;
                         }
                     };
-                    c.template with_src<I8>(s, c.p, body);
+                    if (s < c.s0 && s < logN)
+                        body(Rd<K_LDS>{ c.path_llr(c.p) + n });
+                    else
+                        c.template with_src<I8>(s, c.p, body);
                 }
                 const float sum = c.lanesum_finish(acc);
                 if (active) {
@@ -1150,7 +1273,10 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                             ao[a] = ao[a] + max0(xv);
                         }
                     };
-                    c.template with_src<I8>(s, c.p, body);
+                    if (s < c.s0 && s < logN)
+                        body(Rd<K_LDS>{ c.path_llr(c.p) + n });
+                    else
+                        c.template with_src<I8>(s, c.p, body);
                 }
                 const float z = c.lanesum_finish(az), o = c.lanesum_finish(ao);
                 constexpr int CPL = (2 >> LPL) ? (2 >> LPL) : 1;
@@ -1163,7 +1289,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                 const uint32_t newP = (c.P * 2 < c.L) ? c.P * 2 : c.L;
                 float nval;
                 uint32_t nidx;
-                select_dispatch<LPL, 2>(c, val, newP, nval, nidx);
+                select_dispatch<LPL, 2>(c, val, (c.metric + z > c.metric - o) ? c.metric + z : c.metric - o, newP, nval, nidx);
                 const uint32_t srcp = nidx >> 1, q = nidx & 1u;
                 const uint64_t nslot = shfl_u64(c.slot, (int)(srcp << LPL));
                 c.P = newP;
@@ -1196,7 +1322,40 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                         wk.ix[2] = wk.ix[3] = 0;
                     }
                 };
-                c.template with_src<I8>(s, c.p, search);
+                bool small = false;
+                if constexpr (LPL == 3) small = (s <= 3 && s < c.s0 && s < logN);  // n <= 8, block in LDS
+                if constexpr (LPL == 3) {
+                    if (small) {
+                        constexpr uint32_t INFB = 0xFFFFFFFFu;
+                        const bool in = (uint32_t)c.j < n;
+                        const float xj = (c.path_llr(c.p) + n)[in ? c.j : 0];
+                        const uint32_t a = in ? (fbits(xj) & 0x7FFFFFFFu) : INFB;
+                        if (spc) {
+                            if (s == 2)
+                                find_weak_small<2, 4>(a, c.j, wk);
+                            else
+                                find_weak_small<3, 4>(a, c.j, wk);
+                            const uint64_t sg = ballot64(in && sgn(xj));
+                            par = (uint32_t)__popc((uint32_t)(sg >> c.base) & 0xFFu) & 1u;
+                        } else {
+                            Weak<2> w2;
+                            if (s == 1)
+                                find_weak_small<1, 2>(a, c.j, w2);
+                            else if (s == 2)
+                                find_weak_small<2, 2>(a, c.j, w2);
+                            else
+                                find_weak_small<3, 2>(a, c.j, w2);
+                            wk.v[0] = w2.v[0];
+                            wk.v[1] = w2.v[1];
+                            wk.ix[0] = w2.ix[0];
+                            wk.ix[1] = w2.ix[1];
+                            wk.v[2] = wk.v[3] = 0;
+                            wk.ix[2] = wk.ix[3] = 0;
+                        }
+                    }
+                }
+                if (!small) c.template with_src<I8>(s, c.p, search);
+                PAMD_STAMP(0)
                 const float v0 = bitsf(wk.v[0]), v1 = bitsf(wk.v[1]), v2 = bitsf(wk.v[2]), v3 = bitsf(wk.v[3]);
                 uint32_t nidx;
                 float nval;
@@ -1223,7 +1382,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                         val[r] = t;
                     }
                     newP = (c.P * 8 < c.L) ? c.P * 8 : c.L;
-                    select_dispatch<LPL, 8>(c, val, newP, nval, nidx);
+                    select_dispatch<LPL, 8>(c, val, m, newP, nval, nidx);
                 } else {
                     constexpr int CPL = (4 >> LPL) ? (4 >> LPL) : 1;
                     float val[CPL];
@@ -1241,8 +1400,9 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                         val[r] = t;
                     }
                     newP = (c.P * 4 < c.L) ? c.P * 4 : c.L;
-                    select_dispatch<LPL, 4>(c, val, newP, nval, nidx);
+                    select_dispatch<LPL, 4>(c, val, m, newP, nval, nidx);
                 }
+                PAMD_STAMP(1)
                 const uint32_t srcp = spc ? (nidx >> 3) : (nidx >> 2);
                 const uint32_t q = spc ? (nidx & 7u) : (nidx & 3u);
                 const int sl = (int)(srcp << LPL);
@@ -1266,8 +1426,22 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                     c.metric = nval;
                     c.slot = nslot;
                 }
+                PAMD_STAMP(2)
                 // bits of the new path = signs of the SOURCE path's LLRs (identity buffer) with flips
-                c.template with_src<I8>(s, srcp, [&](auto x) { write_leaf_bits<LPL>(c, x, s, side, nact, fmask, fpos); });
+                if (small) {  // n <= 8: one LLR of the SOURCE path per lane, one ballot byte per path
+                    const bool in = (uint32_t)c.j < n;
+                    uint32_t b = 0;
+                    if (nact && in) {
+                        b = sgn((c.path_llr(srcp) + n)[c.j]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) b ^= (((fmask >> k) & 1u) && fpos[k] == (uint32_t)c.j) ? 1u : 0u;
+                    }
+                    const uint64_t bal = ballot64(b != 0);
+                    if (nact && c.j == 0) (c.area(side, c.p) + woff(s))[0] = (uint32_t)(bal >> c.base) & 0xFFu;
+                } else {
+                    c.template with_src<I8>(s, srcp,
+                                            [&](auto x) { write_leaf_bits<LPL>(c, x, s, side, nact, fmask, fpos); });
+                }
                 break;
             }
             default: break;
