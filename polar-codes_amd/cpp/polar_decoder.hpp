@@ -1,0 +1,100 @@
+// C++ host-side mirror of the reference's decoder interface over the C ABI (include/polar_amd.h).
+//
+// Mirrors PolarCode::Decoding::Decoder (reference: include/polarcode/decoding/decoder.h:40-180) and the factory
+// PolarCode::Decoding::create (decoder.cpp:26-52) for the float / mixed decoders: same method names, argument
+// meaning and exception types, plus decode_batch for B codewords per call.  Header-only; link libpolar_amd.so.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/polar_amd.h"
+
+namespace PolarAmd {
+namespace Decoding {
+
+class Decoder {
+public:
+    Decoder(size_t blockLength, size_t listSize, const std::vector<unsigned>& frozenBits,
+            const std::string& decoderType, int device = 0)
+    {
+        std::vector<uint32_t> f(frozenBits.begin(), frozenBits.end());
+        check(pcd_create(blockLength, listSize, f.data(), f.size(), decoderType.c_str(), device, &h_));
+    }
+    ~Decoder() { pcd_destroy(h_); }
+    Decoder(const Decoder&) = delete;
+    Decoder& operator=(const Decoder&) = delete;
+
+    // Decoder::decode_vector(const float*, void*) decoder.cpp:154-167 -- returns the detector verdict
+    bool decode_vector(const float* pLlr, void* pData)
+    {
+        uint8_t ok = 0;
+        check(pcd_decode_f32(h_, pLlr, 1, static_cast<uint8_t*>(pData), &ok, nullptr, PCD_MEM_HOST, nullptr));
+        return ok != 0;
+    }
+    // Decoder::decode_vector(const char*, void*) decoder.cpp:169-181
+    bool decode_vector(const char* pLlr, void* pData)
+    {
+        uint8_t ok = 0;
+        check(pcd_decode_i8(h_, reinterpret_cast<const int8_t*>(pLlr), 1, static_cast<uint8_t*>(pData), &ok, nullptr,
+                            PCD_MEM_HOST, nullptr));
+        return ok != 0;
+    }
+    // batched form (no reference counterpart): rows x N LLRs -> rows x (K+7)/8 bytes, rows verdicts
+    void decode_batch(const float* llr, size_t rows, uint8_t* out, uint8_t* ok = nullptr, float* metrics = nullptr,
+                      bool device_pointers = false, void* hip_stream = nullptr)
+    {
+        check(pcd_decode_f32(h_, llr, rows, out, ok, metrics, device_pointers ? PCD_MEM_DEVICE : PCD_MEM_HOST, hip_stream));
+    }
+
+    size_t blockLength() const { return pcd_block_length(h_); }
+    size_t infoLength() const { return pcd_info_length(h_); }
+    size_t getListSize() const { return pcd_list_size(h_); }
+    void setSystematic(bool sys) { check(pcd_set_systematic(h_, sys ? 1 : 0)); }
+    bool isSystematic() const { return pcd_is_systematic(h_) != 0; }
+    std::vector<unsigned> frozenBits() const
+    {
+        std::vector<uint32_t> f(pcd_frozen_bits(h_, nullptr, 0));
+        pcd_frozen_bits(h_, f.data(), f.size());
+        return std::vector<unsigned>(f.begin(), f.end());
+    }
+    // Decoder::setErrorDetection(ErrorDetection::create(size, type))
+    void setErrorDetection(unsigned size = 0, const std::string& type = "crc")
+    {
+        check(pcd_set_error_detection(h_, size, type.c_str()));
+    }
+    std::string getErrorDetectionMode() const
+    {
+        char buf[64];
+        pcd_error_detection_mode(h_, buf, sizeof buf);
+        return buf;
+    }
+    pcd_decoder* handle() { return h_; }
+
+private:
+    static void check(int rc)
+    {
+        if (rc == PCD_OK) return;
+        const std::string msg = pcd_last_error();
+        switch (rc) {
+        case PCD_ERR_UNKNOWN_TYPE:
+        case PCD_ERR_CRC_SIZE: throw std::logic_error(msg);           // as the reference does
+        case PCD_ERR_FROZEN_SET:
+        case PCD_ERR_INVALID_ARG: throw std::invalid_argument(msg);
+        default: throw std::runtime_error(msg);
+        }
+    }
+    pcd_decoder* h_ = nullptr;
+};
+
+// PolarCode::Decoding::create(blockLength, listSize, frozenBits, decoderType) -- owning raw pointer, like the reference
+inline Decoder* create(size_t blockLength, size_t listSize, const std::vector<unsigned>& frozenBits,
+                       std::string decoderType)
+{
+    return new Decoder(blockLength, listSize, frozenBits, decoderType);
+}
+
+}  // namespace Decoding
+}  // namespace PolarAmd

@@ -1,0 +1,61 @@
+// Exercises the C++ mirror of the reference's Decoder interface (polar-codes_amd/cpp/polar_decoder.hpp).
+// argv[1] = "host": only host-side behaviour (no GPU needed);  "gpu": also decodes the N = 8 known answer
+// of the reference's test/polarcode/decodingtest.cpp:1143-1173.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "../polar-codes_amd/cpp/polar_decoder.hpp"
+
+using namespace PolarAmd::Decoding;
+
+int main(int argc, char** argv)
+{
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    std::vector<unsigned> frozen = { 0, 1, 2, 4 };
+    std::unique_ptr<Decoder> d(create(8, 4, frozen, "float"));
+    if (d->blockLength() != 8 || d->infoLength() != 4 || d->getListSize() != 4) return 1;
+    if (!d->isSystematic() || d->getErrorDetectionMode() != "CRC-8") return 2;
+    d->setErrorDetection(0, "crc");
+    if (d->getErrorDetectionMode() != "DUMMY-0") return 3;
+    if (d->frozenBits() != frozen) return 4;
+    bool threw = false;
+    try {
+        create(8, 4, frozen, "nonsense");
+    } catch (const std::logic_error&) {
+        threw = true;
+    }
+    if (!threw) return 5;
+    threw = false;
+    try {
+        d->setErrorDetection(7, "crc");
+    } catch (const std::logic_error&) {
+        threw = true;
+    }
+    if (!threw) return 6;
+    if (gpu) {
+        const float llr[8] = { -5, -6, -4, 1, -4, -5, -7, 2 };
+        unsigned char out[8] = { 0 };
+        const bool ok = d->decode_vector(llr, out);
+        if (!ok) return 7;                       // dummy detector always passes
+        if ((out[0] & 0xF0) != 0xF0) return 8;   // decodingtest.cpp:1172
+        std::unique_ptr<Decoder> sc(create(8, 1, frozen, "float"));
+        sc->setErrorDetection(0, "crc");
+        unsigned char out2[8] = { 0 };
+        sc->decode_vector(llr, out2);
+        if ((out2[0] & 0xF0) != 0xF0) return 9;
+    } else {
+        // without a GPU the product must fail loudly, never fall back
+        const float llr[8] = { 1, 1, 1, 1, 1, 1, 1, 1 };
+        unsigned char out[8];
+        threw = false;
+        try {
+            d->decode_vector(llr, out);
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        if (!threw) return 10;
+    }
+    std::puts("cpp shim ok");
+    return 0;
+}

@@ -204,3 +204,11 @@ def test_full_batch_properties(built_library, name, L, det, ebn0):
     assert good.mean() > 0.97, good.mean()
     if det:
         assert np.array_equal(k0.astype(bool) & good, good)
+
+
+def test_cpp_shim_decodes_on_gpu(built_library):
+    """C++ host side (polar_decoder.hpp over the C ABI): N=8 known answer of decodingtest.cpp:1143-1173"""
+    import subprocess
+    from test_host import _build_cpp_shim
+    r = subprocess.run([_build_cpp_shim(built_library), "gpu"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)

@@ -148,3 +148,25 @@ def test_no_gpu_fails_loudly(built_library):
     with pytest.raises(pypolar_amd.PolarAmdError) as ei:
         d.decode_vector(np.ones(64, np.float32))
     assert ei.value.code in (-7, -8)
+
+
+def _build_cpp_shim(built_library):
+    import subprocess
+    import pypolar_amd
+    exe = os.path.join(ROOT, "tests", "_cpp_shim_test")
+    src = os.path.join(ROOT, "tests", "cpp_shim_test.cpp")
+    libdir = os.path.dirname(pypolar_amd.library_path())
+    subprocess.check_call(["g++", "-std=c++17", "-O1", src, "-o", exe, "-L" + libdir, "-lpolar_amd",
+                           "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_cpp_shim_host_side(built_library):
+    """the C++ mirror of PolarCode::Decoding::Decoder compiles against the C ABI with plain g++ and behaves
+    like the reference on the host side (accessors, exception types, loud failure without a GPU)"""
+    import subprocess
+    import torch
+    exe = _build_cpp_shim(built_library)
+    mode = "gpu" if torch.cuda.is_available() else "host"
+    r = subprocess.run([exe, mode], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
