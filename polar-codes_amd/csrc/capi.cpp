@@ -216,6 +216,7 @@ pamd::DecodeParams base_params(const pcd_decoder* d, const void* llr, size_t row
     P.metrics = metrics;
     P.det_on = d->det.size != 0;
     P.systematic = d->systematic ? 1u : 0u;
+    if (const char* ab = std::getenv("PCD_ABLATE")) P.ablate = (uint32_t)std::atoi(ab);
     return P;
 }
 

@@ -29,6 +29,7 @@ struct DecodeParams {
     float* trace;            // diagnostics (nullable): row 0 only, (1 + L) floats after every SCL leaf
     uint32_t trace_cap;
     uint32_t prog_len;
+    uint32_t ablate;         // perf experiments only (PCD_ABLATE): skips parts of the work, results are wrong
     uint32_t* cycles;        // diagnostics (nullable): row 0 only, s_memtime cycles spent per program instruction
 };
 

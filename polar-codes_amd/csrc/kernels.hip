@@ -622,8 +622,9 @@ struct Wr {
     }
 };
 
-template <int LPL>
+template <int LPL, bool S64>
 struct SclCtx {
+    using SlotT = std::conditional_t<S64, uint64_t, uint32_t>;
     static constexpr int LP = 1 << LPL;     // lanes per path
     static constexpr int LMAX = 64 >> LPL;  // path groups per wave
     static constexpr int FB = 6 - LPL;      // bits per slot field
@@ -633,6 +634,7 @@ struct SclCtx {
     uint32_t* bitsL;
     uint32_t* bitsR;
     uint32_t path_stride, wppL, wppR;
+    uint32_t ablate;
     float* arena;  // this wave's global scratch (stages >= s0)
     uint32_t arena_path_stride, s0, logN;
     const void* chan;
@@ -640,7 +642,7 @@ struct SclCtx {
     uint32_t P;      // live paths (wave uniform)
     uint32_t L;      // list size limit
     float metric;
-    uint64_t slot;
+    SlotT slot;
 
     __device__ __forceinline__ float* path_llr(uint32_t q) const { return llr + (size_t)q * path_stride; }
     __device__ __forceinline__ uint32_t* area(uint32_t side, uint32_t q) const
@@ -674,14 +676,29 @@ struct SclCtx {
         else
             fn(Wr<K_LDS>{ path_llr(q) + (1u << t) });
     }
-    __device__ __forceinline__ uint32_t field(uint64_t sl, uint32_t s) const
+    __device__ __forceinline__ uint32_t field(SlotT sl, uint32_t s) const
     {
         return (uint32_t)(sl >> ((s - 1) * FB)) & (uint32_t)(LMAX - 1);
     }
     __device__ __forceinline__ void set_field(uint32_t s)
     {
         const uint32_t sh = (s - 1) * FB;
-        slot = (slot & ~((uint64_t)(LMAX - 1) << sh)) | ((uint64_t)p << sh);
+        slot = (slot & ~((SlotT)(LMAX - 1) << sh)) | ((SlotT)p << sh);
+    }
+    // the slot word of path group q, as a wave-uniform value / fetched from a per-lane source lane
+    __device__ __forceinline__ SlotT slot_of_group(int q) const
+    {
+        if constexpr (S64)
+            return ((uint64_t)readlane_u32((uint32_t)(slot >> 32), q << LPL) << 32) | readlane_u32((uint32_t)slot, q << LPL);
+        else
+            return readlane_u32(slot, q << LPL);
+    }
+    __device__ __forceinline__ SlotT slot_from_lane(int src) const
+    {
+        if constexpr (S64)
+            return shfl_u64(slot, src);
+        else
+            return shfl_u32(slot, src);
     }
 
     // sum over the path of v(i), i < n, in the reference's order: 8 strided accumulators
@@ -727,10 +744,10 @@ struct Weak {
     uint32_t ix[CNT];  // original indices
 };
 
-template <int LPL, int CNT, typename SRC>
-__device__ __forceinline__ void find_weak(const SclCtx<LPL>& c, const SRC& x, uint32_t n, Weak<CNT>& out)
+template <typename CTX, int CNT, typename SRC>
+__device__ __forceinline__ void find_weak(const CTX& c, const SRC& x, uint32_t n, Weak<CNT>& out)
 {
-    constexpr int LP = SclCtx<LPL>::LP;
+    constexpr int LP = CTX::LP;
     constexpr uint32_t INFB = 0xFFFFFFFFu;  // larger than any |x| bit pattern / any position
     uint32_t hv[CNT], hp[CNT];
 #pragma unroll
@@ -823,11 +840,11 @@ __device__ __forceinline__ void find_weak(const SclCtx<LPL>& c, const SRC& x, ui
 // Literal emulation: iteration i finds the first position >= i holding the maximum and swaps it
 // with position i.  On return every lane knows, for ITS OWN new path index p, the winning
 // candidate's metric (nval) and original position (nidx).
-template <int LPL, int CPP>
-__device__ __forceinline__ void select_paths(const SclCtx<LPL>& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
+template <typename CTX, int LPL, int CPP>
+__device__ __forceinline__ void select_paths(const CTX& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
                                              uint32_t newP, float& nval, uint32_t& nidx)
 {
-    constexpr int LP = SclCtx<LPL>::LP;
+    constexpr int LP = CTX::LP;
     constexpr int CPL = (CPP >> LPL) ? (CPP >> LPL) : 1;
     const uint32_t size = c.P * CPP;
     uint32_t idx[CPL], pos[CPL];
@@ -921,11 +938,11 @@ __device__ __forceinline__ void select_paths(const SclCtx<LPL>& c, float (&val)[
 // Same selection for the common case of at most one candidate per lane (CPP <= LP): everything that is
 // wave-uniform (maximum, winner lane, the lane holding position i) lives in SGPRs via DPP + v_readlane, and the
 // winner of iteration i IS what new path i inherits, so no permute is needed afterwards.
-template <int LPL, int CPP>
-__device__ __forceinline__ void select_paths_1(const SclCtx<LPL>& c, float val, uint32_t newP, float& nval,
+template <typename CTX, int LPL, int CPP>
+__device__ __forceinline__ void select_paths_1(const CTX& c, float val, uint32_t newP, float& nval,
                                                uint32_t& nidx)
 {
-    constexpr int LP = SclCtx<LPL>::LP;
+    constexpr int LP = CTX::LP;
     static_assert(CPP <= LP, "one candidate per lane");
     constexpr int CS = CPP == 8 ? 3 : (CPP == 4 ? 2 : 1);
     const uint32_t size = c.P * CPP;
@@ -1017,8 +1034,8 @@ __device__ __forceinline__ void find_weak_small(uint32_t a, int j, Weak<CNT>& ou
 // (constant lane numbers, no scalar loop bookkeeping).  Candidates with equal metrics get equal ranks and
 // collide in the scatter below; that is detected and handed to the literal emulation (select_paths_1), which
 // reproduces the reference's swap-order tie behaviour.
-template <int CPP>
-__device__ __forceinline__ void select_ranked8(const SclCtx<3>& c, float val, uint32_t newP, float& nval,
+template <typename CTX, int CPP>
+__device__ __forceinline__ void select_ranked8(const CTX& c, float val, uint32_t newP, float& nval,
                                                uint32_t& nidx)
 {
     constexpr int CS = CPP == 8 ? 3 : (CPP == 4 ? 2 : 1);
@@ -1040,32 +1057,37 @@ __device__ __forceinline__ void select_ranked8(const SclCtx<3>& c, float val, ui
     // a selected lane whose id did not arrive lost a collision: two winners share a rank = an exact tie
     const uint32_t back = shfl_u32(got, (int)dst);
     if (ballot64(sel && back != (uint32_t)c.lane) != 0) {
-        select_paths_1<3, CPP>(c, val, newP, nval, nidx);
+        select_paths_1<CTX, 3, CPP>(c, val, newP, nval, nidx);
         return;
     }
     nval = unkey(shfl_u32(key, (int)srcl));
     nidx = ((srcl >> 3) << CS) + (srcl & 7u);
 }
 
-template <int LPL, int CPP>
-__device__ __forceinline__ void select_dispatch(const SclCtx<LPL>& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
+template <typename CTX, int LPL, int CPP>
+__device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
                                                 float pathbest, uint32_t newP, float& nval, uint32_t& nidx)
 {
+    if (c.ablate & 1u) {  // perf experiment (diagnostic build only): no selection
+        nval = val[0];
+        nidx = (uint32_t)c.p * CPP;
+        return;
+    }
     if constexpr (LPL == 3)
-        select_ranked8<CPP>(c, val[0], newP, nval, nidx);
+        select_ranked8<CTX, CPP>(c, val[0], newP, nval, nidx);
     else if constexpr (CPP <= (1 << LPL))
-        select_paths_1<LPL, CPP>(c, val[0], newP, nval, nidx);
+        select_paths_1<CTX, LPL, CPP>(c, val[0], newP, nval, nidx);
     else
-        select_paths<LPL, CPP>(c, val, newP, nval, nidx);
+        select_paths<CTX, LPL, CPP>(c, val, newP, nval, nidx);
 }
 
 // write the n leaf bits of every (new) path: sign(x_src[i]) ^ flips, packed, into area(side)[stage]
 // flips: up to 4 positions (fmask bit k enables fpos[k]);  REP passes n_from_llr = false
-template <int LPL, typename SRC>
-__device__ __forceinline__ void write_leaf_bits(const SclCtx<LPL>& c, const SRC& x, uint32_t s, uint32_t side,
+template <typename CTX, typename SRC>
+__device__ __forceinline__ void write_leaf_bits(const CTX& c, const SRC& x, uint32_t s, uint32_t side,
                                                 bool active, uint32_t fmask, const uint32_t fpos[4])
 {
-    constexpr int LP = SclCtx<LPL>::LP;
+    constexpr int LP = CTX::LP;
     const uint32_t n = 1u << s;
     uint32_t* dst = c.area(side, c.p) + woff(s);
     uint32_t acc = 0;
@@ -1087,10 +1109,10 @@ __device__ __forceinline__ void write_leaf_bits(const SclCtx<LPL>& c, const SRC&
     }
 }
 
-template <int LPL, bool I8>
+template <int LPL, bool I8, bool S64, bool DIAG>
 __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
 {
-    using Ctx = SclCtx<LPL>;
+    using Ctx = SclCtx<LPL, S64>;
     constexpr int LP = Ctx::LP;
     constexpr int LMAX = Ctx::LMAX;
     constexpr int NACC = Ctx::NACC;
@@ -1111,6 +1133,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
     c.arena_path_stride = P.arena_path_stride;
     c.s0 = P.s0;
     c.logN = P.logN;
+    c.ablate = DIAG ? P.ablate : 0u;
     c.lane = lane;
     c.p = lane >> LPL;
     c.j = lane & (LP - 1);
@@ -1143,17 +1166,20 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
             const uint32_t s = ins.stage, n = 1u << s, h = n >> 1, side = ins.side;
             const bool active = (uint32_t)c.p < c.P;
             uint64_t t_start = 0;
-            if (P.cycles && cw == 0) t_start = __builtin_amdgcn_s_memtime();
+            if (DIAG && P.cycles && cw == 0) t_start = __builtin_amdgcn_s_memtime();
 #define PAMD_STAMP(k)                                                                             \
-    if (P.cycles && cw == 0) {                                                                    \
+    if (DIAG && P.cycles && cw == 0) {                                                            \
         const uint64_t t_ = __builtin_amdgcn_s_memtime();                                         \
         if (lane == 0) P.cycles[P.prog_len + pc * 4 + (k)] = (uint32_t)(t_ - t_start);            \
     }
 
+            if (DIAG && ((P.ablate & 128u) || ((P.ablate & 64u) && ins.op >= SCL_R0))) continue;
             switch (ins.op) {
             // ------------------------------------------------------------------ inner node ops
             case SCL_F: {  // RateRNode::decode :233-238 -- reads the path's own (identity) buffer
-                if (h >= 64) {
+                if (DIAG && (P.ablate & 8u) && h >= 64) {
+                } else if (DIAG && (P.ablate & 16u) && h < 64) {
+                } else if (h >= 64) {
                     for (uint32_t q = 0; q < c.P; ++q)
                         c.template with_src<I8>(s, q, [&](auto x) {
                             c.with_dst(s - 1, q, [&](auto d) {
@@ -1178,10 +1204,11 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
             }
             case SCL_G: {  // :242-249 -- LLR[s] through the slot word, left bits at identity
                 const uint32_t wo = woff(s - 1);
-                if (h >= 64) {
+                if (DIAG && (P.ablate & 8u) && h >= 64) {
+                } else if (DIAG && (P.ablate & 16u) && h < 64) {
+                } else if (h >= 64) {
                     for (uint32_t q = 0; q < c.P; ++q) {
-                        const uint32_t srcq = c.field(((uint64_t)readlane_u32((uint32_t)(c.slot >> 32), (int)(q << LPL)) << 32) |
-                                                          readlane_u32((uint32_t)c.slot, (int)(q << LPL)), s);
+                        const uint32_t srcq = c.field(c.slot_of_group((int)q), s);
                         const uint32_t* lb = c.area(0, q) + wo;
                         c.template with_src<I8>(s, srcq, [&](auto x) {
                             c.with_dst(s - 1, q, [&](auto d) {
@@ -1211,7 +1238,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                 break;
             }
             case SCL_COMBINE: {  // :253-260 CombineBitsLong / CombineBitsShort
-                if (active) {
+                if (active && !(DIAG && (P.ablate & 16u))) {
                     const uint32_t lq = c.field(c.slot, s);
                     const uint32_t* lb = c.area(0, lq) + woff(s - 1);
                     const uint32_t* rb = c.area(1, c.p) + woff(s - 1);
@@ -1289,9 +1316,9 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                 const uint32_t newP = (c.P * 2 < c.L) ? c.P * 2 : c.L;
                 float nval;
                 uint32_t nidx;
-                select_dispatch<LPL, 2>(c, val, (c.metric + z > c.metric - o) ? c.metric + z : c.metric - o, newP, nval, nidx);
+                select_dispatch<Ctx, LPL, 2>(c, val, (c.metric + z > c.metric - o) ? c.metric + z : c.metric - o, newP, nval, nidx);
                 const uint32_t srcp = nidx >> 1, q = nidx & 1u;
-                const uint64_t nslot = shfl_u64(c.slot, (int)(srcp << LPL));
+                const typename Ctx::SlotT nslot = c.slot_from_lane((int)(srcp << LPL));
                 c.P = newP;
                 if ((uint32_t)c.p < c.P) {
                     c.metric = nval;
@@ -1307,13 +1334,13 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                 uint32_t par = 0;
                 auto search = [&](auto x) {
                     if (spc) {
-                        find_weak<LPL, 4>(c, x, n, wk);
+                        find_weak<Ctx, 4>(c, x, n, wk);
                         uint32_t pb = 0;
                         for (uint32_t i = c.j; i < n; i += LP) pb ^= sgn(x[i]);
                         par = group_xor_u32<LP>(pb) & 1u;
                     } else {
                         Weak<2> w2;
-                        find_weak<LPL, 2>(c, x, n, w2);
+                        find_weak<Ctx, 2>(c, x, n, w2);
                         wk.v[0] = w2.v[0];
                         wk.v[1] = w2.v[1];
                         wk.ix[0] = w2.ix[0];
@@ -1324,8 +1351,13 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                 };
                 bool small = false;
                 if constexpr (LPL == 3) small = (s <= 3 && s < c.s0 && s < logN);  // n <= 8, block in LDS
+                if (DIAG && (P.ablate & 2u)) {  // perf experiment: no weak search
+                    small = true;
+                    wk.v[0] = wk.v[1] = wk.v[2] = wk.v[3] = 0x3F800000u;
+                    wk.ix[0] = 0; wk.ix[1] = 1; wk.ix[2] = 2; wk.ix[3] = 3;
+                } else
                 if constexpr (LPL == 3) {
-                    if (small) {
+                    if (small && !(DIAG && (P.ablate & 2u))) {
                         constexpr uint32_t INFB = 0xFFFFFFFFu;
                         const bool in = (uint32_t)c.j < n;
                         const float xj = (c.path_llr(c.p) + n)[in ? c.j : 0];
@@ -1382,7 +1414,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                         val[r] = t;
                     }
                     newP = (c.P * 8 < c.L) ? c.P * 8 : c.L;
-                    select_dispatch<LPL, 8>(c, val, m, newP, nval, nidx);
+                    select_dispatch<Ctx, LPL, 8>(c, val, m, newP, nval, nidx);
                 } else {
                     constexpr int CPL = (4 >> LPL) ? (4 >> LPL) : 1;
                     float val[CPL];
@@ -1400,13 +1432,13 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                         val[r] = t;
                     }
                     newP = (c.P * 4 < c.L) ? c.P * 4 : c.L;
-                    select_dispatch<LPL, 4>(c, val, m, newP, nval, nidx);
+                    select_dispatch<Ctx, LPL, 4>(c, val, m, newP, nval, nidx);
                 }
                 PAMD_STAMP(1)
                 const uint32_t srcp = spc ? (nidx >> 3) : (nidx >> 2);
                 const uint32_t q = spc ? (nidx & 7u) : (nidx & 3u);
                 const int sl = (int)(srcp << LPL);
-                const uint64_t nslot = shfl_u64(c.slot, sl);
+                const typename Ctx::SlotT nslot = c.slot_from_lane(sl);
                 // flip positions (< 2^15 each) and the parity travel packed in two registers
                 const uint32_t pk0 = shfl_u32(wk.ix[0] | (wk.ix[1] << 16), sl);
                 const uint32_t pk1 = shfl_u32(wk.ix[2] | (wk.ix[3] << 16) | (par << 31), sl);
@@ -1440,7 +1472,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                     if (nact && c.j == 0) (c.area(side, c.p) + woff(s))[0] = (uint32_t)(bal >> c.base) & 0xFFu;
                 } else {
                     c.template with_src<I8>(s, srcp,
-                                            [&](auto x) { write_leaf_bits<LPL>(c, x, s, side, nact, fmask, fpos); });
+                                            [&](auto x) { write_leaf_bits<Ctx>(c, x, s, side, nact, fmask, fpos); });
                 }
                 break;
             }
@@ -1453,11 +1485,11 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             WAVE_SYNC();
-            if (P.cycles && cw == 0) {
+            if (DIAG && P.cycles && cw == 0) {
                 const uint64_t t_end = __builtin_amdgcn_s_memtime();
                 if (lane == 0) P.cycles[pc] = (uint32_t)(t_end - t_start);
             }
-            if (P.trace && cw == 0 && ins.op >= SCL_R0) {
+            if (DIAG && P.trace && cw == 0 && ins.op >= SCL_R0) {
                 if (trace_n < P.trace_cap) {
                     float* t = P.trace + (size_t)trace_n * (1 + P.L);
                     if (lane == 0) t[0] = (float)c.P;
@@ -1467,6 +1499,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
             }
         }
 
+        if (DIAG && (P.ablate & 32u)) continue;
         // ---- SclAvxFloat::extractBestPath :711-750 ---------------------------------------------
         const bool active = (uint32_t)c.p < c.P;
         uint32_t* cwbits = c.area(0, c.p) + woff(logN);
@@ -1552,19 +1585,30 @@ __global__ void collect_failed_kernel(const uint8_t* ok, uint32_t rows, uint32_t
 // =============================================================================================
 //  launchers
 // =============================================================================================
-template <int LPL>
-static hipError_t launch_scl_t(const DecodeParams& P, bool i8, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+template <int LPL, bool I8, bool S64, bool DIAG>
+static hipError_t launch_scl_k(const DecodeParams& P, dim3 grid, dim3 block, size_t lds, hipStream_t st)
 {
-    if (i8) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((scl_decode_kernel<LPL, true>), grid, block, lds, st, P);
-    } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((scl_decode_kernel<LPL, false>), grid, block, lds, st, P);
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((scl_decode_kernel<LPL, I8, S64, DIAG>), grid, block, lds, st, P);
     return hipGetLastError();
+}
+
+// Instantiations: the production kernels (no diagnostics) for every lanes-per-path split, with a 64-bit slot
+// word; a 32-bit slot word variant for L <= 8 when log2(N) * 3 <= 32 (the headline configuration); and a
+// diagnostic variant (trace / cycle stamps / ablation switches) for float input only.
+template <int LPL>
+static hipError_t launch_scl_t(const DecodeParams& P, bool i8, bool slot64, bool diag, dim3 grid, dim3 block, size_t lds,
+                               hipStream_t st)
+{
+    if (diag && !i8) return launch_scl_k<LPL, false, true, true>(P, grid, block, lds, st);
+    if constexpr (LPL == 3) {
+        if (!slot64)
+            return i8 ? launch_scl_k<LPL, true, false, false>(P, grid, block, lds, st)
+                      : launch_scl_k<LPL, false, false, false>(P, grid, block, lds, st);
+    }
+    return i8 ? launch_scl_k<LPL, true, true, false>(P, grid, block, lds, st)
+              : launch_scl_k<LPL, false, true, false>(P, grid, block, lds, st);
 }
 
 hipError_t launch_sc(const DecodeParams& P, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,
@@ -1587,12 +1631,15 @@ hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, un
                       size_t lds, hipStream_t st)
 {
     dim3 g(grid), b(64 * waves_per_block);
+    const bool diag = P.trace || P.cycles || P.ablate;
+    const unsigned fb = 6u - (unsigned)lpl;
+    const bool slot64 = P.logN * fb > 32u;
     switch (lpl) {
-    case 1: return launch_scl_t<1>(P, i8, g, b, lds, st);
-    case 2: return launch_scl_t<2>(P, i8, g, b, lds, st);
-    case 3: return launch_scl_t<3>(P, i8, g, b, lds, st);
-    case 4: return launch_scl_t<4>(P, i8, g, b, lds, st);
-    case 5: return launch_scl_t<5>(P, i8, g, b, lds, st);
+    case 1: return launch_scl_t<1>(P, i8, slot64, diag, g, b, lds, st);
+    case 2: return launch_scl_t<2>(P, i8, slot64, diag, g, b, lds, st);
+    case 3: return launch_scl_t<3>(P, i8, slot64, diag, g, b, lds, st);
+    case 4: return launch_scl_t<4>(P, i8, slot64, diag, g, b, lds, st);
+    case 5: return launch_scl_t<5>(P, i8, slot64, diag, g, b, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
