@@ -117,7 +117,7 @@ void compute_geometry(pcd_decoder* d)
         d->lmax = lmax;
         d->lpl = 6 - (int)ilog2(lmax);
         const unsigned LP = 64 / lmax;
-        const unsigned pad = LP < 32 ? LP : 0;
+        const unsigned pad = LP < 32 ? (LP < 4 ? 4 : LP) : 0;  // bank spread; multiple of 4 floats (16-byte LDS vectors)
         auto woff = [](unsigned t) { return t <= 5 ? t : ((1u << (t - 5)) + 4u); };
         const unsigned topw = d->logN >= 6 ? (1u << (d->logN - 6)) : 1u;  // words of a stage logN-1 block
         d->wppL = (woff(d->logN) + bitw) | 1u;                             // left children + the root output
@@ -130,7 +130,8 @@ void compute_geometry(pcd_decoder* d)
         const unsigned lo = d->logN < 6 ? d->logN : 6;
         for (unsigned s0 = d->logN; s0 + 1 > lo; --s0) {
             const size_t bytes = (size_t)lds_words(s0) * 4;
-            const unsigned waves = bytes > kMaxLds ? 0u : (unsigned)std::min<size_t>(8, kMaxLds / bytes);
+            // up to 16 waves per CU pay off (measured at cfg 3: s0 = 9 / 8 / 7 / 6 -> 7.5 / 6.3 / 11.1 / 10.8 M cw/s)
+            const unsigned waves = bytes > kMaxLds ? 0u : (unsigned)std::min<size_t>(16, kMaxLds / bytes);
             if (waves > best_waves) {
                 best_waves = waves;
                 best_s0 = s0;
@@ -226,10 +227,10 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     P.wave_lds_words = d->sc_wave_words;
     P.metrics = nullptr;
     const size_t lds = (size_t)d->sc_wpb * d->sc_wave_words * 4;
-    if (d->sc_blocks_per_cu == 0) {
-        const size_t by_lds = kMaxLds / lds;
-        const size_t by_waves = 32 / d->sc_wpb;
-        d->sc_blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(by_lds, std::min<size_t>(by_waves, 16)));
+    if (d->sc_blocks_per_cu == 0) {  // resident workgroups per CU: the grid is sized to exactly fill the chip
+        int occ = 0;
+        HIP_TRY(pamd::launch_sc(P, i8, 1, d->sc_wpb, lds, st, &occ));
+        d->sc_blocks_per_cu = std::max(1, occ);
     }
     const unsigned need = (unsigned)((P.rows + d->sc_wpb - 1) / d->sc_wpb);
     const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->sc_blocks_per_cu)));
@@ -248,10 +249,11 @@ int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     P.arena_path_stride = d->arena_path_stride;
     P.arena_wave_words = d->arena_wave_words;
     const size_t lds = (size_t)d->scl_wpb * d->scl_wave_words * 4;
-    if (d->scl_blocks_per_cu == 0) {
-        const size_t by_lds = kMaxLds / lds;
-        const size_t by_waves = 32 / d->scl_wpb;
-        d->scl_blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(by_lds, std::min<size_t>(by_waves, 16)));
+    if (d->scl_blocks_per_cu == 0) {  // resident workgroups per CU (LDS and VGPR limited)
+        int occ = 0;
+        HIP_TRY(pamd::launch_scl(P, d->lpl, i8, 1, d->scl_wpb, lds, st, &occ));
+        d->scl_blocks_per_cu = std::max(1, occ);
+        if (std::getenv("PCD_VERBOSE")) std::fprintf(stderr, "[pcd] scl: s0=%u lds=%zu B occupancy=%d blocks/CU\n", d->s0, lds, occ);
     }
     const unsigned need = (unsigned)((P.rows + d->scl_wpb - 1) / d->scl_wpb);
     const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->scl_blocks_per_cu)));

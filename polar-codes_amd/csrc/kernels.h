@@ -33,10 +33,11 @@ struct DecodeParams {
     uint32_t* cycles;        // diagnostics (nullable): row 0 only, s_memtime cycles spent per program instruction
 };
 
+// occupancy != nullptr: do not launch, return the resident workgroups per CU (occupancy API) in *occupancy
 hipError_t launch_sc(const DecodeParams& P, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,
-                     hipStream_t st);
+                     hipStream_t st, int* occupancy = nullptr);
 hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, unsigned waves_per_block,
-                      size_t lds, hipStream_t st);
+                      size_t lds, hipStream_t st, int* occupancy = nullptr);
 hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,
                                  hipStream_t st);
 

@@ -599,6 +599,8 @@ __device__ __forceinline__ uint32_t woff(uint32_t t) { return t <= 5 ? t : ((1u 
 // global "arena" (L2-resident scratch) for s0 <= stage < logN, and stage logN is the channel row itself.
 typedef float __attribute__((address_space(3))) lds_f32;
 enum { K_LDS = 0, K_GF32 = 1, K_GI8 = 2, K_ARENA = 3 };
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef v4f32 __attribute__((address_space(3))) lds_f32x4;
 template <int KIND>
 struct Rd {
     const void* p;
@@ -606,10 +608,23 @@ struct Rd {
     {
         if constexpr (KIND == K_LDS) return ((const lds_f32*)(uintptr_t)p)[i];
         else if constexpr (KIND == K_GI8) return (float)reinterpret_cast<const int8_t*>(p)[i];
-        else if constexpr (KIND == K_ARENA)
-            // written earlier by other lanes of this wave: read at L2 (sc1), never from a stale L1 line
-            return __hip_atomic_load(reinterpret_cast<const float*>(p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // K_ARENA: written earlier by other lanes of THIS wave; the stores were waited for (vmcnt(0)) and a CU's
+        // L1 is coherent for its own waves' accesses, so a plain load sees them
         else return reinterpret_cast<const float*>(p)[i];
+    }
+    // four consecutive LLRs, i % 4 == 0 and 16-byte aligned storage
+    __device__ __forceinline__ float4 ld4(uint32_t i) const
+    {
+        if constexpr (KIND == K_LDS) {
+            const v4f32 v = *(const lds_f32x4*)(uintptr_t)(reinterpret_cast<const float*>(p) + i);
+            return make_float4(v.x, v.y, v.z, v.w);
+        } else if constexpr (KIND == K_GI8) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const int8_t*>(p) + i);
+            return make_float4((float)(int8_t)(w & 0xFF), (float)(int8_t)((w >> 8) & 0xFF), (float)(int8_t)((w >> 16) & 0xFF),
+                               (float)(int8_t)(w >> 24));
+        } else {
+            return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+        }
     }
 };
 template <int KIND>
@@ -619,6 +634,18 @@ struct Wr {
     {
         if constexpr (KIND == K_LDS) ((lds_f32*)(uintptr_t)p)[i] = v;
         else reinterpret_cast<float*>(p)[i] = v;
+    }
+    __device__ __forceinline__ void st4(uint32_t i, float4 v) const
+    {
+        if constexpr (KIND == K_LDS) {
+            v4f32 t;
+            t.x = v.x;
+            t.y = v.y;
+            t.z = v.z;
+            t.w = v.w;
+            *(lds_f32x4*)(uintptr_t)(reinterpret_cast<float*>(p) + i) = t;
+        }
+        else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i) = v;
     }
 };
 
@@ -667,6 +694,28 @@ struct SclCtx {
         } else {
             fn(Rd<K_LDS>{ path_llr(q) + (1u << t) });
         }
+    }
+    // compile-time memory kind of stage t (wave uniform), and the per-path base pointer for that kind
+    template <bool I8, typename F>
+    __device__ __forceinline__ void with_src_kind(uint32_t t, F&& fn) const
+    {
+        if (t == logN) {
+            if constexpr (I8)
+                fn(std::integral_constant<int, K_GI8>{});
+            else
+                fn(std::integral_constant<int, K_GF32>{});
+        } else if (t >= s0) {
+            fn(std::integral_constant<int, K_ARENA>{});
+        } else {
+            fn(std::integral_constant<int, K_LDS>{});
+        }
+    }
+    template <int KIND>
+    __device__ __forceinline__ const void* src_base(uint32_t t, uint32_t q) const
+    {
+        if constexpr (KIND == K_LDS) return path_llr(q) + (1u << t);
+        else if constexpr (KIND == K_ARENA) return arena_stage(q, t);
+        else return chan;
     }
     template <typename F>
     __device__ __forceinline__ void with_dst(uint32_t t, uint32_t q, F&& fn) const
@@ -1180,12 +1229,24 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                 if (DIAG && (P.ablate & 8u) && h >= 64) {
                 } else if (DIAG && (P.ablate & 16u) && h < 64) {
                 } else if (h >= 64) {
-                    for (uint32_t q = 0; q < c.P; ++q)
-                        c.template with_src<I8>(s, q, [&](auto x) {
-                            c.with_dst(s - 1, q, [&](auto d) {
-                                for (uint32_t i = lane; i < h; i += 64) d.set(i, polar_f(x[i], x[h + i]));
-                            });
-                        });
+                    // 16-byte items: item e = (path q, 4 consecutive LLRs); several loads in flight per lane
+                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
+                    c.template with_src_kind<I8>(s, [&](auto KS) {
+                        constexpr int SK = decltype(KS)::value;
+                        const bool dst_arena = (s - 1) >= c.s0;
+#pragma unroll 2
+                        for (uint32_t e = lane; e < total; e += 64) {
+                            const uint32_t q = e >> ish, i = (e & (ipp - 1)) << 2;
+                            const Rd<SK> x{ c.template src_base<SK>(s, q) };
+                            const float4 a = x.ld4(i), b = x.ld4(h + i);
+                            const float4 r = make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z),
+                                                         polar_f(a.w, b.w));
+                            if (dst_arena)
+                                Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
+                            else
+                                Wr<K_LDS>{ c.path_llr(q) + h }.st4(i, r);
+                        }
+                    });
                 } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case)
                     if (active) {
                         const float* x = c.path_llr(c.p) + n;
@@ -1207,16 +1268,30 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                 if (DIAG && (P.ablate & 8u) && h >= 64) {
                 } else if (DIAG && (P.ablate & 16u) && h < 64) {
                 } else if (h >= 64) {
-                    for (uint32_t q = 0; q < c.P; ++q) {
-                        const uint32_t srcq = c.field(c.slot_of_group((int)q), s);
-                        const uint32_t* lb = c.area(0, q) + wo;
-                        c.template with_src<I8>(s, srcq, [&](auto x) {
-                            c.with_dst(s - 1, q, [&](auto d) {
-                                for (uint32_t i = lane; i < h; i += 64)
-                                    d.set(i, polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u));
-                            });
-                        });
-                    }
+                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
+                    c.template with_src_kind<I8>(s, [&](auto KS) {
+                        constexpr int SK = decltype(KS)::value;
+                        const bool dst_arena = (s - 1) >= c.s0;
+#pragma unroll 2
+                        for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+                            const uint32_t e = e0 + lane;
+                            const bool in = e < total;
+                            const uint32_t q = in ? (e >> ish) : 0u, i = (e & (ipp - 1)) << 2;
+                            // LLR[s] of path q lives in the buffer its slot word names (all lanes take part in the move)
+                            const uint32_t srcq = c.field(c.slot_from_lane((int)(q << LPL)), s);
+                            if (in) {
+                                const Rd<SK> x{ c.template src_base<SK>(s, srcq) };
+                                const float4 a = x.ld4(i), b = x.ld4(h + i);
+                                const uint32_t u = ((c.area(0, q) + wo)[i >> 5] >> (i & 31u)) & 0xFu;
+                                const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
+                                                             polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, u >> 3));
+                                if (dst_arena)
+                                    Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
+                                else
+                                    Wr<K_LDS>{ c.path_llr(q) + h }.st4(i, r);
+                            }
+                        }
+                    });
                 } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case); h <= 32: one bit word
                     if (active) {
                         const float* x = c.path_llr(c.field(c.slot, s)) + n;
@@ -1585,9 +1660,28 @@ __global__ void collect_failed_kernel(const uint8_t* ok, uint32_t rows, uint32_t
 // =============================================================================================
 //  launchers
 // =============================================================================================
+// grid == 0: do not launch, report the resident workgroups per CU for this block size / LDS size in *occ
 template <int LPL, bool I8, bool S64, bool DIAG>
-static hipError_t launch_scl_k(const DecodeParams& P, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+static hipError_t launch_scl_k(const DecodeParams& P, dim3 grid, dim3 block, size_t lds, hipStream_t st, int* occ)
 {
+    if (occ) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, scl_decode_kernel<LPL, I8, S64, DIAG>, (int)block.x, lds);
+        if (e != hipSuccess) return e;
+        // the API over-reports for single-wave workgroups: clamp by the register file (512 VGPRs per SIMD lane,
+        // allocation granule 8, at most 8 waves per SIMD; MI355X_MICROARCH.md "Register files")
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG>));
+        if (e != hipSuccess) return e;
+        const int regs = ((fa.numRegs > 0 ? fa.numRegs : 1) + 7) & ~7;
+        int waves_per_simd = 512 / regs;
+        if (waves_per_simd > 8) waves_per_simd = 8;
+        if (waves_per_simd < 1) waves_per_simd = 1;
+        const int by_regs = (4 * waves_per_simd) / (int)(block.x / 64);
+        if (*occ > by_regs) *occ = by_regs;
+        return hipSuccess;
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((scl_decode_kernel<LPL, I8, S64, DIAG>), grid, block, lds, st, P);
@@ -1599,47 +1693,49 @@ static hipError_t launch_scl_k(const DecodeParams& P, dim3 grid, dim3 block, siz
 // diagnostic variant (trace / cycle stamps / ablation switches) for float input only.
 template <int LPL>
 static hipError_t launch_scl_t(const DecodeParams& P, bool i8, bool slot64, bool diag, dim3 grid, dim3 block, size_t lds,
-                               hipStream_t st)
+                               hipStream_t st, int* occ)
 {
-    if (diag && !i8) return launch_scl_k<LPL, false, true, true>(P, grid, block, lds, st);
+    if (diag && !i8) return launch_scl_k<LPL, false, true, true>(P, grid, block, lds, st, occ);
     if constexpr (LPL == 3) {
         if (!slot64)
-            return i8 ? launch_scl_k<LPL, true, false, false>(P, grid, block, lds, st)
-                      : launch_scl_k<LPL, false, false, false>(P, grid, block, lds, st);
+            return i8 ? launch_scl_k<LPL, true, false, false>(P, grid, block, lds, st, occ)
+                      : launch_scl_k<LPL, false, false, false>(P, grid, block, lds, st, occ);
     }
-    return i8 ? launch_scl_k<LPL, true, true, false>(P, grid, block, lds, st)
-              : launch_scl_k<LPL, false, true, false>(P, grid, block, lds, st);
+    return i8 ? launch_scl_k<LPL, true, true, false>(P, grid, block, lds, st, occ)
+              : launch_scl_k<LPL, false, true, false>(P, grid, block, lds, st, occ);
 }
 
 hipError_t launch_sc(const DecodeParams& P, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,
-                     hipStream_t st)
+                     hipStream_t st, int* occupancy)
 {
     dim3 g(grid), b(64 * waves_per_block);
     if (i8) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<true>, (int)b.x, lds);
         hipLaunchKernelGGL((sc_decode_kernel<true>), g, b, lds, st, P);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<false>, (int)b.x, lds);
         hipLaunchKernelGGL((sc_decode_kernel<false>), g, b, lds, st, P);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, unsigned waves_per_block,
-                      size_t lds, hipStream_t st)
+                      size_t lds, hipStream_t st, int* occupancy)
 {
     dim3 g(grid), b(64 * waves_per_block);
     const bool diag = P.trace || P.cycles || P.ablate;
     const unsigned fb = 6u - (unsigned)lpl;
     const bool slot64 = P.logN * fb > 32u;
     switch (lpl) {
-    case 1: return launch_scl_t<1>(P, i8, slot64, diag, g, b, lds, st);
-    case 2: return launch_scl_t<2>(P, i8, slot64, diag, g, b, lds, st);
-    case 3: return launch_scl_t<3>(P, i8, slot64, diag, g, b, lds, st);
-    case 4: return launch_scl_t<4>(P, i8, slot64, diag, g, b, lds, st);
-    case 5: return launch_scl_t<5>(P, i8, slot64, diag, g, b, lds, st);
+    case 1: return launch_scl_t<1>(P, i8, slot64, diag, g, b, lds, st, occupancy);
+    case 2: return launch_scl_t<2>(P, i8, slot64, diag, g, b, lds, st, occupancy);
+    case 3: return launch_scl_t<3>(P, i8, slot64, diag, g, b, lds, st, occupancy);
+    case 4: return launch_scl_t<4>(P, i8, slot64, diag, g, b, lds, st, occupancy);
+    case 5: return launch_scl_t<5>(P, i8, slot64, diag, g, b, lds, st, occupancy);
     default: return hipErrorInvalidValue;
     }
 }
