@@ -124,7 +124,8 @@ void compute_geometry(pcd_decoder* d)
         d->wppR = (woff(d->logN ? d->logN - 1 : 0) + topw) | 1u;           // right children: stages < logN
         // LLR stages [s0, logN) go to a global arena; pick s0 for the best occupancy (ties: the most LDS)
         auto lds_words = [&](unsigned s0) {
-            return (lmax * ((1u << s0) + pad) + lmax * (d->wppL + d->wppR) + 3) & ~3u;
+            // path LLR buffers | left / right bit areas (rounded to 16 B) | 64 words of scratch
+            return ((lmax * ((1u << s0) + pad) + lmax * (d->wppL + d->wppR) + 3) & ~3u) + 64u;
         };
         unsigned best_s0 = d->logN, best_waves = 0;
         const unsigned lo = d->logN < 6 ? d->logN : 6;

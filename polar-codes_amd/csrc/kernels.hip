@@ -662,6 +662,7 @@ struct SclCtx {
     uint32_t* bitsR;
     uint32_t path_stride, wppL, wppR;
     uint32_t ablate;
+    uint32_t* scratch;  // 64 LDS words of per-wave scratch (candidate keys)
     float* arena;  // this wave's global scratch (stages >= s0)
     uint32_t arena_path_stride, s0, logN;
     const void* chan;
@@ -1090,12 +1091,31 @@ __device__ __forceinline__ void select_ranked8(const CTX& c, float val, uint32_t
     constexpr int CS = CPP == 8 ? 3 : (CPP == 4 ? 2 : 1);
     const bool valid = ((uint32_t)c.j < (uint32_t)CPP) && ((uint32_t)c.p < c.P);
     const uint32_t key = valid ? okey(val) : 0u;  // 0 is below every real key
+    // every lane compares its key with all candidate keys: the keys go through a 64-word LDS scratch and come
+    // back as broadcast 16-byte reads (pure VALU compares, no v_readlane -> SGPR -> v_cmp hazards)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 __attribute__((address_space(3))) lds_u32x4;
+    typedef uint32_t __attribute__((address_space(3))) lds_u32;
+    ((lds_u32*)(uintptr_t)c.scratch)[c.lane] = key;
+    WAVE_SYNC();
     uint32_t gt = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         if ((uint32_t)q < c.P) {  // wave uniform
-#pragma unroll
-            for (int r = 0; r < CPP; ++r) gt += (readlane_u32(key, q * 8 + r) > key) ? 1u : 0u;
+            const u32x4 k0 = *(const lds_u32x4*)(uintptr_t)(c.scratch + q * 8);
+            gt += (k0.x > key) ? 1u : 0u;
+            if constexpr (CPP > 1) gt += (k0.y > key) ? 1u : 0u;
+            if constexpr (CPP > 2) {
+                gt += (k0.z > key) ? 1u : 0u;
+                gt += (k0.w > key) ? 1u : 0u;
+            }
+            if constexpr (CPP > 4) {
+                const u32x4 k1 = *(const lds_u32x4*)(uintptr_t)(c.scratch + q * 8 + 4);
+                gt += (k1.x > key) ? 1u : 0u;
+                gt += (k1.y > key) ? 1u : 0u;
+                gt += (k1.z > key) ? 1u : 0u;
+                gt += (k1.w > key) ? 1u : 0u;
+            }
         }
     }
     const bool sel = valid && gt < newP;
@@ -1158,8 +1178,9 @@ __device__ __forceinline__ void write_leaf_bits(const CTX& c, const SRC& x, uint
     }
 }
 
+// 4 waves per SIMD (<= 128 VGPRs) for the L <= 8 production kernels: occupancy is what hides the LDS / arena latency
 template <int LPL, bool I8, bool S64, bool DIAG>
-__global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
+__global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_kernel(DecodeParams P)
 {
     using Ctx = SclCtx<LPL, S64>;
     constexpr int LP = Ctx::LP;
@@ -1175,6 +1196,7 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
     c.llr = reinterpret_cast<float*>(wl);
     c.bitsL = wl + (size_t)LMAX * P.path_stride;
     c.bitsR = c.bitsL + (size_t)LMAX * P.wppL;
+    c.scratch = wl + (((size_t)LMAX * P.path_stride + (size_t)LMAX * (P.wppL + P.wppR) + 3) & ~(size_t)3);  // 16-byte aligned
     c.path_stride = P.path_stride;
     c.wppL = P.wppL;
     c.wppR = P.wppR;
@@ -1223,188 +1245,10 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
     }
 
             if (DIAG && ((P.ablate & 128u) || ((P.ablate & 64u) && ins.op >= SCL_R0))) continue;
-            switch (ins.op) {
-            // ------------------------------------------------------------------ inner node ops
-            case SCL_F: {  // RateRNode::decode :233-238 -- reads the path's own (identity) buffer
-                if (DIAG && (P.ablate & 8u) && h >= 64) {
-                } else if (DIAG && (P.ablate & 16u) && h < 64) {
-                } else if (h >= 64) {
-                    // 16-byte items: item e = (path q, 4 consecutive LLRs); several loads in flight per lane
-                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
-                    c.template with_src_kind<I8>(s, [&](auto KS) {
-                        constexpr int SK = decltype(KS)::value;
-                        const bool dst_arena = (s - 1) >= c.s0;
-#pragma unroll 2
-                        for (uint32_t e = lane; e < total; e += 64) {
-                            const uint32_t q = e >> ish, i = (e & (ipp - 1)) << 2;
-                            const Rd<SK> x{ c.template src_base<SK>(s, q) };
-                            const float4 a = x.ld4(i), b = x.ld4(h + i);
-                            const float4 r = make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z),
-                                                         polar_f(a.w, b.w));
-                            if (dst_arena)
-                                Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
-                            else
-                                Wr<K_LDS>{ c.path_llr(q) + h }.st4(i, r);
-                        }
-                    });
-                } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case)
-                    if (active) {
-                        const float* x = c.path_llr(c.p) + n;
-                        float* d = c.path_llr(c.p) + h;
-                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_f(x[i], x[h + i]);
-                    }
-                } else if (active) {
-                    c.template with_src<I8>(s, c.p, [&](auto x) {
-                        c.with_dst(s - 1, c.p, [&](auto d) {
-                            for (uint32_t i = c.j; i < h; i += LP) d.set(i, polar_f(x[i], x[h + i]));
-                        });
-                    });
-                }
-                c.set_field(s);
-                break;
-            }
-            case SCL_G: {  // :242-249 -- LLR[s] through the slot word, left bits at identity
-                const uint32_t wo = woff(s - 1);
-                if (DIAG && (P.ablate & 8u) && h >= 64) {
-                } else if (DIAG && (P.ablate & 16u) && h < 64) {
-                } else if (h >= 64) {
-                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
-                    c.template with_src_kind<I8>(s, [&](auto KS) {
-                        constexpr int SK = decltype(KS)::value;
-                        const bool dst_arena = (s - 1) >= c.s0;
-#pragma unroll 2
-                        for (uint32_t e0 = 0; e0 < total; e0 += 64) {
-                            const uint32_t e = e0 + lane;
-                            const bool in = e < total;
-                            const uint32_t q = in ? (e >> ish) : 0u, i = (e & (ipp - 1)) << 2;
-                            // LLR[s] of path q lives in the buffer its slot word names (all lanes take part in the move)
-                            const uint32_t srcq = c.field(c.slot_from_lane((int)(q << LPL)), s);
-                            if (in) {
-                                const Rd<SK> x{ c.template src_base<SK>(s, srcq) };
-                                const float4 a = x.ld4(i), b = x.ld4(h + i);
-                                const uint32_t u = ((c.area(0, q) + wo)[i >> 5] >> (i & 31u)) & 0xFu;
-                                const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
-                                                             polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, u >> 3));
-                                if (dst_arena)
-                                    Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
-                                else
-                                    Wr<K_LDS>{ c.path_llr(q) + h }.st4(i, r);
-                            }
-                        }
-                    });
-                } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case); h <= 32: one bit word
-                    if (active) {
-                        const float* x = c.path_llr(c.field(c.slot, s)) + n;
-                        float* d = c.path_llr(c.p) + h;
-                        const uint32_t lw = (c.area(0, c.p) + wo)[0];
-                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
-                    }
-                } else if (active) {
-                    const uint32_t srcq = c.field(c.slot, s);
-                    const uint32_t* lb = c.area(0, c.p) + wo;
-                    c.template with_src<I8>(s, srcq, [&](auto x) {
-                        c.with_dst(s - 1, c.p, [&](auto d) {
-                            for (uint32_t i = c.j; i < h; i += LP)
-                                d.set(i, polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u));
-                        });
-                    });
-                }
-                c.set_field(s);  // from now on the field names the holder of the LEFT bits
-                break;
-            }
-            case SCL_COMBINE: {  // :253-260 CombineBitsLong / CombineBitsShort
-                if (active && !(DIAG && (P.ablate & 16u))) {
-                    const uint32_t lq = c.field(c.slot, s);
-                    const uint32_t* lb = c.area(0, lq) + woff(s - 1);
-                    const uint32_t* rb = c.area(1, c.p) + woff(s - 1);
-                    uint32_t* ob = c.area(side, c.p) + woff(s);
-                    if (h >= 32) {
-                        const uint32_t hw = h >> 5;
-                        for (uint32_t w = c.j; w < hw; w += LP) {
-                            const uint32_t r = rb[w];
-                            ob[w] = lb[w] ^ r;
-                            ob[hw + w] = r;
-                        }
-                    } else if (c.j == 0) {
-                        const uint32_t mask = (1u << h) - 1u;
-                        const uint32_t r = rb[0] & mask;
-                        ob[0] = ((lb[0] ^ r) & mask) | (r << h);
-                    }
-                }
-                break;
-            }
-            // ------------------------------------------------------------------ leaves
-            case SCL_R0: {  // RateZeroDecoder::decode :316-337
-                float acc[NACC];
-#pragma unroll
-                for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
-                if (active && (LP < 8 || c.j < 8)) {
-                    auto body = [&](auto x) {
-#pragma unroll
-                        for (int a = 0; a < NACC; ++a) {
-                            const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
-                            for (uint32_t i = v; i < n; i += 8) acc[a] = acc[a] + min0(x[i]);
-                            if (v >= n) acc[a] = acc[a] + 0.0f;
-                        }
-                    };
-                    if (s < c.s0 && s < logN)
-                        body(Rd<K_LDS>{ c.path_llr(c.p) + n });
-                    else
-                        c.template with_src<I8>(s, c.p, body);
-                }
-                const float sum = c.lanesum_finish(acc);
-                if (active) {
-                    c.metric = c.metric + sum;
-                    uint32_t* ob = c.area(side, c.p) + woff(s);
-                    const uint32_t nw = n >= 32 ? (n >> 5) : 1u;
-                    for (uint32_t w = c.j; w < nw; w += LP) ob[w] = 0u;
-                }
-                break;
-            }
-            case SCL_REP: {  // RepetitionDecoder::decode :428-481 (n = 2 or 4)
-                float az[NACC], ao[NACC];
-#pragma unroll
-                for (int a = 0; a < NACC; ++a) az[a] = ao[a] = 0.0f;
-                if (active && (LP < 8 || c.j < 8)) {
-                    auto body = [&](auto x) {
-#pragma unroll
-                        for (int a = 0; a < NACC; ++a) {
-                            const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
-                            const float xv = v < n ? x[v < n ? v : 0] : 0.0f;
-                            az[a] = az[a] + min0(xv);
-                            ao[a] = ao[a] + max0(xv);
-                        }
-                    };
-                    if (s < c.s0 && s < logN)
-                        body(Rd<K_LDS>{ c.path_llr(c.p) + n });
-                    else
-                        c.template with_src<I8>(s, c.p, body);
-                }
-                const float z = c.lanesum_finish(az), o = c.lanesum_finish(ao);
-                constexpr int CPL = (2 >> LPL) ? (2 >> LPL) : 1;
-                float val[CPL];
-#pragma unroll
-                for (int r = 0; r < CPL; ++r) {
-                    const uint32_t q = (uint32_t)c.j * CPL + r;
-                    val[r] = (q == 0) ? c.metric + z : c.metric - o;
-                }
-                const uint32_t newP = (c.P * 2 < c.L) ? c.P * 2 : c.L;
-                float nval;
-                uint32_t nidx;
-                select_dispatch<Ctx, LPL, 2>(c, val, (c.metric + z > c.metric - o) ? c.metric + z : c.metric - o, newP, nval, nidx);
-                const uint32_t srcp = nidx >> 1, q = nidx & 1u;
-                const typename Ctx::SlotT nslot = c.slot_from_lane((int)(srcp << LPL));
-                c.P = newP;
-                if ((uint32_t)c.p < c.P) {
-                    c.metric = nval;
-                    c.slot = nslot;
-                    if (c.j == 0) (c.area(side, c.p) + woff(s))[0] = q ? ((1u << n) - 1u) : 0u;
-                }
-                break;
-            }
-            case SCL_R1:     // RateOneDecoder::decode :353-413
-            case SCL_SPC: {  // SpcDecoder::decode     :498-621
-                const bool spc = ins.op == SCL_SPC;
+            // dispatch ordered by frequency (F / G / COMBINE are three quarters of the program); the two forking
+            // leaves share one generic body instantiated separately, so each variant is straight-line code
+            auto fork_leaf = [&](auto SPC_T) {  // SpcDecoder::decode     :498-621
+                constexpr bool spc = decltype(SPC_T)::value;
                 Weak<4> wk;
                 uint32_t par = 0;
                 auto search = [&](auto x) {
@@ -1549,9 +1393,177 @@ __global__ __launch_bounds__(256) void scl_decode_kernel(DecodeParams P)
                     c.template with_src<I8>(s, srcp,
                                             [&](auto x) { write_leaf_bits<Ctx>(c, x, s, side, nact, fmask, fpos); });
                 }
-                break;
-            }
-            default: break;
+            };
+            if (ins.op == SCL_F) {  // RateRNode::decode :233-238 -- reads the path's own (identity) buffer
+                if (DIAG && (P.ablate & 8u) && h >= 64) {
+                } else if (DIAG && (P.ablate & 16u) && h < 64) {
+                } else if (h >= 64) {
+                    // 16-byte items: item e = (path q, 4 consecutive LLRs); several loads in flight per lane
+                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
+                    c.template with_src_kind<I8>(s, [&](auto KS) {
+                        constexpr int SK = decltype(KS)::value;
+                        const bool dst_arena = (s - 1) >= c.s0;
+#pragma unroll 2
+                        for (uint32_t e = lane; e < total; e += 64) {
+                            const uint32_t q = e >> ish, i = (e & (ipp - 1)) << 2;
+                            const Rd<SK> x{ c.template src_base<SK>(s, q) };
+                            const float4 a = x.ld4(i), b = x.ld4(h + i);
+                            const float4 r = make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z),
+                                                         polar_f(a.w, b.w));
+                            if (dst_arena)
+                                Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
+                            else
+                                Wr<K_LDS>{ c.path_llr(q) + h }.st4(i, r);
+                        }
+                    });
+                } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case)
+                    if (active) {
+                        const float* x = c.path_llr(c.p) + n;
+                        float* d = c.path_llr(c.p) + h;
+                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_f(x[i], x[h + i]);
+                    }
+                } else if (active) {
+                    c.template with_src<I8>(s, c.p, [&](auto x) {
+                        c.with_dst(s - 1, c.p, [&](auto d) {
+                            for (uint32_t i = c.j; i < h; i += LP) d.set(i, polar_f(x[i], x[h + i]));
+                        });
+                    });
+                }
+                c.set_field(s);
+            } else if (ins.op == SCL_G) {  // :242-249 -- LLR[s] through the slot word, left bits at identity
+                const uint32_t wo = woff(s - 1);
+                if (DIAG && (P.ablate & 8u) && h >= 64) {
+                } else if (DIAG && (P.ablate & 16u) && h < 64) {
+                } else if (h >= 64) {
+                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
+                    c.template with_src_kind<I8>(s, [&](auto KS) {
+                        constexpr int SK = decltype(KS)::value;
+                        const bool dst_arena = (s - 1) >= c.s0;
+#pragma unroll 2
+                        for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+                            const uint32_t e = e0 + lane;
+                            const bool in = e < total;
+                            const uint32_t q = in ? (e >> ish) : 0u, i = (e & (ipp - 1)) << 2;
+                            // LLR[s] of path q lives in the buffer its slot word names (all lanes take part in the move)
+                            const uint32_t srcq = c.field(c.slot_from_lane((int)(q << LPL)), s);
+                            if (in) {
+                                const Rd<SK> x{ c.template src_base<SK>(s, srcq) };
+                                const float4 a = x.ld4(i), b = x.ld4(h + i);
+                                const uint32_t u = ((c.area(0, q) + wo)[i >> 5] >> (i & 31u)) & 0xFu;
+                                const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
+                                                             polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, u >> 3));
+                                if (dst_arena)
+                                    Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
+                                else
+                                    Wr<K_LDS>{ c.path_llr(q) + h }.st4(i, r);
+                            }
+                        }
+                    });
+                } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case); h <= 32: one bit word
+                    if (active) {
+                        const float* x = c.path_llr(c.field(c.slot, s)) + n;
+                        float* d = c.path_llr(c.p) + h;
+                        const uint32_t lw = (c.area(0, c.p) + wo)[0];
+                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
+                    }
+                } else if (active) {
+                    const uint32_t srcq = c.field(c.slot, s);
+                    const uint32_t* lb = c.area(0, c.p) + wo;
+                    c.template with_src<I8>(s, srcq, [&](auto x) {
+                        c.with_dst(s - 1, c.p, [&](auto d) {
+                            for (uint32_t i = c.j; i < h; i += LP)
+                                d.set(i, polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u));
+                        });
+                    });
+                }
+                c.set_field(s);  // from now on the field names the holder of the LEFT bits
+            } else if (ins.op == SCL_COMBINE) {  // :253-260 CombineBitsLong / CombineBitsShort
+                if (active && !(DIAG && (P.ablate & 16u))) {
+                    const uint32_t lq = c.field(c.slot, s);
+                    const uint32_t* lb = c.area(0, lq) + woff(s - 1);
+                    const uint32_t* rb = c.area(1, c.p) + woff(s - 1);
+                    uint32_t* ob = c.area(side, c.p) + woff(s);
+                    if (h >= 32) {
+                        const uint32_t hw = h >> 5;
+                        for (uint32_t w = c.j; w < hw; w += LP) {
+                            const uint32_t r = rb[w];
+                            ob[w] = lb[w] ^ r;
+                            ob[hw + w] = r;
+                        }
+                    } else if (c.j == 0) {
+                        const uint32_t mask = (1u << h) - 1u;
+                        const uint32_t r = rb[0] & mask;
+                        ob[0] = ((lb[0] ^ r) & mask) | (r << h);
+                    }
+                }
+            } else if (ins.op == SCL_R0) {  // RateZeroDecoder::decode :316-337
+                float acc[NACC];
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+                if (active && (LP < 8 || c.j < 8)) {
+                    auto body = [&](auto x) {
+#pragma unroll
+                        for (int a = 0; a < NACC; ++a) {
+                            const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
+                            for (uint32_t i = v; i < n; i += 8) acc[a] = acc[a] + min0(x[i]);
+                            if (v >= n) acc[a] = acc[a] + 0.0f;
+                        }
+                    };
+                    if (s < c.s0 && s < logN)
+                        body(Rd<K_LDS>{ c.path_llr(c.p) + n });
+                    else
+                        c.template with_src<I8>(s, c.p, body);
+                }
+                const float sum = c.lanesum_finish(acc);
+                if (active) {
+                    c.metric = c.metric + sum;
+                    uint32_t* ob = c.area(side, c.p) + woff(s);
+                    const uint32_t nw = n >= 32 ? (n >> 5) : 1u;
+                    for (uint32_t w = c.j; w < nw; w += LP) ob[w] = 0u;
+                }
+            } else if (ins.op == SCL_REP) {  // RepetitionDecoder::decode :428-481 (n = 2 or 4)
+                float az[NACC], ao[NACC];
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) az[a] = ao[a] = 0.0f;
+                if (active && (LP < 8 || c.j < 8)) {
+                    auto body = [&](auto x) {
+#pragma unroll
+                        for (int a = 0; a < NACC; ++a) {
+                            const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
+                            const float xv = v < n ? x[v < n ? v : 0] : 0.0f;
+                            az[a] = az[a] + min0(xv);
+                            ao[a] = ao[a] + max0(xv);
+                        }
+                    };
+                    if (s < c.s0 && s < logN)
+                        body(Rd<K_LDS>{ c.path_llr(c.p) + n });
+                    else
+                        c.template with_src<I8>(s, c.p, body);
+                }
+                const float z = c.lanesum_finish(az), o = c.lanesum_finish(ao);
+                constexpr int CPL = (2 >> LPL) ? (2 >> LPL) : 1;
+                float val[CPL];
+#pragma unroll
+                for (int r = 0; r < CPL; ++r) {
+                    const uint32_t q = (uint32_t)c.j * CPL + r;
+                    val[r] = (q == 0) ? c.metric + z : c.metric - o;
+                }
+                const uint32_t newP = (c.P * 2 < c.L) ? c.P * 2 : c.L;
+                float nval;
+                uint32_t nidx;
+                select_dispatch<Ctx, LPL, 2>(c, val, (c.metric + z > c.metric - o) ? c.metric + z : c.metric - o, newP, nval, nidx);
+                const uint32_t srcp = nidx >> 1, q = nidx & 1u;
+                const typename Ctx::SlotT nslot = c.slot_from_lane((int)(srcp << LPL));
+                c.P = newP;
+                if ((uint32_t)c.p < c.P) {
+                    c.metric = nval;
+                    c.slot = nslot;
+                    if (c.j == 0) (c.area(side, c.p) + woff(s))[0] = q ? ((1u << n) - 1u) : 0u;
+                }
+            } else if (ins.op == SCL_SPC) {
+                fork_leaf(std::true_type{});
+            } else if (ins.op == SCL_R1) {
+                fork_leaf(std::false_type{});
             }
             if (ins.op <= SCL_G && s - 1 >= c.s0) {
                 // this op stored LLRs to the global arena: wait for the stores (L2 is the meeting point; the
