@@ -46,7 +46,8 @@ struct pcd_decoder {
     bool has_sc = false, has_scl = false;
 
     // launch geometry
-    unsigned sc_wave_words = 0, sc_wpb = 4;
+    unsigned sc_wave_words = 0, sc_wpb = 4;  // LDS words per codeword, waves per workgroup
+    int sc_lcl = 4;                           // log2(lanes per codeword): 4 -> four codewords per wave
     int lpl = 3;
     unsigned lmax = 8, path_stride = 0, wppL = 0, wppR = 0, scl_wave_words = 0, scl_wpb = 1;
     unsigned s0 = 0, arena_path_stride = 0, arena_wave_words = 0;
@@ -107,10 +108,15 @@ void compute_geometry(pcd_decoder* d)
 {
     const unsigned N = d->N;
     const unsigned bitw = N >= 32 ? N / 32 : 1;
-    d->sc_wave_words = (2 * N + bitw + 3) & ~3u;
-    unsigned wpb = 4;
-    while (wpb > 1 && (size_t)wpb * d->sc_wave_words * 4 > kMaxLds / 2) wpb >>= 1;
-    d->sc_wpb = wpb;
+    // SC: N floats (stages below the root) + packed bits per codeword; 64/LC codewords per wave
+    d->sc_wave_words = (N + bitw + 3) & ~3u;
+    d->sc_lcl = N <= 1024 ? 4 : 6;
+    if (const char* e = std::getenv("PCD_SC_LCL")) {  // experiments
+        const int v = std::atoi(e);
+        d->sc_lcl = (v == 3 || v == 6) ? v : 4;
+    }
+    d->sc_wpb = 1;  // single-wave workgroups: LDS granularity of one wave, nothing is shared between waves anyway
+    if (const char* e = std::getenv("PCD_SC_WPB")) d->sc_wpb = (unsigned)std::max(1, std::atoi(e));
     if (d->L > 1) {
         unsigned lmax = 2;
         while (lmax < d->L) lmax <<= 1;
@@ -227,15 +233,19 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     P.prog = d->d_sc_prog;
     P.wave_lds_words = d->sc_wave_words;
     P.metrics = nullptr;
-    const size_t lds = (size_t)d->sc_wpb * d->sc_wave_words * 4;
+    const unsigned cw_per_wave = 64u >> d->sc_lcl;
+    const size_t lds = (size_t)d->sc_wpb * cw_per_wave * d->sc_wave_words * 4;
     if (d->sc_blocks_per_cu == 0) {  // resident workgroups per CU: the grid is sized to exactly fill the chip
         int occ = 0;
-        HIP_TRY(pamd::launch_sc(P, i8, 1, d->sc_wpb, lds, st, &occ));
+        HIP_TRY(pamd::launch_sc(P, d->sc_lcl, i8, 1, d->sc_wpb, lds, st, &occ));
         d->sc_blocks_per_cu = std::max(1, occ);
+        if (std::getenv("PCD_VERBOSE"))
+            std::fprintf(stderr, "[pcd] sc: %u codewords/wave, lds=%zu B/workgroup, occupancy=%d blocks/CU\n", cw_per_wave, lds, occ);
     }
-    const unsigned need = (unsigned)((P.rows + d->sc_wpb - 1) / d->sc_wpb);
+    const unsigned cw_per_block = d->sc_wpb * cw_per_wave;
+    const unsigned need = (unsigned)((P.rows + cw_per_block - 1) / cw_per_block);
     const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->sc_blocks_per_cu)));
-    HIP_TRY(pamd::launch_sc(P, i8, grid, d->sc_wpb, lds, st));
+    HIP_TRY(pamd::launch_sc(P, d->sc_lcl, i8, grid, d->sc_wpb, lds, st));
     return PCD_OK;
 }
 
@@ -418,7 +428,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         d->has_scl = true;
     }
     compute_geometry(d);
-    if ((size_t)d->sc_wave_words * 4 > kMaxLds && d->has_sc) {
+    if ((size_t)d->sc_wave_words * 4 * (64u >> d->sc_lcl) > kMaxLds && d->has_sc) {
         delete d;
         return fail(PCD_ERR_CAPACITY, "block length too large for the SC kernel's LDS layout");
     }
@@ -530,9 +540,9 @@ int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4])
     } else {
         if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
         info[0] = d->sc_wave_words * 4;
-        info[1] = d->sc_wpb;
+        info[1] = d->sc_wpb * (64u >> d->sc_lcl);
         info[2] = 1;
-        info[3] = (unsigned)(kMaxLds / ((size_t)d->sc_wpb * d->sc_wave_words * 4));
+        info[3] = (unsigned)(kMaxLds / ((size_t)info[1] * d->sc_wave_words * 4));
     }
     return PCD_OK;
 }

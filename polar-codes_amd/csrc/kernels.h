@@ -25,7 +25,7 @@ struct DecodeParams {
     float* arena;            // SCL: global scratch for LLR stages >= s0 (one slice per resident wave)
     uint32_t arena_wave_words, arena_path_stride;
     uint32_t s0;             // SCL: first LLR stage kept in the arena (logN = none)
-    uint32_t wave_lds_words; // LDS words one wave (one codeword) owns
+    uint32_t wave_lds_words; // LDS words one codeword owns (SCL: one wave = one codeword; SC: 64/LC codewords per wave)
     float* trace;            // diagnostics (nullable): row 0 only, (1 + L) floats after every SCL leaf
     uint32_t trace_cap;
     uint32_t prog_len;
@@ -34,7 +34,7 @@ struct DecodeParams {
 };
 
 // occupancy != nullptr: do not launch, return the resident workgroups per CU (occupancy API) in *occupancy
-hipError_t launch_sc(const DecodeParams& P, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,
+hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,
                      hipStream_t st, int* occupancy = nullptr);
 hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, unsigned waves_per_block,
                       size_t lds, hipStream_t st, int* occupancy = nullptr);

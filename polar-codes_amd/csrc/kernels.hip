@@ -189,358 +189,363 @@ __device__ __forceinline__ uint32_t spc4_signs(const float in[4])
 // =============================================================================================
 //  Fast-SSC
 // =============================================================================================
-// LDS per wave: llr[2N] floats (stage s at offset 1<<s; the channel row is stage logN at offset N)
-//               bits[max(1, N/32)] words, code bit i = word i>>5, bit i&31.
-
-// store `cnt` (<= 64) bits of `m` at code-bit offset `off` (off is a multiple of cnt when cnt < 32)
-__device__ __forceinline__ void sc_put_bits(uint32_t* bits, uint32_t off, uint32_t cnt, uint64_t m, int lane)
-{
-    if (cnt >= 64) {
-        if (lane < 2) bits[(off >> 5) + lane] = (uint32_t)(m >> (32 * lane));
-    } else if (cnt == 32) {
-        if (lane == 0) bits[off >> 5] = (uint32_t)m;
-    } else {
-        if (lane == 0) {
+// LC = 2^LCL lanes work on one codeword, so a wave decodes 64/LC codewords side by side (LC = 16 for
+// N <= 1024: the tree ops below stage 6 have at most 16 elements, and every wave-uniform cost -- program
+// fetch, dispatch, address arithmetic -- is shared by the four codewords).  Control flow is identical for
+// all codewords, so nothing diverges.
+// LDS per codeword: llr[N] floats (stage s < logN at offset 1<<s; the channel row is read from global
+// memory by the root ops) + max(1, N/32) words of packed partial sums (code bit i = word i>>5, bit i&31).
+template <int LCL>
+struct ScLanes {
+    static constexpr int LC = 1 << LCL;
+    static constexpr uint64_t MASK = LC == 64 ? ~0ull : ((1ull << LC) - 1ull);
+    int l;       // lane inside the codeword group
+    int lbase;   // first wave lane of the group
+    __device__ __forceinline__ uint64_t slice(uint64_t ballot) const { return (ballot >> lbase) & MASK; }
+    // store `cnt` (<= LC) bits of m at code-bit offset off (off % cnt == 0 when cnt < 32)
+    __device__ __forceinline__ void put_bits(uint32_t* bits, uint32_t off, uint32_t cnt, uint64_t m) const
+    {
+        if (cnt >= 64) {
+            if (l < 2) bits[(off >> 5) + l] = (uint32_t)(m >> (32 * l));
+        } else if (cnt == 32) {
+            if (l == 0) bits[off >> 5] = (uint32_t)m;
+        } else if (l == 0) {
             const uint32_t sh = off & 31u, mask = ((1u << cnt) - 1u) << sh;
             const uint32_t w = bits[off >> 5];
             bits[off >> 5] = (w & ~mask) | (((uint32_t)m << sh) & mask);
         }
     }
-}
-__device__ __forceinline__ void sc_flip_bit(uint32_t* bits, uint32_t pos, int lane)
-{
-    if (lane == 0) bits[pos >> 5] ^= 1u << (pos & 31u);
-}
-// fill n bits at off with a repeating 32-bit pattern (pattern period divides 32 and n)
-__device__ __forceinline__ void sc_fill_pattern(uint32_t* bits, uint32_t off, uint32_t n, uint32_t pat, int lane)
-{
-    if (n >= 32) {
-        for (uint32_t w = lane; w < (n >> 5); w += 64) bits[(off >> 5) + w] = pat;
-    } else {
-        sc_put_bits(bits, off, n, pat & ((1u << n) - 1u), lane);
+    __device__ __forceinline__ void flip_bit(uint32_t* bits, uint32_t pos) const
+    {
+        if (l == 0) bits[pos >> 5] ^= 1u << (pos & 31u);
     }
-}
-
-// the reference's fold8 (8 strided AVX accumulators, acc = 0; acc += x[8k+v]); result broadcast
-__device__ __forceinline__ void sc_fold8(const float* x, uint32_t n, int lane, float a[8])
-{
-    float acc = 0.0f;
-    if (lane < 8) {
-        for (uint32_t i = lane; i < n; i += 8) acc = acc + x[i];
-        if ((uint32_t)lane >= n) acc = acc + 0.0f;
+    // fill n bits at off with a repeating 32-bit pattern (pattern period divides 32 and n)
+    __device__ __forceinline__ void fill_pattern(uint32_t* bits, uint32_t off, uint32_t n, uint32_t pat) const
+    {
+        if (n >= 32) {
+            for (uint32_t w = l; w < (n >> 5); w += LC) bits[(off >> 5) + w] = pat;
+        } else {
+            put_bits(bits, off, n, pat & ((1u << n) - 1u));
+        }
     }
+    // the reference's fold8 (8 strided AVX accumulators, acc = 0; acc += x[8k+v]); result broadcast in the group
+    template <typename X>
+    __device__ __forceinline__ void fold8(const X& x, uint32_t n, float a[8]) const
+    {
+        float acc = 0.0f;
+        if (l < 8)
+            for (uint32_t i = l; i < n; i += 8) acc = acc + x(i);
 #pragma unroll
-    for (int v = 0; v < 8; ++v) a[v] = shfl_f32(acc, v);
-}
+        for (int v = 0; v < 8; ++v) a[v] = shfl_f32(acc, lbase + v);
+    }
+    // lexicographic (value, index) minimum over the group; key of a lane without candidates = (inf, ~0)
+    __device__ __forceinline__ uint32_t min_index(uint32_t best, uint32_t bidx, bool any) const
+    {
+        uint64_t key = any ? (((uint64_t)best << 32) | bidx) : (((uint64_t)0x7F800000u << 32) | 0xFFFFFFFFu);
+#pragma unroll
+        for (int m = 1; m < LC; m <<= 1) {
+            const uint64_t o = shflx_u64(key, m);
+            key = o < key ? o : key;
+        }
+        const uint32_t idx = (uint32_t)key;
+        return idx == 0xFFFFFFFFu ? 0u : idx;
+    }
+    // first index of the minimum of |x[0..n)| (SpcDecoder::decode :342-373)
+    template <typename X>
+    __device__ __forceinline__ uint32_t firstmin_abs(const X& x, uint32_t n) const
+    {
+        uint32_t best = 0x7F800000u, bidx = 0;  // +inf, index 0 (reference start values)
+        bool any = false;
+        for (uint32_t i = l; i < n; i += LC) {
+            const uint32_t a = fbits(x(i)) & 0x7FFFFFFFu;
+            if (a < best) {
+                best = a;
+                bidx = i;
+                any = true;
+            }
+        }
+        return min_index(best, bidx, any);
+    }
+};
 __device__ __forceinline__ float reduce_add8(const float a[8])
 {
     return ((((((a[0] + a[1]) + a[2]) + a[3]) + a[4]) + a[5]) + a[6]) + a[7];
 }
 
-// first index of the minimum of |x[0..n)| (SpcDecoder::decode :342-373)
-__device__ __forceinline__ uint32_t sc_firstmin_abs(const float* x, uint32_t n, int lane)
-{
-    uint32_t best = 0x7F800000u, bidx = 0;  // +inf, index 0 (reference start values)
-    bool any = false;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t a = fbits(x[i]) & 0x7FFFFFFFu;
-        if (a < best) {
-            best = a;
-            bidx = i;
-            any = true;
-        }
-    }
-    // lexicographic (value, index) minimum over the wave
-    uint64_t key = any ? (((uint64_t)best << 32) | bidx) : (((uint64_t)0x7F800000u << 32) | 0xFFFFFFFFu);
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const uint64_t o = shflx_u64(key, m);
-        key = o < key ? o : key;
-    }
-    const uint32_t idx = (uint32_t)key;
-    return idx == 0xFFFFFFFFu ? 0u : idx;
-}
-
-template <bool I8>
+template <int LCL, bool I8>
 __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
 {
+    constexpr int LC = 1 << LCL;
+    constexpr int CW = 64 >> LCL;  // codewords per wave
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const uint32_t wpb = blockDim.x >> 6;
-    uint32_t* wl = smem + (size_t)wib * P.wave_lds_words;
-    float* llr = reinterpret_cast<float*>(wl);
-    uint32_t* bits = wl + 2u * P.N;
-    const uint32_t N = P.N;
+    ScLanes<LCL> g;
+    g.l = lane & (LC - 1);
+    g.lbase = lane & ~(LC - 1);
+    const int l = g.l;
+    const uint32_t slot = (uint32_t)lane >> LCL;
+    const uint32_t N = P.N, logN = P.logN;
     const uint32_t nwords = N >= 32 ? (N >> 5) : 1u;
+    // this codeword's LDS slice
+    uint32_t* wl = smem + ((size_t)wib * CW + slot) * P.wave_lds_words;
+    float* llr = reinterpret_cast<float*>(wl);
+    uint32_t* bits = wl + N;
     const uint32_t wave0 = blockIdx.x * wpb + wib, nwaves = gridDim.x * wpb;
     const const_u64_ptr prog64 = (const_u64_ptr)(uintptr_t)P.prog;
+    const uint32_t ngroups = (P.rows + CW - 1) / CW;
 
-    for (uint32_t cw = wave0; cw < P.rows; cw += nwaves) {
-        const uint32_t row = P.rowidx ? P.rowidx[cw] : cw;
-        // ---- stage the channel row (FloatContainer::insertLlr bitcontainer.cpp:197-207) --------
-        if (I8) {
-            const int8_t* src = reinterpret_cast<const int8_t*>(P.llr) + (size_t)row * N;
-            for (uint32_t i = lane; i < N; i += 64) llr[N + i] = (float)src[i];
-        } else {
-            const float* src = reinterpret_cast<const float*>(P.llr) + (size_t)row * N;
-            if ((N & 255u) == 0) {
-                const float4* s4 = reinterpret_cast<const float4*>(src);
-                float4* d4 = reinterpret_cast<float4*>(llr + N);
-                for (uint32_t i = lane; i < (N >> 2); i += 64) d4[i] = s4[i];
-            } else {
-                for (uint32_t i = lane; i < N; i += 64) llr[N + i] = src[i];
-            }
-        }
-        WAVE_SYNC();
+    for (uint32_t grp = wave0; grp < ngroups; grp += nwaves) {
+        const uint32_t cwi = grp * CW + slot;
+        const bool live = cwi < P.rows;  // the last group may be ragged: idle slots decode row 0 and store nothing
+        const uint32_t row = live ? (P.rowidx ? P.rowidx[cwi] : cwi) : (P.rowidx ? P.rowidx[0] : 0u);
+        const void* chan = I8 ? (const void*)(reinterpret_cast<const int8_t*>(P.llr) + (size_t)row * N)
+                              : (const void*)(reinterpret_cast<const float*>(P.llr) + (size_t)row * N);
 
         uint64_t iw_next = prog64[0];
         for (uint32_t pc = 0;; ++pc) {
             const uint64_t iw = iw_next;
-            Ins ins;
-            ins.op = (uint8_t)(iw & 0xFF);
-            if (ins.op == OP_END) break;
+            const uint32_t op = (uint32_t)(iw & 0xFF);
+            if (op == OP_END) break;
             iw_next = prog64[pc + 1];  // scalar load, in flight while this instruction executes
-            ins.stage = (uint8_t)((iw >> 8) & 0xFF);
-            ins.side = (uint8_t)((iw >> 16) & 0xFF);
-            ins.off = (uint32_t)(iw >> 32);
-            const uint32_t s = ins.stage, n = 1u << s, h = n >> 1, off = ins.off;
-            const float* x = llr + n;  // this block's input LLRs
-            switch (ins.op) {
-            case SC_F:
-                for (uint32_t i = lane; i < h; i += 64) llr[h + i] = polar_f(x[i], x[h + i]);
-                break;
-            case SC_G:
-                for (uint32_t i = lane; i < h; i += 64) {
-                    const uint32_t b = off + i;
-                    const uint32_t u = (bits[b >> 5] >> (b & 31u)) & 1u;
-                    llr[h + i] = polar_g(x[i], x[h + i], u);
-                }
-                break;
-            case SC_G0R:
-                for (uint32_t i = lane; i < h; i += 64) llr[h + i] = x[i] + x[h + i];
-                break;
-            case SC_COMBINE:
-            case SC_COMBINE0R: {
-                const bool copy = ins.op == SC_COMBINE0R;
-                if (h >= 32) {
-                    const uint32_t w0 = off >> 5, hw = h >> 5;
-                    for (uint32_t w = lane; w < hw; w += 64) {
-                        const uint32_t r = bits[w0 + hw + w];
-                        bits[w0 + w] = copy ? r : (bits[w0 + w] ^ r);
-                    }
-                } else if (lane == 0) {
-                    const uint32_t sh = off & 31u, mask = (1u << h) - 1u;
-                    uint32_t w = bits[off >> 5];
-                    const uint32_t r = (w >> (sh + h)) & mask;
-                    if (copy)
-                        w = (w & ~(mask << sh)) | (r << sh);
-                    else
-                        w ^= r << sh;
-                    bits[off >> 5] = w;
-                }
-                break;
-            }
-            case SC_RONE: {  // h >= 8
-                for (uint32_t i0 = 0; i0 < h; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    const bool act = i < h;
-                    uint32_t u = 0, sl = 0;
-                    if (act) {
+            const uint32_t s = (uint32_t)((iw >> 8) & 0xFF), n = 1u << s, h = n >> 1, off = (uint32_t)(iw >> 32);
+
+            // the op body, instantiated for the two kinds of input: an LDS stage buffer, or (root) the channel row
+            auto run = [&](auto x) {
+                switch (op) {
+                case SC_F:
+                    for (uint32_t i = l; i < h; i += LC) llr[h + i] = polar_f(x(i), x(h + i));
+                    break;
+                case SC_G:
+                    for (uint32_t i = l; i < h; i += LC) {
                         const uint32_t b = off + i;
-                        u = (bits[b >> 5] >> (b & 31u)) & 1u;
-                        sl = sgn(polar_g(x[i], x[h + i], u));
+                        llr[h + i] = polar_g(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
                     }
-                    const uint64_t mr = ballot64(act && sl);
-                    const uint64_t ml = ballot64(act && (sl ^ u));
-                    WAVE_SYNC();
-                    const uint32_t cnt = h < 64 ? h : 64;
-                    sc_put_bits(bits, off + i0, cnt, ml, lane);
-                    sc_put_bits(bits, off + h + i0, cnt, mr, lane);
+                    break;
+                case SC_G0R:
+                    for (uint32_t i = l; i < h; i += LC) llr[h + i] = x(i) + x(h + i);
+                    break;
+                case SC_COMBINE:
+                case SC_COMBINE0R: {
+                    const bool copy = op == SC_COMBINE0R;
+                    if (h >= 32) {
+                        const uint32_t w0 = off >> 5, hw = h >> 5;
+                        for (uint32_t w = l; w < hw; w += LC) {
+                            const uint32_t r = bits[w0 + hw + w];
+                            bits[w0 + w] = copy ? r : (bits[w0 + w] ^ r);
+                        }
+                    } else if (l == 0) {
+                        const uint32_t sh = off & 31u, mask = (1u << h) - 1u;
+                        uint32_t w = bits[off >> 5];
+                        const uint32_t r = (w >> (sh + h)) & mask;
+                        if (copy)
+                            w = (w & ~(mask << sh)) | (r << sh);
+                        else
+                            w ^= r << sh;
+                        bits[off >> 5] = w;
+                    }
+                    break;
                 }
-                break;
-            }
-            case SC_R0:
-                sc_fill_pattern(bits, off, n, 0u, lane);
-                break;
-            case SC_R1:
-                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    const uint64_t m = ballot64(i < n && sgn(x[i < n ? i : 0]));
-                    sc_put_bits(bits, off + i0, n < 64 ? n : 64, m, lane);
+                case SC_RONE: {  // h >= 8
+                    for (uint32_t i0 = 0; i0 < h; i0 += LC) {
+                        const uint32_t i = i0 + l;
+                        const bool act = i < h;
+                        uint32_t u = 0, sl = 0;
+                        if (act) {
+                            const uint32_t b = off + i;
+                            u = (bits[b >> 5] >> (b & 31u)) & 1u;
+                            sl = sgn(polar_g(x(i), x(h + i), u));
+                        }
+                        const uint64_t mr = g.slice(ballot64(act && sl));
+                        const uint64_t ml = g.slice(ballot64(act && (sl ^ u)));
+                        WAVE_SYNC();
+                        const uint32_t cnt = h < (uint32_t)LC ? h : (uint32_t)LC;
+                        g.put_bits(bits, off + i0, cnt, ml);
+                        g.put_bits(bits, off + h + i0, cnt, mr);
+                    }
+                    break;
                 }
-                break;
-            case SC_REP: {
-                float a[8];
-                sc_fold8(x, n, lane, a);
-                const float sum = reduce_add8(a);
-                sc_fill_pattern(bits, off, n, sgn(sum) ? 0xFFFFFFFFu : 0u, lane);
-                break;
-            }
-            case SC_SPC: {
-                uint32_t par = 0;
-                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    const uint64_t m = ballot64(i < n && sgn(x[i < n ? i : 0]));
-                    par ^= (uint32_t)__popcll(m) & 1u;
-                    sc_put_bits(bits, off + i0, n < 64 ? n : 64, m, lane);
+                case SC_R0:
+                    g.fill_pattern(bits, off, n, 0u);
+                    break;
+                case SC_R1:
+                    for (uint32_t i0 = 0; i0 < n; i0 += LC) {
+                        const uint32_t i = i0 + l;
+                        const uint64_t m = g.slice(ballot64(i < n && sgn(x(i < n ? i : 0))));
+                        g.put_bits(bits, off + i0, n < (uint32_t)LC ? n : (uint32_t)LC, m);
+                    }
+                    break;
+                case SC_REP: {
+                    float a[8];
+                    g.fold8(x, n, a);
+                    g.fill_pattern(bits, off, n, sgn(reduce_add8(a)) ? 0xFFFFFFFFu : 0u);
+                    break;
                 }
-                const uint32_t im = sc_firstmin_abs(x, n, lane);
-                if (par) sc_flip_bit(bits, off + im, lane);
-                break;
-            }
-            case SC_DREP: {
-                float a[8];
-                sc_fold8(x, n, lane, a);
-                float e, o;
-                if (n >= 8) {
-                    e = (a[0] + a[4]) + (a[2] + a[6]);
-                    o = (a[1] + a[5]) + (a[3] + a[7]);
-                } else {
-                    e = ((a[0] + a[2]) + a[4]) + a[6];
-                    o = ((a[1] + a[3]) + a[5]) + a[7];
+                case SC_SPC: {
+                    uint32_t par = 0;
+                    for (uint32_t i0 = 0; i0 < n; i0 += LC) {
+                        const uint32_t i = i0 + l;
+                        const uint64_t m = g.slice(ballot64(i < n && sgn(x(i < n ? i : 0))));
+                        par ^= (uint32_t)__popcll(m) & 1u;
+                        g.put_bits(bits, off + i0, n < (uint32_t)LC ? n : (uint32_t)LC, m);
+                    }
+                    const uint32_t im = g.firstmin_abs(x, n);
+                    if (par) g.flip_bit(bits, off + im);
+                    break;
                 }
-                sc_fill_pattern(bits, off, n, (sgn(e) ? 0x55555555u : 0u) | (sgn(o) ? 0xAAAAAAAAu : 0u), lane);
-                break;
-            }
-            case SC_DSPC8: {  // flip EVERY class member tied for the class minimum
-                const int l8 = lane & 7;
-                const float v = x[l8];
-                float m = absf(v);
-                uint32_t p = sgn(v);
+                case SC_DREP: {
+                    float a[8];
+                    g.fold8(x, n, a);
+                    float e, o;
+                    if (n >= 8) {
+                        e = (a[0] + a[4]) + (a[2] + a[6]);
+                        o = (a[1] + a[5]) + (a[3] + a[7]);
+                    } else {
+                        e = ((a[0] + a[2]) + a[4]) + a[6];
+                        o = ((a[1] + a[3]) + a[5]) + a[7];
+                    }
+                    g.fill_pattern(bits, off, n, (sgn(e) ? 0x55555555u : 0u) | (sgn(o) ? 0xAAAAAAAAu : 0u));
+                    break;
+                }
+                case SC_DSPC8: {  // flip EVERY class member tied for the class minimum
+                    const int l8 = l & 7;
+                    const float v = x(l8);
+                    float m = absf(v);
+                    uint32_t p = sgn(v);
 #pragma unroll
-                for (int k = 2; k < 8; k <<= 1) {
-                    const float om = shflx_f32(m, k);
-                    m = om < m ? om : m;
-                    p ^= shflx_u32(p, k);
+                    for (int k = 2; k < 8; k <<= 1) {
+                        const float om = shflx_f32(m, k);
+                        m = om < m ? om : m;
+                        p ^= shflx_u32(p, k);
+                    }
+                    const uint32_t bit = sgn(v) ^ ((p && absf(v) == m) ? 1u : 0u);
+                    g.put_bits(bits, off, 8, g.slice(ballot64(l < 8 && bit)));
+                    break;
                 }
-                const uint32_t bit = sgn(v) ^ ((p && absf(v) == m) ? 1u : 0u);
-                const uint64_t mk = ballot64(lane < 8 && bit);
-                sc_put_bits(bits, off, 8, mk, lane);
-                break;
-            }
-            case SC_DSPC: {  // n > 8: per AVX lane the LAST row with the lane minimum, lowest lane wins
-                float minv = 3.402823466e+38f;
-                uint32_t mini = 0;
-                if (lane < 8) {
-                    for (uint32_t i = lane; i < n; i += 8) {
-                        const float a = absf(x[i]);
-                        if (!(a > minv)) {
-                            minv = a;
-                            mini = i;
+                case SC_DSPC: {  // n > 8: per AVX lane the LAST row with the lane minimum, lowest lane wins
+                    float minv = 3.402823466e+38f;
+                    uint32_t mini = 0;
+                    if (l < 8) {
+                        for (uint32_t i = l; i < n; i += 8) {
+                            const float a = absf(x(i));
+                            if (!(a > minv)) {
+                                minv = a;
+                                mini = i;
+                            }
                         }
                     }
-                }
-                float cm = minv;  // class minimum over lanes of equal parity (within lanes 0..7)
+                    float cm = minv;  // class minimum over lanes of equal parity (within lanes 0..7 of the group)
 #pragma unroll
-                for (int k = 2; k < 8; k <<= 1) {
-                    const float om = shflx_f32(cm, k);
-                    cm = om < cm ? om : cm;
-                }
-                const uint64_t tie = ballot64(lane < 8 && minv == cm);
-                const int le = __ffsll((long long)(tie & 0x55ull)) - 1;
-                const int lo = __ffsll((long long)(tie & 0xAAull)) - 1;
-                const uint32_t ie = shfl_u32(mini, le < 0 ? 0 : le), io = shfl_u32(mini, lo < 0 ? 1 : lo);
-                uint32_t pe = 0, po = 0;
-                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    const uint64_t m = ballot64(i < n && sgn(x[i < n ? i : 0]));
-                    pe ^= (uint32_t)__popcll(m & 0x5555555555555555ull) & 1u;
-                    po ^= (uint32_t)__popcll(m & 0xAAAAAAAAAAAAAAAAull) & 1u;
-                    sc_put_bits(bits, off + i0, n < 64 ? n : 64, m, lane);
-                }
-                if (pe) sc_flip_bit(bits, off + ie, lane);
-                if (po) sc_flip_bit(bits, off + io, lane);
-                break;
-            }
-            case SC_TREP: {
-                float a[8], t[4];
-                sc_fold8(x, n, lane, a);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = a[j] + a[j + 4];
-                const uint32_t r = spc4_signs(t);
-                sc_fill_pattern(bits, off, n, r * 0x11111111u, lane);
-                break;
-            }
-            case SC_TYPE5:
-            case SC_REPONE8: {
-                float l[8], q[4], gg[4];
-                if (ins.op == SC_TYPE5) {
-                    sc_fold8(x, n, lane, l);
-                } else {
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) l[v] = x[v];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = polar_f(l[j], l[j + 4]);
-                const float rho = (q[0] + q[1]) + (q[2] + q[3]);
-                const uint32_t sr = sgn(rho);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) gg[j] = polar_g(l[j], l[j + 4], sr);
-                uint32_t ss;
-                if (ins.op == SC_TYPE5) {
-                    ss = spc4_signs(gg);
-                } else {
-                    ss = sgn(gg[0]) | (sgn(gg[1]) << 1) | (sgn(gg[2]) << 2) | (sgn(gg[3]) << 3);
-                }
-                const uint32_t byte = ((sr ? (ss ^ 0xFu) : ss) & 0xFu) | (ss << 4);
-                sc_fill_pattern(bits, off, n, byte * 0x01010101u, lane);
-                break;
-            }
-            case SC_ZSPC8: {
-                float t[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = x[j] + x[j + 4];
-                const uint32_t r = spc4_signs(t);
-                sc_put_bits(bits, off, 8, (uint64_t)(r | (r << 4)), lane);
-                break;
-            }
-            case SC_ZEROSPC: {  // n > 8; outputs the RIGHT half's signs
-                uint32_t par = 0;
-                uint32_t best = 0x7F800000u, bidx = 0;
-                bool any = false;
-                for (uint32_t i0 = 0; i0 < h; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    const bool act = i < h;
-                    float y = 0.0f, r = 0.0f;
-                    if (act) {
-                        r = x[h + i];
-                        y = x[i] + r;
-                        const uint32_t a = fbits(y) & 0x7FFFFFFFu;
-                        if (a < best) {
-                            best = a;
-                            bidx = i;
-                            any = true;
-                        }
+                    for (int k = 2; k < 8; k <<= 1) {
+                        const float om = shflx_f32(cm, k);
+                        cm = om < cm ? om : cm;
                     }
-                    par ^= (uint32_t)__popcll(ballot64(act && sgn(y))) & 1u;
-                    const uint64_t m = ballot64(act && sgn(r));
-                    const uint32_t cnt = h < 64 ? h : 64;
-                    sc_put_bits(bits, off + i0, cnt, m, lane);
-                    sc_put_bits(bits, off + h + i0, cnt, m, lane);
+                    const uint64_t tie = g.slice(ballot64(l < 8 && minv == cm));
+                    const int le = __ffsll((long long)(tie & 0x55ull)) - 1;
+                    const int lo = __ffsll((long long)(tie & 0xAAull)) - 1;
+                    const uint32_t ie = shfl_u32(mini, g.lbase + (le < 0 ? 0 : le)), io = shfl_u32(mini, g.lbase + (lo < 0 ? 1 : lo));
+                    uint32_t pe = 0, po = 0;
+                    for (uint32_t i0 = 0; i0 < n; i0 += LC) {
+                        const uint32_t i = i0 + l;
+                        const uint64_t m = g.slice(ballot64(i < n && sgn(x(i < n ? i : 0))));
+                        pe ^= (uint32_t)__popcll(m & 0x5555555555555555ull) & 1u;
+                        po ^= (uint32_t)__popcll(m & 0xAAAAAAAAAAAAAAAAull) & 1u;
+                        g.put_bits(bits, off + i0, n < (uint32_t)LC ? n : (uint32_t)LC, m);
+                    }
+                    if (pe) g.flip_bit(bits, off + ie);
+                    if (po) g.flip_bit(bits, off + io);
+                    break;
                 }
-                uint64_t key = any ? (((uint64_t)best << 32) | bidx) : (((uint64_t)0x7F800000u << 32) | 0xFFFFFFFFu);
+                case SC_TREP: {
+                    float a[8], t[4];
+                    g.fold8(x, n, a);
 #pragma unroll
-                for (int m = 1; m < 64; m <<= 1) {
-                    const uint64_t o = shflx_u64(key, m);
-                    key = o < key ? o : key;
+                    for (int j = 0; j < 4; ++j) t[j] = a[j] + a[j + 4];
+                    g.fill_pattern(bits, off, n, spc4_signs(t) * 0x11111111u);
+                    break;
                 }
-                uint32_t im = (uint32_t)key;
-                if (im == 0xFFFFFFFFu) im = 0;
-                if (par) {
-                    sc_flip_bit(bits, off + im, lane);
-                    sc_flip_bit(bits, off + h + im, lane);
+                case SC_TYPE5:
+                case SC_REPONE8: {
+                    float v8[8], q[4], gg[4];
+                    if (op == SC_TYPE5) {
+                        g.fold8(x, n, v8);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) v8[v] = x(v);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[j] = polar_f(v8[j], v8[j + 4]);
+                    const float rho = (q[0] + q[1]) + (q[2] + q[3]);
+                    const uint32_t sr = sgn(rho);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gg[j] = polar_g(v8[j], v8[j + 4], sr);
+                    uint32_t ss;
+                    if (op == SC_TYPE5)
+                        ss = spc4_signs(gg);
+                    else
+                        ss = sgn(gg[0]) | (sgn(gg[1]) << 1) | (sgn(gg[2]) << 2) | (sgn(gg[3]) << 3);
+                    const uint32_t byte = ((sr ? (ss ^ 0xFu) : ss) & 0xFu) | (ss << 4);
+                    g.fill_pattern(bits, off, n, byte * 0x01010101u);
+                    break;
                 }
-                break;
-            }
-            default: break;
+                case SC_ZSPC8: {
+                    float t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = x(j) + x(j + 4);
+                    const uint32_t r = spc4_signs(t);
+                    g.put_bits(bits, off, 8, (uint64_t)(r | (r << 4)));
+                    break;
+                }
+                case SC_ZEROSPC: {  // n > 8; outputs the RIGHT half's signs
+                    uint32_t par = 0;
+                    uint32_t best = 0x7F800000u, bidx = 0;
+                    bool any = false;
+                    for (uint32_t i0 = 0; i0 < h; i0 += LC) {
+                        const uint32_t i = i0 + l;
+                        const bool act = i < h;
+                        float y = 0.0f, r = 0.0f;
+                        if (act) {
+                            r = x(h + i);
+                            y = x(i) + r;
+                            const uint32_t a = fbits(y) & 0x7FFFFFFFu;
+                            if (a < best) {
+                                best = a;
+                                bidx = i;
+                                any = true;
+                            }
+                        }
+                        par ^= (uint32_t)__popcll(g.slice(ballot64(act && sgn(y)))) & 1u;
+                        const uint64_t m = g.slice(ballot64(act && sgn(r)));
+                        const uint32_t cnt = h < (uint32_t)LC ? h : (uint32_t)LC;
+                        g.put_bits(bits, off + i0, cnt, m);
+                        g.put_bits(bits, off + h + i0, cnt, m);
+                    }
+                    const uint32_t im = g.min_index(best, bidx, any);
+                    if (par) {
+                        g.flip_bit(bits, off + im);
+                        g.flip_bit(bits, off + h + im);
+                    }
+                    break;
+                }
+                default: break;
+                }
+            };
+            if (s == logN) {
+                if constexpr (I8)
+                    run([&](uint32_t i) { return (float)reinterpret_cast<const int8_t*>(chan)[i]; });
+                else
+                    run([&](uint32_t i) { return reinterpret_cast<const float*>(chan)[i]; });
+            } else {
+                const float* xs = llr + n;
+                run([&](uint32_t i) { return xs[i]; });
             }
             WAVE_SYNC();
         }
 
         // ---- output: FastSscAvxFloat::decode :940-955 ------------------------------------------
         if (!P.systematic) {  // re-encode (butterfly_fip.cpp:15-63) on the packed words
-            for (uint32_t w = lane; w < nwords; w += 64) {
+            for (uint32_t w = l; w < nwords; w += LC) {
                 uint32_t v = bits[w];
                 if (N >= 2) v ^= (v >> 1) & 0x55555555u;
                 if (N >= 4) v ^= (v >> 2) & 0x33333333u;
@@ -551,29 +556,30 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
             }
             WAVE_SYNC();
             for (uint32_t hw = 1; hw < nwords; hw <<= 1) {
-                for (uint32_t w = lane; w < nwords; w += 64)
+                for (uint32_t w = l; w < nwords; w += LC)
                     if (!(w & hw)) bits[w] ^= bits[w + hw];
                 WAVE_SYNC();
             }
         }
         uint32_t syn = 0;
         uint8_t* orow = P.out + (size_t)row * P.nb;
-        for (uint32_t t0 = 0; t0 < P.K; t0 += 64) {
-            const uint32_t t = t0 + lane;
+        for (uint32_t t0 = 0; t0 < P.K; t0 += LC) {
+            const uint32_t t = t0 + l;
             uint32_t bit = 0;
             if (t < P.K) {
                 const uint32_t pos = P.lut[t];
                 bit = (bits[pos >> 5] >> (pos & 31u)) & 1u;
                 if (bit) syn ^= P.syn[t];
             }
-            const uint64_t m = ballot64(bit != 0);
-            if (lane < 8) {
-                const uint32_t byte = (t0 >> 3) + lane;
-                if (byte < P.nb) orow[byte] = (uint8_t)(__brev((uint32_t)((m >> (8 * lane)) & 0xFFu)) >> 24);
+            const uint64_t m = g.slice(ballot64(bit != 0));
+            if (l < LC / 8) {
+                const uint32_t byte = (t0 >> 3) + l;
+                if (live && byte < P.nb) orow[byte] = (uint8_t)(__brev((uint32_t)((m >> (8 * l)) & 0xFFu)) >> 24);
             }
         }
-        syn = wave_xor_u32(syn);
-        if (lane == 0 && P.ok) P.ok[row] = (syn == 0) ? 1 : 0;
+#pragma unroll
+        for (int m = 1; m < LC; m <<= 1) syn ^= shflx_u32(syn, m);
+        if (live && l == 0 && P.ok) P.ok[row] = (syn == 0) ? 1 : 0;
         WAVE_SYNC();
     }
 }
@@ -672,14 +678,15 @@ struct SclCtx {
     float metric;
     SlotT slot;
 
-    __device__ __forceinline__ float* path_llr(uint32_t q) const { return llr + (size_t)q * path_stride; }
+    // (24-bit multiplies are full rate; v_mul_lo_u32 is not)
+    __device__ __forceinline__ float* path_llr(uint32_t q) const { return llr + __umul24(q, path_stride); }
     __device__ __forceinline__ uint32_t* area(uint32_t side, uint32_t q) const
     {
-        return side ? bitsR + (size_t)q * wppR : bitsL + (size_t)q * wppL;
+        return side ? bitsR + __umul24(q, wppR) : bitsL + __umul24(q, wppL);
     }
     __device__ __forceinline__ float* arena_stage(uint32_t q, uint32_t t) const
     {
-        return arena + (size_t)q * arena_path_stride + ((1u << t) - (1u << s0));
+        return arena + __umul24(q, arena_path_stride) + ((1u << t) - (1u << s0));
     }
     // call fn(accessor) with the reader for the stage-t LLRs of path buffer q
     template <bool I8, typename F>
@@ -1717,22 +1724,26 @@ static hipError_t launch_scl_t(const DecodeParams& P, bool i8, bool slot64, bool
               : launch_scl_k<LPL, false, true, false>(P, grid, block, lds, st, occ);
 }
 
-hipError_t launch_sc(const DecodeParams& P, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,
+template <int LCL, bool I8>
+static hipError_t launch_sc_k(const DecodeParams& P, dim3 g, dim3 b, size_t lds, hipStream_t st, int* occupancy)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<LCL, I8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<LCL, I8>, (int)b.x, lds);
+    hipLaunchKernelGGL((sc_decode_kernel<LCL, I8>), g, b, lds, st, P);
+    return hipGetLastError();
+}
+
+// lcl: log2 of the lanes that share one codeword (4 -> four codewords per wave, 6 -> one)
+hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,
                      hipStream_t st, int* occupancy)
 {
     dim3 g(grid), b(64 * waves_per_block);
-    if (i8) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<true>, (int)b.x, lds);
-        hipLaunchKernelGGL((sc_decode_kernel<true>), g, b, lds, st, P);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<false>, (int)b.x, lds);
-        hipLaunchKernelGGL((sc_decode_kernel<false>), g, b, lds, st, P);
-    }
-    return hipGetLastError();
+    if (lcl == 3)
+        return i8 ? launch_sc_k<3, true>(P, g, b, lds, st, occupancy) : launch_sc_k<3, false>(P, g, b, lds, st, occupancy);
+    if (lcl == 4)
+        return i8 ? launch_sc_k<4, true>(P, g, b, lds, st, occupancy) : launch_sc_k<4, false>(P, g, b, lds, st, occupancy);
+    return i8 ? launch_sc_k<6, true>(P, g, b, lds, st, occupancy) : launch_sc_k<6, false>(P, g, b, lds, st, occupancy);
 }
 
 hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, unsigned waves_per_block,
