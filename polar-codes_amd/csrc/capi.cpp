@@ -32,6 +32,15 @@ unsigned ilog2(size_t n)
 }
 
 constexpr size_t kMaxLds = 160 * 1024;  // LDS per CU on gfx950 (a single workgroup may use all of it)
+// LDS is handed out in granules; the occupancy API ignores that and over-reports (13 resident single-wave
+// workgroups reported for 12 096 B each, 12 measured: the 13th of every CU ran after the others, halving the
+// throughput).  1 280 B = 160 KiB / 128 matches every case measured on MI355X.
+constexpr size_t kLdsGranule = 1280;
+inline size_t lds_blocks_per_cu(size_t bytes)
+{
+    const size_t rounded = (bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule;
+    return rounded ? kMaxLds / rounded : 0;
+}
 
 }  // namespace
 
@@ -138,7 +147,7 @@ void compute_geometry(pcd_decoder* d)
         for (unsigned s0 = d->logN; s0 + 1 > lo; --s0) {
             const size_t bytes = (size_t)lds_words(s0) * 4;
             // up to 16 waves per CU pay off (measured at cfg 3: s0 = 9 / 8 / 7 / 6 -> 7.5 / 6.3 / 11.1 / 10.8 M cw/s)
-            const unsigned waves = bytes > kMaxLds ? 0u : (unsigned)std::min<size_t>(16, kMaxLds / bytes);
+            const unsigned waves = bytes > kMaxLds ? 0u : (unsigned)std::min<size_t>(16, lds_blocks_per_cu(bytes));
             if (waves > best_waves) {
                 best_waves = waves;
                 best_s0 = s0;
@@ -238,7 +247,7 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     if (d->sc_blocks_per_cu == 0) {  // resident workgroups per CU: the grid is sized to exactly fill the chip
         int occ = 0;
         HIP_TRY(pamd::launch_sc(P, d->sc_lcl, i8, 1, d->sc_wpb, lds, st, &occ));
-        d->sc_blocks_per_cu = std::max(1, occ);
+        d->sc_blocks_per_cu = std::max(1, std::min(occ, (int)lds_blocks_per_cu(lds)));
         if (std::getenv("PCD_VERBOSE"))
             std::fprintf(stderr, "[pcd] sc: %u codewords/wave, lds=%zu B/workgroup, occupancy=%d blocks/CU\n", cw_per_wave, lds, occ);
     }
@@ -263,7 +272,8 @@ int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     if (d->scl_blocks_per_cu == 0) {  // resident workgroups per CU (LDS and VGPR limited)
         int occ = 0;
         HIP_TRY(pamd::launch_scl(P, d->lpl, i8, 1, d->scl_wpb, lds, st, &occ));
-        d->scl_blocks_per_cu = std::max(1, occ);
+        d->scl_blocks_per_cu = std::max(1, std::min(occ, (int)lds_blocks_per_cu(lds)));
+        if (const char* e = std::getenv("PCD_BLOCKS_PER_CU")) d->scl_blocks_per_cu = std::max(1, std::atoi(e));  // experiments
         if (std::getenv("PCD_VERBOSE")) std::fprintf(stderr, "[pcd] scl: s0=%u lds=%zu B occupancy=%d blocks/CU\n", d->s0, lds, occ);
     }
     const unsigned need = (unsigned)((P.rows + d->scl_wpb - 1) / d->scl_wpb);
