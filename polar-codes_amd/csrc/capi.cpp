@@ -113,6 +113,8 @@ int grow(T*& p, size_t& cap, size_t bytes)
     return PCD_OK;
 }
 
+void specialize_scl(pcd_decoder* d);
+
 void compute_geometry(pcd_decoder* d)
 {
     const unsigned N = d->N;
@@ -160,7 +162,27 @@ void compute_geometry(pcd_decoder* d)
         d->scl_wave_words = lds_words(d->s0);
         d->arena_path_stride = d->s0 < d->logN ? ((1u << d->logN) - (1u << d->s0)) : 0;
         d->arena_wave_words = lmax * d->arena_path_stride;
+        if (!std::getenv("PCD_NO_SPECIALIZE")) specialize_scl(d);
         d->scl_wpb = 1;
+    }
+}
+
+// Replace generic inner-node ops by their specialised forms (program.h) for the chosen geometry.
+void specialize_scl(pcd_decoder* d)
+{
+    auto woff = [](unsigned t) { return t <= 5 ? t : ((1u << (t - 5)) + 4u); };
+    const unsigned fb = 6u - (unsigned)d->lpl;
+    for (auto& in : d->scl_prog.ins) {
+        const unsigned s = in.stage;
+        if (in.op != pamd::SCL_F && in.op != pamd::SCL_G && in.op != pamd::SCL_COMBINE) continue;
+        const uint32_t aux = woff(s) | (woff(s - 1) << 9) | (((s - 1) * fb) << 18);
+        if (in.op == pamd::SCL_COMBINE) {
+            in.op = (s - 1 < 5) ? pamd::SCL_C_S : pamd::SCL_C_W;
+            in.off = aux;
+        } else if (s <= 6 && s < d->s0 && s < d->logN) {
+            in.op = in.op == pamd::SCL_F ? pamd::SCL_F_S : pamd::SCL_G_S;
+            in.off = aux;
+        }
     }
 }
 

@@ -1401,7 +1401,46 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                                             [&](auto x) { write_leaf_bits<Ctx>(c, x, s, side, nact, fmask, fpos); });
                 }
             };
-            if (ins.op == SCL_F) {  // RateRNode::decode :233-238 -- reads the path's own (identity) buffer
+            const uint32_t aux = (uint32_t)(iw >> 32);
+            const uint32_t wo_s = aux & 0x1FFu, wo_c = (aux >> 9) & 0x1FFu, fsh = (aux >> 18) & 0x3Fu;
+            const bool skip_small = DIAG && (P.ablate & 16u);
+            if (ins.op == SCL_F_S) {  // F, both stages in LDS, h < 64 (specialised on the host)
+                if (active && !skip_small) {
+                    const float* x = c.path_llr(c.p) + n;
+                    float* d = c.path_llr(c.p) + h;
+                    for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_f(x[i], x[h + i]);
+                }
+                c.slot = (c.slot & ~((typename Ctx::SlotT)(LMAX - 1) << fsh)) | ((typename Ctx::SlotT)c.p << fsh);
+            } else if (ins.op == SCL_G_S) {  // G, both stages in LDS, h <= 32: one left-bit word
+                if (active && !skip_small) {
+                    const uint32_t srcq = (uint32_t)(c.slot >> fsh) & (uint32_t)(LMAX - 1);
+                    const float* x = c.path_llr(srcq) + n;
+                    float* d = c.path_llr(c.p) + h;
+                    const uint32_t lw = (c.area(0, c.p) + wo_c)[0];
+                    for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
+                }
+                c.slot = (c.slot & ~((typename Ctx::SlotT)(LMAX - 1) << fsh)) | ((typename Ctx::SlotT)c.p << fsh);
+            } else if (ins.op == SCL_C_S) {  // COMBINE, h < 32
+                if (active && c.j == 0 && !skip_small) {
+                    const uint32_t lq = (uint32_t)(c.slot >> fsh) & (uint32_t)(LMAX - 1);
+                    const uint32_t mask = (1u << h) - 1u;
+                    const uint32_t r = (c.area(1, c.p) + wo_c)[0] & mask;
+                    (c.area(side, c.p) + wo_s)[0] = (((c.area(0, lq) + wo_c)[0] ^ r) & mask) | (r << h);
+                }
+            } else if (ins.op == SCL_C_W) {  // COMBINE, h >= 32
+                if (active && !skip_small) {
+                    const uint32_t lq = (uint32_t)(c.slot >> fsh) & (uint32_t)(LMAX - 1);
+                    const uint32_t* lb = c.area(0, lq) + wo_c;
+                    const uint32_t* rb = c.area(1, c.p) + wo_c;
+                    uint32_t* ob = c.area(side, c.p) + wo_s;
+                    const uint32_t hw = h >> 5;
+                    for (uint32_t w = c.j; w < hw; w += LP) {
+                        const uint32_t r = rb[w];
+                        ob[w] = lb[w] ^ r;
+                        ob[hw + w] = r;
+                    }
+                }
+            } else if (ins.op == SCL_F) {  // RateRNode::decode :233-238 -- reads the path's own (identity) buffer
                 if (DIAG && (P.ablate & 8u) && h >= 64) {
                 } else if (DIAG && (P.ablate & 16u) && h < 64) {
                 } else if (h >= 64) {

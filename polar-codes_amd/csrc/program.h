@@ -40,6 +40,14 @@ enum Op : uint8_t {
     SCL_R1,        // RateOneDecoder::decode  :353-413
     SCL_REP,       // RepetitionDecoder::decode :428-481
     SCL_SPC,       // SpcDecoder::decode      :498-621
+    // Specialised forms the host substitutes once the launch geometry is known (capi.cpp, specialize_scl):
+    // both LLR stages in LDS and fewer than 64 outputs per path, so the kernel can skip every memory-kind
+    // decision.  `off` then carries precomputed constants: bits 0-8 woff(stage), 9-17 woff(stage-1),
+    // 18-23 the slot-word shift of the stage.
+    SCL_F_S = 40,
+    SCL_G_S,
+    SCL_C_S,       // COMBINE with h < 32 (one bit word per child)
+    SCL_C_W,       // COMBINE with h >= 32 (word-wise)
 };
 
 struct Ins {
