@@ -174,6 +174,10 @@ void specialize_scl(pcd_decoder* d)
     const unsigned fb = 6u - (unsigned)d->lpl;
     for (auto& in : d->scl_prog.ins) {
         const unsigned s = in.stage;
+        if ((in.op == pamd::SCL_SPC || in.op == pamd::SCL_R1) && d->lpl == 3 && s <= 3 && s < d->s0 && s < d->logN) {
+            in.op = in.op == pamd::SCL_SPC ? pamd::SCL_SPC_S : pamd::SCL_R1_S;
+            continue;
+        }
         if (in.op != pamd::SCL_F && in.op != pamd::SCL_G && in.op != pamd::SCL_COMBINE) continue;
         const uint32_t aux = woff(s) | (woff(s - 1) << 9) | (((s - 1) * fb) << 18);
         if (in.op == pamd::SCL_COMBINE) {

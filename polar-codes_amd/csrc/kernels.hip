@@ -1251,10 +1251,11 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
         if (lane == 0) P.cycles[P.prog_len + pc * 4 + (k)] = (uint32_t)(t_ - t_start);            \
     }
 
-            if (DIAG && ((P.ablate & 128u) || ((P.ablate & 64u) && ins.op >= SCL_R0))) continue;
+            const bool is_leaf = (ins.op >= SCL_R0 && ins.op <= SCL_SPC) || ins.op == SCL_SPC_S || ins.op == SCL_R1_S;
+            if (DIAG && ((P.ablate & 128u) || ((P.ablate & 64u) && is_leaf))) continue;
             // dispatch ordered by frequency (F / G / COMBINE are three quarters of the program); the two forking
             // leaves share one generic body instantiated separately, so each variant is straight-line code
-            auto fork_leaf = [&](auto SPC_T) {  // SpcDecoder::decode     :498-621
+            auto fork_leaf = [&](auto SPC_T, auto SMALL_T) {  // SpcDecoder::decode     :498-621
                 constexpr bool spc = decltype(SPC_T)::value;
                 Weak<4> wk;
                 uint32_t par = 0;
@@ -1275,8 +1276,9 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                         wk.ix[2] = wk.ix[3] = 0;
                     }
                 };
-                bool small = false;
-                if constexpr (LPL == 3) small = (s <= 3 && s < c.s0 && s < logN);  // n <= 8, block in LDS
+                // n <= 8 with the block in LDS and 8 lanes per path: decided on the host (SCL_SPC_S / SCL_R1_S)
+                constexpr bool kSmallOp = decltype(SMALL_T)::value;
+                bool small = kSmallOp;
                 if (DIAG && (P.ablate & 2u)) {  // perf experiment: no weak search
                     small = true;
                     wk.v[0] = wk.v[1] = wk.v[2] = wk.v[3] = 0x3F800000u;
@@ -1312,7 +1314,9 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                         }
                     }
                 }
-                if (!small) c.template with_src<I8>(s, c.p, search);
+                if constexpr (!kSmallOp) {
+                    if (!small) c.template with_src<I8>(s, c.p, search);
+                }
                 PAMD_STAMP(0)
                 const float v0 = bitsf(wk.v[0]), v1 = bitsf(wk.v[1]), v2 = bitsf(wk.v[2]), v3 = bitsf(wk.v[3]);
                 uint32_t nidx;
@@ -1396,7 +1400,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                     }
                     const uint64_t bal = ballot64(b != 0);
                     if (nact && c.j == 0) (c.area(side, c.p) + woff(s))[0] = (uint32_t)(bal >> c.base) & 0xFFu;
-                } else {
+                } else if constexpr (!kSmallOp) {
                     c.template with_src<I8>(s, srcp,
                                             [&](auto x) { write_leaf_bits<Ctx>(c, x, s, side, nact, fmask, fpos); });
                 }
@@ -1404,6 +1408,16 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
             const uint32_t aux = (uint32_t)(iw >> 32);
             const uint32_t wo_s = aux & 0x1FFu, wo_c = (aux >> 9) & 0x1FFu, fsh = (aux >> 18) & 0x3Fu;
             const bool skip_small = DIAG && (P.ablate & 16u);
+            if constexpr (LPL == 3) {
+                if (ins.op == SCL_SPC_S) {
+                    fork_leaf(std::true_type{}, std::true_type{});
+                    goto op_done;
+                }
+                if (ins.op == SCL_R1_S) {
+                    fork_leaf(std::false_type{}, std::true_type{});
+                    goto op_done;
+                }
+            }
             if (ins.op == SCL_F_S) {  // F, both stages in LDS, h < 64 (specialised on the host)
                 if (active && !skip_small) {
                     const float* x = c.path_llr(c.p) + n;
@@ -1607,10 +1621,11 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                     if (c.j == 0) (c.area(side, c.p) + woff(s))[0] = q ? ((1u << n) - 1u) : 0u;
                 }
             } else if (ins.op == SCL_SPC) {
-                fork_leaf(std::true_type{});
+                fork_leaf(std::true_type{}, std::false_type{});
             } else if (ins.op == SCL_R1) {
-                fork_leaf(std::false_type{});
+                fork_leaf(std::false_type{}, std::false_type{});
             }
+        op_done:
             if (ins.op <= SCL_G && s - 1 >= c.s0) {
                 // this op stored LLRs to the global arena: wait for the stores (L2 is the meeting point; the
                 // arena is read back with sc1 loads)
@@ -1622,7 +1637,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                 const uint64_t t_end = __builtin_amdgcn_s_memtime();
                 if (lane == 0) P.cycles[pc] = (uint32_t)(t_end - t_start);
             }
-            if (DIAG && P.trace && cw == 0 && ins.op >= SCL_R0) {
+            if (DIAG && P.trace && cw == 0 && is_leaf) {
                 if (trace_n < P.trace_cap) {
                     float* t = P.trace + (size_t)trace_n * (1 + P.L);
                     if (lane == 0) t[0] = (float)c.P;

@@ -48,6 +48,8 @@ enum Op : uint8_t {
     SCL_G_S,
     SCL_C_S,       // COMBINE with h < 32 (one bit word per child)
     SCL_C_W,       // COMBINE with h >= 32 (word-wise)
+    SCL_SPC_S,     // SPC / R1 leaf of at most 8 LLRs held in LDS, 8 lanes per path (L <= 8 kernels only)
+    SCL_R1_S,
 };
 
 struct Ins {
