@@ -130,20 +130,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # BENCH_BACKEND=gloo: rehearsal of the N > 1 plumbing on a box with fewer GPUs than ranks (ranks share
+    # devices, the gather goes through host memory); the driver's runs use the default, nccl (= RCCL).
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     log2b = args.log2_batch if args.log2_batch is not None else cfg["log2_batch"]
     B = 1 << log2b                                   # per GPU (weak scaling: fixed work per GPU)
     N, K, L = cfg["N"], cfg["K"], cfg["L"]
     nb = (K + 7) // 8
     frozen = frozen_bits(N, K, cfg["dsnr"], "BB")
-    dec = pypolar_amd.PolarDecoder(N, L, frozen, "float", device=local_rank)
+    dec = pypolar_amd.PolarDecoder(N, L, frozen, "float", device=dev_index)
     dec.setErrorDetection(cfg["crc"], cfg["crc_type"])
 
     llr, info = make_batch(cfg, frozen, B, dev, seed=1234 + rank)
@@ -151,15 +159,28 @@ def main():
     ok = torch.empty((B,), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
+    # N > 1: the only exchange of the path -- decoded bytes + verdict of every rank (RCCL all-gather over xGMI)
+    packed = torch.empty((B, nb + 1), dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.empty((B * world, nb + 1), dtype=torch.uint8, device=dev) if world > 1 else None
+
     def step():
         dec.decode_batch(llr, out=out, ok=ok)
         if world > 1:
-            return sharding.gather_decoded(sharding.pack_result(out, ok))
+            packed[:, :nb].copy_(out)
+            packed[:, nb].copy_(ok)
+            if backend != "nccl":  # rehearsal path: gloo gathers host tensors
+                host = torch.empty((B * world, nb + 1), dtype=torch.uint8)
+                torch.distributed.all_gather_into_tensor(host, packed.cpu())
+                return host
+            return sharding.gather_decoded(packed, equal_rows=True, out=gathered)
         return None
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            if backend == "nccl":
+                torch.distributed.barrier(device_ids=[dev_index])
+            else:
+                torch.distributed.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -172,7 +193,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     kms = dec.kernel_times_ms()

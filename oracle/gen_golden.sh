@@ -51,5 +51,22 @@ for N in 8 16 32 64 128 256 512 2048; do
     done
   done
 done
+# --- hand-made frozen sets (reach SC nodes no construction produces: ZEROSPC (Q8), DSPC n > 8, TREP, plain n = 8) ---
+: > $G/handmade.bin
+hm() {  # N  "frozen indices"
+  printf "%s\n" $2 > $T/f.txt
+  for L in 1 4 8; do for mode in noise ties; do
+    seed=$(( seed + 1 ))
+    $H gen $1 0 $L @$T/f.txt 0.0 0 crc 2.0 12 $seed $mode float $T/x.bin 2>/dev/null
+    cat $T/x.bin >> $G/handmade.bin
+  done; done
+}
+hm 16 "0 1 2 3 4 5 6 7 8"
+hm 32 "0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16"
+hm 32 "0 1"
+hm 16 "0 1 2 3 4 5 6 7 8 9 10 11 12"
+hm 8  "0 1 4"
+hm 16 "0 1 2 4 8"
+hm 64 "0 1 2 3 4 5 6 7 8 9 10 12 16 17 18 20 24 32 33 34 36 40 48"
 rm -rf $T
 ls -la $G; du -sh --apparent-size $G

@@ -12,6 +12,7 @@
 //
 // Sub-commands
 //   gen   N K L ctor dsnr crcsize crctype ebn0_db count seed mode dectype out.bin
+//         (ctor = BB | BE | 5G, or @file with one frozen index per line: hand-made sets, K is then derived)
 //         writes a golden fixture (format below).  A FRESH decoder object is used for every
 //         codeword (the reference carries mMetric[0] over between calls).
 //   time  N K L ctor dsnr crcsize crctype ebn0_db rows threads seconds
@@ -137,7 +138,16 @@ static int cmd_gen(int argc, char** argv)
     const std::string mode = argv[12];
     c.dectype = (std::string(argv[13]) == "mixed") ? 2 : 0;
     const char* out = argv[14];
-    c.F = Construction::frozen_bits(c.N, c.K, c.dsnr, c.ctor);
+    if (!c.ctor.empty() && c.ctor[0] == '@') {  // explicit frozen set: one index per line in the named file
+        FILE* ff = fopen(c.ctor.c_str() + 1, "r");
+        if (!ff) { perror(c.ctor.c_str() + 1); return 1; }
+        unsigned v;
+        while (fscanf(ff, "%u", &v) == 1) c.F.push_back(v);
+        fclose(ff);
+        c.K = c.N - (unsigned)c.F.size();
+    } else {
+        c.F = Construction::frozen_bits(c.N, c.K, c.dsnr, c.ctor);
+    }
     const unsigned nb = (c.K + 7) / 8;
 
     Encoding::ButterflyFipPacked enc(c.N, c.F);

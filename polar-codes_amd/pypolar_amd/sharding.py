@@ -19,12 +19,20 @@ def pack_result(out_bytes, ok):
     return torch.cat([out_bytes, ok.reshape(-1, 1).to(torch.uint8)], dim=1).contiguous()
 
 
-def gather_decoded(packed_local, rows_total=None, group=None):
+def gather_decoded(packed_local, rows_total=None, group=None, equal_rows=False, out=None):
     """All-gather the per-rank packed results into the full [rows_total, nb + 1] matrix (every rank gets
-    it).  Ranks may hold different row counts (ragged tail): shorter blocks are padded for the collective."""
+    it).  Ranks may hold different row counts (ragged tail): shorter blocks are padded for the collective.
+    equal_rows=True (every rank holds the same number of rows, e.g. the weak-scaling benchmark) skips the
+    row-count exchange: exactly one collective, no host synchronisation; `out` may be a preallocated buffer."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return packed_local
+    if equal_rows:
+        if out is None:
+            out = torch.empty((world * packed_local.shape[0], packed_local.shape[1]), dtype=packed_local.dtype,
+                              device=packed_local.device)
+        dist.all_gather_into_tensor(out, packed_local, group=group)
+        return out
     n_local = torch.tensor([packed_local.shape[0]], dtype=torch.int64, device=packed_local.device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)

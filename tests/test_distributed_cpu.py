@@ -31,6 +31,10 @@ def _worker(rank, world, port, rows, nb, q):
     out = ((idx[:, None] * 7 + torch.arange(nb)[None, :] * 13) % 251).to(torch.uint8)
     ok = (idx % 3 == 0).to(torch.uint8)
     full = sharding.gather_decoded(sharding.pack_result(out, ok), rows)
+    if rows % world == 0:  # the benchmark's fast path: equal blocks, preallocated output, one collective
+        buf = torch.empty((rows, nb + 1), dtype=torch.uint8)
+        full2 = sharding.gather_decoded(sharding.pack_result(out, ok), equal_rows=True, out=buf)
+        assert torch.equal(full2, full)
     gi = torch.arange(rows, dtype=torch.int64)
     exp = torch.cat([((gi[:, None] * 7 + torch.arange(nb)[None, :] * 13) % 251).to(torch.uint8),
                      (gi % 3 == 0).to(torch.uint8)[:, None]], dim=1)

@@ -212,3 +212,60 @@ def test_cpp_shim_decodes_on_gpu(built_library):
     from test_host import _build_cpp_shim
     r = subprocess.run([_build_cpp_shim(built_library), "gpu"], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("N,K,L", [(256, 128, 3), (256, 96, 5), (512, 256, 6), (128, 64, 12), (1024, 512, 7),
+                                    (8192, 4096, 1), (8192, 4096, 4), (4096, 1024, 8), (16384, 8192, 1)])
+def test_odd_list_sizes_and_large_blocks(built_library, N, K, L):
+    """list sizes that are not powers of two (the reference accepts any L) and block lengths above the
+    BASELINE configs, on Bhattacharyya frozen sets built by pypolar_amd.construction (= the reference's)."""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    rng = np.random.default_rng(N + 17 * L)
+    frozen = frozen_bits(N, K, 0.0, "BB")
+    det = 8
+    B = 24 if N <= 1024 else 6
+    rows = []
+    for i in range(B):
+        info = rng.integers(0, 256, K // 8, dtype=np.uint8)
+        _, cw = ob.encode(N, frozen, det, info)
+        x = 1.0 - 2.0 * np.unpackbits(cw)[:N]
+        rows.append(x + rng.normal(0, 0.95, N) if i % 2 else np.round((x + rng.normal(0, 0.9, N)) * 4))
+    llr = np.asarray(rows, np.float32)
+    d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
+    res = d.decode_batch(llr, return_metrics=L > 1)
+    e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, det, llr, True, "float")
+    assert np.array_equal(res[0], e_out)
+    assert np.array_equal(res[1].astype(np.uint8), e_ok)
+    if L > 1:
+        assert np.allclose(res[2], e_met, rtol=METRIC_RTOL, atol=0)
+
+
+HANDMADE = [
+    # frozen sets no construction produces but the API accepts; they reach the SC nodes the BB/BE sets never
+    # use (SURVEY Q8 / App. A.1 rule 11a: ZEROSPC needs index 7 frozen while 9 is information; plain n = 8
+    # blocks without a special decoder; DSPC with n > 8; TREP)
+    (16, [0, 1, 2, 3, 4, 5, 6, 7, 8]),                 # left half frozen, right half one frozen -> ZEROSPC
+    (32, list(range(16)) + [16]),                      # ZEROSPC at n = 32
+    (32, [0, 1]),                                      # DSPC, n = 32
+    (16, list(range(13))),                             # TREP  (c = n-3, last frozen = n-4)
+    (8, [0, 1, 4]),                                    # n = 8 without a special node -> ShortRateR
+    (16, [0, 1, 2, 4, 8]),                             # generic split, RateR + small leaves
+    (64, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 17, 18, 20, 24, 32, 33, 34, 36, 40, 48]),
+]
+
+
+@pytest.mark.parametrize("N,frozen", HANDMADE, ids=[f"N{n}_F{len(f)}" for n, f in HANDMADE])
+@pytest.mark.parametrize("L", [1, 4, 8])
+def test_handmade_frozen_sets(built_library, N, frozen, L):
+    import pypolar_amd
+    rng = np.random.default_rng(N * 7 + len(frozen) + L)
+    F = np.asarray(frozen, np.uint32)
+    llr = np.concatenate([rng.normal(0, 1, (96, N)), rng.choice([-1.0, 1.0, 2.0, -2.0], (96, N))]).astype(np.float32)
+    d = pypolar_amd.PolarDecoder(N, L, F, "float")
+    d.setErrorDetection(0, "crc")
+    res = d.decode_batch(llr, return_metrics=L > 1)
+    e_out, e_ok, e_met = ob.decode_batch(N, L, F, 0, llr, True, "float")
+    assert np.array_equal(res[0], e_out)
+    if L > 1:
+        assert np.allclose(res[2], e_met, rtol=METRIC_RTOL, atol=0)
