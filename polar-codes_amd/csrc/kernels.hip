@@ -1674,7 +1674,19 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
         }
         // detector verdict of every path in parallel (syndrome XOR), first passing path wins
         uint32_t winner = 0, okflag = 1;
+        bool best_passes = false;
         if (P.det_on) {
+            // the best path passes for almost every codeword: check it alone with all 64 lanes first
+            const uint32_t* b0 = c.area(0, 0) + woff(logN);
+            uint32_t syn0 = 0;
+            for (uint32_t t = lane; t < P.K; t += 64) {
+                const uint32_t pos = P.lut[t];
+                if ((b0[pos >> 5] >> (pos & 31u)) & 1u) syn0 ^= P.syn[t];
+            }
+            syn0 = group_xor_u32<64>(syn0);
+            best_passes = __builtin_amdgcn_readfirstlane(syn0) == 0;
+        }
+        if (P.det_on && !best_passes) {
             uint32_t syn = 0;
             if (active) {
                 for (uint32_t t = c.j; t < P.K; t += LP) {
