@@ -13,7 +13,10 @@ import os
 
 import numpy as np
 
-__all__ = ["PolarDecoder", "PolarAmdError", "library_path", "load_library", "C_SYMBOLS"]
+from .construction import frozen_bits  # noqa: E402,F401  (pypolar.frozen_bits)
+from .detector import Detector          # noqa: E402,F401  (pypolar.Detector)
+
+__all__ = ["PolarDecoder", "Detector", "frozen_bits", "PolarAmdError", "library_path", "load_library", "C_SYMBOLS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpolar_amd.so")

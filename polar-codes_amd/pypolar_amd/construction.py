@@ -29,9 +29,28 @@ def bhattacharyya_parameters(N, K, design_snr_db):
 def frozen_bits(blockLength, infoLength, designSNR=0.0, constructor_type="BB"):
     N, K = int(blockLength), int(infoLength)
     t = str(constructor_type).lower()
-    if "be" in t or "5g" in t:
-        raise NotImplementedError("only the Bhattacharyya (\"BB\") construction is provided; pass other "
-                                  "frozen sets explicitly (they are plain index lists)")
+    if "be" in t:
+        return beta_expansion_frozen_bits(N, K)
+    if "5g" in t:
+        raise NotImplementedError("the 5G reliability table is not shipped; pass that frozen set explicitly "
+                                  "(it is a plain index list)")
     z = bhattacharyya_parameters(N, K, designSNR)
     order = np.argsort(-z, kind="stable")     # stable descending: ties keep ascending index order
+    return np.sort(order[: N - K]).astype(np.uint32)
+
+
+def beta_expansion_frozen_bits(N, K):
+    """``frozen_bits(N, K, _, "BE")``: polarisation-weight construction with beta = 2^(1/4)
+    (reference: src/polarcode/construction/betaexpansion.cpp:44-78): weight(i) = sum_j bit_j(i) * beta^j, the
+    N-K smallest weights are frozen."""
+    n = int(round(math.log2(N)))
+    beta = math.pow(2.0, 1.0 / 4.0)
+    w = [math.pow(beta, float(j)) for j in range(n)]
+    weights = np.zeros(N, np.float64)
+    for i in range(N):
+        acc = 0.0
+        for j in range(n):
+            acc += w[j] * ((i >> j) & 1)
+        weights[i] = acc
+    order = np.argsort(weights, kind="stable")
     return np.sort(order[: N - K]).astype(np.uint32)

@@ -68,3 +68,68 @@ def checksum_bit_matrix(size, nb):
         msg[t >> 3] = 0x80 >> (t & 7)
         M[t] = np.unpackbits(generate(size, msg)[nb - fb:])
     return M
+
+
+def _crc_msb_bits(data, nbits, width, poly):
+    """CRC++ CalculateBits (CRC.h:613-645, :1059-1110): MSB-first over the first nbits bits of the byte stream"""
+    top, mask, r = 1 << (width - 1), (1 << width) - 1, 0
+    d = bytes(np.asarray(data, dtype=np.uint8))
+    for t in range(nbits):
+        bit = (d[t >> 3] >> (7 - (t & 7))) & 1
+        fb = (1 if (r & top) else 0) ^ bit
+        r = (r << 1) & mask
+        if fb:
+            r ^= poly
+    return r
+
+
+class Detector:
+    """``pypolar.Detector(size, type)`` (reference: python/bindings/detector_python.cc:19-77) for the detectors of
+    the accelerated path: dummy (size 0), CRC-8, CRC-11 (NR), CRC-24C (NR), CRC-32C.  Host-side utility."""
+
+    def __init__(self, size, type):
+        t = str(type).lower()
+        if "crc" in t:
+            if size not in (0, 6, 8, 11, 16, 24, 32):
+                raise RuntimeError("CRC INVALID SIZE!")
+            if size in (6, 16):
+                raise NotImplementedError("CRC-6 / CRC-16 are not on the accelerated path")
+        elif "cmac" in t:
+            raise NotImplementedError("CMAC is not on the accelerated path")
+        else:
+            raise RuntimeError("Unknown Error detector requested!")
+        self._size = int(size)
+
+    def getCheckBitCount(self):
+        return self._size
+
+    def getType(self):
+        return "DUMMY" if self._size == 0 else ("CRCNR" if self._size in (11, 24) else "CRC")
+
+    @staticmethod
+    def _arr(data):
+        a = np.asarray(data)
+        if a.ndim != 1:
+            raise RuntimeError("Only ONE-dimensional vectors allowed!")
+        return np.ascontiguousarray(a.astype(np.uint8))
+
+    def calculate(self, data, bitsize):
+        a = self._arr(data)
+        if a.size * 8 < bitsize:
+            raise RuntimeError("Provided number of bits is smaller than stated significant bits!")
+        if self._size in _PARAMS:
+            w, poly, _ = _PARAMS[self._size]
+            if self._size == 8:                       # CRC8::calculate works on whole bytes (crc8.cpp:31-34)
+                return _crc_msb(a[: bitsize // 8], w, poly)
+            return _crc_msb_bits(a, int(bitsize), w, poly)
+        if self._size == 32:                          # CRC32::calculate: gen(words, bits / 8) (crc32.cpp:28-31)
+            return _crc32c_le(a[: 4 * (int(bitsize) // 8)])
+        return 0
+
+    def generate(self, data):
+        a = self._arr(data)
+        fb = (self._size + 8) // 8 if self._size % 8 else self._size // 8
+        return generate(self._size, np.concatenate([a, np.zeros(fb, np.uint8)]))
+
+    def check(self, data):
+        return check(self._size, self._arr(data))

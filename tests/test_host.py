@@ -170,3 +170,58 @@ def test_cpp_shim_host_side(built_library):
     mode = "gpu" if torch.cuda.is_available() else "host"
     r = subprocess.run([exe, mode], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
+def test_frozen_bits_match_reference_sets():
+    """pypolar.frozen_bits parity (qa_pypolar_decoder.py:29-46): the BB and BE constructions reproduce every
+    frozen set the reference produced for the golden fixtures (the sets are stored in the fixture headers)."""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    dsnr = {"cfg1_n64_k40_sc_awgn.bin": 1.0}
+    for name in ("cfg1_n64_k40_sc_awgn.bin", "cfg2_n1024_k512_sc_awgn.bin", "cfg5_n4096_k2048_l32_crc32_awgn.bin"):
+        fx = gio.load_named(name)
+        assert np.array_equal(frozen_bits(fx.N, fx.K, dsnr.get(name, 0.0), "BB"), fx.frozen), name
+    n_bb = n_be = 0
+    for path in gio.all_files("sweep_*.bin"):
+        for fx in gio.load(path):
+            if fx.crc_size == 8 or (fx.K <= 8 or fx.K % 8):   # gen_golden.sh: BB sets carry CRC-8 when K allows
+                bb = frozen_bits(fx.N, fx.K, 0.0, "BB")
+                if np.array_equal(bb, fx.frozen):
+                    n_bb += 1
+                    continue
+            assert np.array_equal(frozen_bits(fx.N, fx.K, 0.0, "BE"), fx.frozen), fx.name
+            n_be += 1
+    assert n_bb > 100 and n_be > 30
+    assert pypolar_amd.frozen_bits is frozen_bits
+
+
+def test_detector_class_known_answers():
+    """pypolar.Detector mirror against the reference's own vectors (python/qa_pypolar_detector.py)"""
+    import pypolar_amd
+    D = pypolar_amd.Detector
+    d8 = D(8, "cRc")
+    assert (d8.getCheckBitCount(), d8.getType()) == (8, "CRC")
+    for msg, ref in (("ChaoticLama", 0x67), ("NeverListenToTheVoid!", 0x69)):         # :63-84
+        m = np.array([ord(c) for c in msg])
+        assert d8.generate(m)[-1] == ref and d8.check(np.append(m, ref)) and not d8.check(np.append(m, 42))
+    d32 = D(32, "cRc")
+    for msg, ref in (("Test", [0x8C, 0x2D, 0xE2, 0x19]), ("FooBarPolarT", [0x38, 0xAC, 0x62, 0xC9])):   # :86-123
+        res = d32.generate(np.array([ord(c) for c in msg]))
+        assert list(res[-4:]) == ref and d32.check(res)
+    bits_a = np.array([0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 1, 0, 0, 1, 0], np.uint8)
+    bits_b = np.array([1, 0, 1, 1, 1, 1, 0, 1, 0, 0, 0, 1, 0], np.uint8)
+    d24 = D(24, "cRcNr")
+    assert (d24.getCheckBitCount(), d24.getType()) == (24, "CRCNR")
+    assert d24.calculate(np.packbits(bits_a), bits_a.size) == 0x1FB065                # :301-323
+    assert d24.calculate(np.packbits(bits_b), bits_b.size) == 0xF70030
+    assert list(d24.generate(np.frombuffer(b"123456789", np.uint8))[-3:]) == [0xF4, 0x82, 0x79]
+    d11 = D(11, "cRcNr")
+    assert d11.calculate(np.packbits(bits_a), bits_a.size) == 0x0608                  # :424-447
+    assert d11.calculate(np.packbits(bits_b), bits_b.size) == 0x06C8
+    assert list(d11.generate(np.frombuffer(b"123456789", np.uint8))[-2:]) == [0x05, 0xCA]
+    assert list(d11.generate(np.array([ord(c) for c in "CommsIsAComplicatedMatter"]))[-2:]) == [0x04, 0x4E]
+    assert D(0, "crc").getType() == "DUMMY" and D(0, "crc").check(np.zeros(4, np.uint8))
+    with pytest.raises(RuntimeError, match="CRC INVALID SIZE!"):
+        D(7, "crc")
+    with pytest.raises(RuntimeError, match="Unknown Error detector requested!"):
+        D(8, "md5")
