@@ -56,6 +56,7 @@ struct pcd_decoder {
 
     // launch geometry
     unsigned sc_wave_words = 0, sc_wpb = 4;  // LDS words per codeword, waves per workgroup
+    unsigned sc_virtual_top = 0;
     int sc_lcl = 4;                           // log2(lanes per codeword): 4 -> four codewords per wave
     int lpl = 3;
     unsigned lmax = 8, path_stride = 0, wppL = 0, wppR = 0, scl_wave_words = 0, scl_wpb = 1;
@@ -119,9 +120,12 @@ void compute_geometry(pcd_decoder* d)
 {
     const unsigned N = d->N;
     const unsigned bitw = N >= 32 ? N / 32 : 1;
-    // SC: N floats (stages below the root) + packed bits per codeword; 64/LC codewords per wave
-    d->sc_wave_words = (N + bitw + 3) & ~3u;
-    d->sc_lcl = N <= 1024 ? 4 : 6;
+    // SC: LLR stages below the root + packed bits per codeword; 64/LC codewords per wave.  The stage right below
+    // the root (N/2 floats, half of the LLR memory) is not stored but recomputed from the channel row whenever the
+    // root's children are inner nodes or leaves reading through the same accessor (always possible; N >= 16).
+    d->sc_virtual_top = (N >= 16 && !std::getenv("PCD_SC_NO_VIRTUAL")) ? 1u : 0u;
+    d->sc_wave_words = ((d->sc_virtual_top ? N / 2 : N) + bitw + 3) & ~3u;
+    d->sc_lcl = N <= 2048 ? 4 : 6;  // 16 lanes per codeword while four codewords still leave >= 9 waves per CU
     if (const char* e = std::getenv("PCD_SC_LCL")) {  // experiments
         const int v = std::atoi(e);
         d->sc_lcl = (v == 3 || v == 6) ? v : 4;
@@ -268,6 +272,8 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     P.prog = d->d_sc_prog;
     P.wave_lds_words = d->sc_wave_words;
     P.metrics = nullptr;
+    P.sc_virtual_top = d->sc_virtual_top;
+    P.prog_root_g0r = (!d->sc_prog.ins.empty() && d->sc_prog.ins[0].op == pamd::SC_G0R) ? 1u : 0u;
     const unsigned cw_per_wave = 64u >> d->sc_lcl;
     const size_t lds = (size_t)d->sc_wpb * cw_per_wave * d->sc_wave_words * 4;
     if (d->sc_blocks_per_cu == 0) {  // resident workgroups per CU: the grid is sized to exactly fill the chip

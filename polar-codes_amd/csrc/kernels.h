@@ -25,6 +25,8 @@ struct DecodeParams {
     float* arena;            // SCL: global scratch for LLR stages >= s0 (one slice per resident wave)
     uint32_t arena_wave_words, arena_path_stride;
     uint32_t s0;             // SCL: first LLR stage kept in the arena (logN = none)
+    uint32_t sc_virtual_top; // SC: stage logN-1 is recomputed from the channel row instead of being stored in LDS
+    uint32_t prog_root_g0r;  // SC: the root is a ZeroR node (its right child input is a + b)
     uint32_t wave_lds_words; // LDS words one codeword owns (SCL: one wave = one codeword; SC: 64/LC codewords per wave)
     float* trace;            // diagnostics (nullable): row 0 only, (1 + L) floats after every SCL leaf
     uint32_t trace_cap;

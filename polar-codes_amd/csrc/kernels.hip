@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
     // this codeword's LDS slice
     uint32_t* wl = smem + ((size_t)wib * CW + slot) * P.wave_lds_words;
     float* llr = reinterpret_cast<float*>(wl);
-    uint32_t* bits = wl + N;
+    const bool virt = P.sc_virtual_top != 0;          // stage logN-1 recomputed from the channel, not stored
+    uint32_t* bits = wl + (virt ? (N >> 1) : N);
     const uint32_t wave0 = blockIdx.x * wpb + wib, nwaves = gridDim.x * wpb;
     const const_u64_ptr prog64 = (const_u64_ptr)(uintptr_t)P.prog;
     const uint32_t ngroups = (P.rows + CW - 1) / CW;
@@ -531,11 +532,26 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                 default: break;
                 }
             };
-            if (s == logN) {
+            auto ch = [&](uint32_t i) -> float {
                 if constexpr (I8)
-                    run([&](uint32_t i) { return (float)reinterpret_cast<const int8_t*>(chan)[i]; });
+                    return (float)reinterpret_cast<const int8_t*>(chan)[i];
                 else
-                    run([&](uint32_t i) { return reinterpret_cast<const float*>(chan)[i]; });
+                    return reinterpret_cast<const float*>(chan)[i];
+            };
+            if (s == logN) {
+                // the stage below the root is never stored (see below), so the root's F / G / G0R have nothing to do
+                if (!(virt && (op == SC_F || op == SC_G || op == SC_G0R))) run(ch);
+            } else if (virt && s + 1 == logN) {
+                // "virtual" stage logN-1: its LLRs are recomputed from the channel row (L2-resident) on every use
+                // instead of living in LDS -- left half: f(x_i, x_{i+N/2}); right half: g(.., root-left bit i) where
+                // the root's left output still sits untouched in bits[0, N/2)
+                const uint32_t hN = N >> 1;
+                if (off == 0)
+                    run([&](uint32_t i) { return polar_f(ch(i), ch(hN + i)); });
+                else if (P.prog_root_g0r)
+                    run([&](uint32_t i) { return ch(i) + ch(hN + i); });
+                else
+                    run([&](uint32_t i) { return polar_g(ch(i), ch(hN + i), (bits[i >> 5] >> (i & 31u)) & 1u); });
             } else {
                 const float* xs = llr + n;
                 run([&](uint32_t i) { return xs[i]; });
