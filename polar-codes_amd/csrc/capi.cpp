@@ -61,6 +61,7 @@ struct pcd_decoder {
     int lpl = 3;
     unsigned lmax = 8, path_stride = 0, wppL = 0, wppR = 0, scl_wave_words = 0, scl_wpb = 1;
     unsigned s0 = 0, arena_path_stride = 0, arena_wave_words = 0;
+    bool virtual_top = false;
     float* d_arena = nullptr;
     size_t d_arena_cap = 0;
 
@@ -174,6 +175,27 @@ void compute_geometry(pcd_decoder* d)
 // Replace generic inner-node ops by their specialised forms (program.h) for the chosen geometry.
 void specialize_scl(pcd_decoder* d)
 {
+    // Virtual top stage: if the stage below the root would live in the arena and both children of the root are
+    // inner nodes with at least 64 outputs per path, it is never stored -- the root's F / G only keep their
+    // slot-word bookkeeping (flag 2) and the children's F / G recompute their inputs from the channel row
+    // (flag 4, +8 for the right child).  Removes the largest arena stage and its HBM-side traffic.
+    if (d->s0 < d->logN && d->logN >= 8 && !std::getenv("PCD_NO_VIRTUAL")) {
+        bool ok = !d->scl_prog.ins.empty() && d->scl_prog.ins[0].op == pamd::SCL_F && d->scl_prog.ins[0].stage == d->logN;
+        for (const auto& in : d->scl_prog.ins)
+            if (in.stage == d->logN - 1 && in.op >= pamd::SCL_R0 && in.op <= pamd::SCL_SPC) ok = false;  // leaf child
+        if (ok) {
+            bool seen_root_g = false;
+            for (auto& in : d->scl_prog.ins) {
+                if (in.stage == d->logN && (in.op == pamd::SCL_F || in.op == pamd::SCL_G)) {
+                    in.side |= 2;
+                    if (in.op == pamd::SCL_G) seen_root_g = true;
+                } else if (in.stage == d->logN - 1 && (in.op == pamd::SCL_F || in.op == pamd::SCL_G)) {
+                    in.side |= seen_root_g ? (4 | 8) : 4;
+                }
+            }
+            d->virtual_top = true;
+        }
+    }
     auto woff = [](unsigned t) { return t <= 5 ? t : ((1u << (t - 5)) + 4u); };
     const unsigned fb = 6u - (unsigned)d->lpl;
     for (auto& in : d->scl_prog.ins) {

@@ -1201,6 +1201,22 @@ __device__ __forceinline__ void write_leaf_bits(const CTX& c, const SRC& x, uint
     }
 }
 
+// "Virtual" stage logN-1: the LLRs right below the root are never stored.  Left child of the root:
+// f(x_i, x_{i+N/2}); right child: g(x_i, x_{i+N/2}, u_i) with u = the root's left-child bits of the path (held by
+// the path buffer its slot word names).  Four consecutive values from two 16-byte channel loads.
+template <bool I8>
+__device__ __forceinline__ float4 virt_top4(const void* chan, uint32_t halfN, uint32_t i, bool right, const uint32_t* rootleft)
+{
+    const Rd<I8 ? K_GI8 : K_GF32> x{ chan };
+    const float4 a = x.ld4(i), b = x.ld4(halfN + i);
+    if (right) {
+        const uint32_t u = (rootleft[i >> 5] >> (i & 31u)) & 0xFu;
+        return make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u), polar_g(a.z, b.z, (u >> 2) & 1u),
+                           polar_g(a.w, b.w, u >> 3));
+    }
+    return make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z), polar_f(a.w, b.w));
+}
+
 // 4 waves per SIMD (<= 128 VGPRs) for the L <= 8 production kernels: occupancy is what hides the LDS / arena latency
 template <int LPL, bool I8, bool S64, bool DIAG>
 __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_kernel(DecodeParams P)
@@ -1257,7 +1273,10 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
             iw_next = prog64[pc + 1];  // scalar load, in flight while this instruction executes
             ins.stage = (uint8_t)((iw >> 8) & 0xFF);
             ins.side = (uint8_t)((iw >> 16) & 0xFF);
-            const uint32_t s = ins.stage, n = 1u << s, h = n >> 1, side = ins.side;
+            const uint32_t s = ins.stage, n = 1u << s, h = n >> 1, side = ins.side & 1u;
+            // host flags (capi.cpp, specialize_scl): 2 = the output stage is virtual (nothing to store),
+            // 4 = the input stage is virtual (recomputed from the channel row), 8 = ... of the root's RIGHT child
+            const uint32_t vflags = ins.side & 0xEu;
             const bool active = (uint32_t)c.p < c.P;
             uint64_t t_start = 0;
             if (DIAG && P.cycles && cw == 0) t_start = __builtin_amdgcn_s_memtime();
@@ -1473,6 +1492,29 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
             } else if (ins.op == SCL_F) {  // RateRNode::decode :233-238 -- reads the path's own (identity) buffer
                 if (DIAG && (P.ablate & 8u) && h >= 64) {
                 } else if (DIAG && (P.ablate & 16u) && h < 64) {
+                } else if (vflags & 2u) {
+                    // the output stage is virtual: its consumers recompute it from the channel row
+                } else if (vflags & 4u) {
+                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
+                    const bool right = (vflags & 8u) != 0, dst_arena = (s - 1) >= c.s0;
+                    const uint32_t wtop = woff(logN - 1);
+#pragma unroll 2
+                    for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+                        const uint32_t e = e0 + lane;
+                        const bool in = e < total;
+                        const uint32_t q = in ? (e >> ish) : 0u, i = (e & (ipp - 1)) << 2;
+                        const uint32_t holder = c.field(c.slot_from_lane((int)(q << LPL)), logN);
+                        if (in) {
+                            const uint32_t* rl = c.area(0, holder) + wtop;
+                            const float4 a = virt_top4<I8>(chan, N >> 1, i, right, rl), b = virt_top4<I8>(chan, N >> 1, h + i, right, rl);
+                            const float4 r = make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z),
+                                                         polar_f(a.w, b.w));
+                            if (dst_arena)
+                                Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
+                            else
+                                Wr<K_LDS>{ c.path_llr(q) + h }.st4(i, r);
+                        }
+                    }
                 } else if (h >= 64) {
                     // 16-byte items: item e = (path q, 4 consecutive LLRs); several loads in flight per lane
                     const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
@@ -1510,6 +1552,30 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                 const uint32_t wo = woff(s - 1);
                 if (DIAG && (P.ablate & 8u) && h >= 64) {
                 } else if (DIAG && (P.ablate & 16u) && h < 64) {
+                } else if (vflags & 2u) {
+                    // virtual output stage: only the slot-word update below remains
+                } else if (vflags & 4u) {
+                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
+                    const bool right = (vflags & 8u) != 0, dst_arena = (s - 1) >= c.s0;
+                    const uint32_t wtop = woff(logN - 1);
+#pragma unroll 2
+                    for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+                        const uint32_t e = e0 + lane;
+                        const bool in = e < total;
+                        const uint32_t q = in ? (e >> ish) : 0u, i = (e & (ipp - 1)) << 2;
+                        const uint32_t holder = c.field(c.slot_from_lane((int)(q << LPL)), logN);
+                        if (in) {
+                            const uint32_t* rl = c.area(0, holder) + wtop;
+                            const float4 a = virt_top4<I8>(chan, N >> 1, i, right, rl), b = virt_top4<I8>(chan, N >> 1, h + i, right, rl);
+                            const uint32_t u = ((c.area(0, q) + wo)[i >> 5] >> (i & 31u)) & 0xFu;
+                            const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
+                                                         polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, u >> 3));
+                            if (dst_arena)
+                                Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
+                            else
+                                Wr<K_LDS>{ c.path_llr(q) + h }.st4(i, r);
+                        }
+                    }
                 } else if (h >= 64) {
                     const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
                     c.template with_src_kind<I8>(s, [&](auto KS) {
@@ -1642,7 +1708,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                 fork_leaf(std::false_type{}, std::false_type{});
             }
         op_done:
-            if (ins.op <= SCL_G && s - 1 >= c.s0) {
+            if (ins.op <= SCL_G && s - 1 >= c.s0 && !(vflags & 2u)) {
                 // this op stored LLRs to the global arena: wait for the stores (L2 is the meeting point; the
                 // arena is read back with sc1 loads)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
