@@ -1,5 +1,5 @@
 import sys, os
-sys.path[:0] = ['polar-codes_amd', 'tests']
+import os; _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [os.path.join(_R, 'polar-codes_amd'), os.path.join(_R, 'tests')]
 import numpy as np, golden_io as gio, oracle_binding as ob, pypolar_amd
 rng = np.random.default_rng(1)
 for N in (16, 32, 64, 128, 256, 512):
@@ -18,6 +18,6 @@ for N in (16, 32, 64, 128, 256, 512):
             if nb_out or nb_met:
                 r = int(np.argwhere((met != e_met).any(axis=1) | (out != e_out).any(axis=1))[0][0])
                 print(f"N={N} K={K} L={L}: bad out rows {nb_out} met rows {nb_met}; first row {r}")
-                np.save(f"gpurun_out/fail_N{N}_K{K}_L{L}.npy", llr[r])
-                np.save(f"gpurun_out/fail_N{N}_K{K}_L{L}_frozen.npy", frozen)
+                np.save(f"/tmp/fail_N{N}_K{K}_L{L}.npy", llr[r])
+                np.save(f"/tmp/fail_N{N}_K{K}_L{L}_frozen.npy", frozen)
 print("done")
