@@ -34,54 +34,119 @@ CONFIGS = {
                  name="N=1024 K=512 SC, batch=2^20"),
     "cfg3": dict(N=1024, K=512, L=8, dsnr=0.0, crc=24, crc_type="crcnr", ebn0=2.0, log2_batch=20,
                  name="N=1024 K=512 SCL L=8 + CRC-24C, batch=2^20"),
+    # secondary workload: the encoder side of cfg3
+    "enc3": dict(N=1024, K=512, L=0, dsnr=0.0, crc=24, crc_type="crcnr", ebn0=2.0, log2_batch=22,
+                 name="N=1024 K=512 + CRC-24C, batch=2^22"),
 }
 
 
-def polar_transform_(x):
-    """in-place x = u G (natural order, parent = [a^b | b]) on a [B, N] uint8 tensor"""
-    B, N = x.shape
-    h = 1
-    while h < N:
-        v = x.view(B, N // (2 * h), 2, h)
-        v[:, :, 0, :] ^= v[:, :, 1, :]
-        h *= 2
-    return x
-
-
 def make_batch(cfg, frozen, B, device, seed):
-    """synthetic traffic: random payload -> checksum -> systematic polar encoding -> BPSK + AWGN.
+    """synthetic traffic: random payload -> checksum + systematic polar encoding (the product's own HIP encoder,
+    parity-tested against the reference in tests/test_gpu_encoder.py) -> BPSK + AWGN.
     returns (llr float32 [B, N], info bytes uint8 [B, nb])"""
     N, K = cfg["N"], cfg["K"]
     nb = (K + 7) // 8
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    info_pos = torch.from_numpy(np.setdiff1d(np.arange(N), frozen).astype(np.int64)).to(device)
-    frozen_t = torch.from_numpy(frozen.astype(np.int64)).to(device)
-    fb = pdet.field_bytes(cfg["crc"])
-    M = torch.from_numpy(pdet.checksum_bit_matrix(cfg["crc"], nb).astype(np.float32)).to(device) if fb else None
+    enc = pypolar_amd.PolarEncoder(N, frozen, device=device.index)
+    enc.setErrorDetection(cfg["crc"], cfg["crc_type"])
     sigma = 1.0 / np.sqrt(2.0 * 10 ** (cfg["ebn0"] / 10.0) * K / N)
+    info = torch.randint(0, 256, (B, nb), generator=g, device=device, dtype=torch.uint8)
+    code = enc.encode_batch(info)                  # fills the checksum fields of `info` in place
     llr = torch.empty((B, N), dtype=torch.float32, device=device)
-    info = torch.empty((B, nb), dtype=torch.uint8, device=device)
-    weights = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.int32, device=device)
+    shifts = torch.arange(7, -1, -1, device=device, dtype=torch.uint8)
     chunk = 1 << 17
     for lo in range(0, B, chunk):
         n = min(chunk, B - lo)
-        msg = torch.randint(0, 2, (n, 8 * (nb - fb)), generator=g, device=device, dtype=torch.uint8)
-        if fb:
-            chk = (msg.float() @ M).to(torch.int32).remainder_(2).to(torch.uint8)
-            bits = torch.cat([msg, chk], dim=1)
-        else:
-            bits = msg
-        info[lo:lo + n] = (bits.view(n, nb, 8).to(torch.int32) * weights).sum(dim=2).to(torch.uint8)
-        u = torch.zeros((n, N), dtype=torch.uint8, device=device)
-        u[:, info_pos] = bits[:, :K]
-        polar_transform_(u)
-        u[:, frozen_t] = 0
-        polar_transform_(u)
+        bits = ((code[lo:lo + n].unsqueeze(-1) >> shifts) & 1).reshape(n, N)
         noise = torch.randn((n, N), generator=g, device=device, dtype=torch.float32)
-        llr[lo:lo + n] = (1.0 - 2.0 * u.float()) + sigma * noise
-        del u, noise, bits, msg
+        llr[lo:lo + n] = (1.0 - 2.0 * bits.float()) + sigma * noise
+        del bits, noise
+    torch.cuda.synchronize()
     return llr, info
+
+
+def cpu_baseline_encode(cfg, seconds):
+    """the reference's CPU encoder (oracle/_ref) on the GPU box's host cores; else the scalar oracle port"""
+    cores = len(os.sched_getaffinity(0))
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if os.path.exists(harness):
+        try:
+            out = subprocess.run([harness, "enctime", str(cfg["N"]), str(cfg["K"]), "BB", str(cfg["dsnr"]),
+                                  str(cfg["crc"]), cfg["crc_type"], str(cores), str(seconds)],
+                                 capture_output=True, text=True, timeout=seconds * 6 + 120, check=True)
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+            return {"value": r["cw_per_s"], "unit": "codewords/s", "cores": cores, "kind": "reference",
+                    "sample": f"256 random information words per thread cycled for {r['seconds']:.1f} s, one reference "
+                              f"ButterflyFipPacked per thread ({cores} threads), {r['codewords']} encodes"}
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] reference harness unavailable ({e}); timing the oracle port", file=sys.stderr)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    frozen = frozen_bits(cfg["N"], cfg["K"], cfg["dsnr"])
+    info = np.random.default_rng(0).integers(0, 256, (cfg["K"] + 7) // 8, dtype=np.uint8)
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds:
+        for _ in range(64):
+            ob.encode(cfg["N"], frozen, cfg["crc"], info)
+        n += 64
+    el = time.time() - t0
+    return {"value": n / el, "unit": "codewords/s", "cores": 1, "kind": "port",
+            "sample": f"{n} encodes by the scalar C oracle in {el:.1f} s"}
+
+
+def bench_encode(args, cfg, dev, dev_index, rank, world, barrier_fn):
+    """secondary workload: batched systematic encoding + checksum generation"""
+    N, K = cfg["N"], cfg["K"]
+    nb = (K + 7) // 8
+    log2b = args.log2_batch if args.log2_batch is not None else cfg["log2_batch"]
+    B = 1 << log2b
+    frozen = frozen_bits(N, K, cfg["dsnr"], "BB")
+    enc = pypolar_amd.PolarEncoder(N, frozen, device=dev_index)
+    enc.setErrorDetection(cfg["crc"], cfg["crc_type"])
+    g = torch.Generator(device=dev)
+    g.manual_seed(77 + rank)
+    info = torch.randint(0, 256, (B, nb), generator=g, device=dev, dtype=torch.uint8)
+    code = torch.empty((B, N // 8), dtype=torch.uint8, device=dev)
+    for _ in range(args.warmup):
+        enc.encode_batch(info, out=code)
+    barrier_fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:  # the encoder is launched on torch's current stream, so torch events bracket the kernel
+        a.record()
+        enc.encode_batch(info, out=code)
+        b.record()
+    barrier_fn()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    if rank != 0:
+        return
+    fb = pdet.field_bytes(cfg["crc"])
+    bytes_per_cw = nb + N // 8 + fb      # information word in, code word out, checksum field written back
+    achieved = bytes_per_cw * B / (k_ms * 1e-3) / 1e9
+    cw_s = B * world * args.steps / elapsed
+    res = {
+        "metric": f"codewords/sec, systematic encode, {cfg['name']}",
+        "value": cw_s, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "encode " + cfg["name"] + (" per GPU" if world > 1 else ""), "block_length": N,
+                   "info_bits": K, "detector": f"{cfg['crc_type']}-{cfg['crc']}", "codewords_per_gpu": B,
+                   "frozen_set": f"BB dSNR {cfg['dsnr']} dB",
+                   "parallelism": f"rows sharded over {world} GPU(s), no exchange" if world > 1 else "single GPU"},
+        "code_gbit_per_s": cw_s * N / 1e9,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "encode_kernel",
+                     "kernel_ms_avg": k_ms, "algorithmic_bytes_per_codeword": bytes_per_cw, "codewords_per_launch": B},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_encode(cfg, args.cpu_seconds)
+    print(json.dumps(res))
 
 
 def cpu_baseline(cfg, seconds):
@@ -145,6 +210,16 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    if args.config.startswith("enc"):
+        def enc_barrier():
+            if world > 1:
+                torch.distributed.barrier(device_ids=[dev_index]) if backend == "nccl" else torch.distributed.barrier()
+            torch.cuda.synchronize()
+        bench_encode(args, cfg, dev, dev_index, rank, world, enc_barrier)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     log2b = args.log2_batch if args.log2_batch is not None else cfg["log2_batch"]
     B = 1 << log2b                                   # per GPU (weak scaling: fixed work per GPU)

@@ -1,5 +1,5 @@
 /*
- * polar_amd.h -- C ABI of the MI355X-native batched polar SC / SCL decoder.
+ * polar_amd.h -- C ABI of the MI355X-native batched polar SC / SCL decoder (pcd_*) and encoder (pce_*).
  *
  * Drop-in boundary for the reference's decode path (ant-uni-bremen/polar-codes):
  *   PolarCode::Decoding::create()            src/polarcode/decoding/decoder.cpp:26-52
@@ -74,7 +74,9 @@ size_t pcd_out_bytes(const pcd_decoder* d);                    /* (K + 7) / 8   
  *   ok      : rows x uint8, the detector verdict = decode()'s return value          (nullable)
  *   metrics : rows x list_size float32 final path metrics, best first (SCL only)    (nullable)
  *   stream  : hipStream_t (NULL = default stream).  Device pointers: asynchronous on `stream`;
- *             host pointers: staged through device buffers and synchronised before returning. */
+ *             host pointers: staged through device buffers and synchronised before returning.
+ *             The "mixed" decoder synchronises the stream once per call (it reads the number of
+ *             codewords the SC pass failed on before launching the list pass). */
 int pcd_decode_f32(pcd_decoder* d, const float* llr, size_t rows, uint8_t* out, uint8_t* ok,
                    float* metrics, int mem, void* stream);
 /* Batched Decoder::decode_vector(const char*, void*): int8 LLRs widened to float exactly as
@@ -101,6 +103,39 @@ int pcd_scl_trace(pcd_decoder* d, const float* llr_row, float* trace, unsigned c
  * decoding ONE row on an otherwise idle GPU (ops[i]/stages[i] describe instruction i; *count = program length). */
 int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
                     unsigned cap, unsigned* count);
+
+/* =====================================================================================================
+ * Batched ENCODER: PolarCode::Encoding::ButterflyFipPacked behind pypolar.PolarEncoder
+ *   ButterflyFipPacked(blockLength, frozenBits)   src/polarcode/encoding/butterfly_fip_packed.cpp:27-43
+ *   Encoder::encode_vector(void* info, void* code) src/polarcode/encoding/encoder.cpp:79-91
+ *   ButterflyFipPacked::encode                    butterfly_fip_packed.cpp:45-59
+ *   pypolar.PolarEncoder                          python/bindings/encoder_python.cc:21-61
+ * One HIP kernel launch encodes `rows` information words; results are bit-identical to the reference.
+ * Status codes, memory-space tags and pcd_last_error() are shared with the decoder.
+ * ===================================================================================================== */
+typedef struct pce_encoder pce_encoder; /* opaque handle; not thread-safe */
+
+/* frozen[] strictly ascending.  A new encoder is systematic and carries the DUMMY detector
+ * (Encoder::Encoder encoder.cpp:17-26) -- unlike a new decoder, which carries CRC-8. */
+int pce_create(size_t block_length, const uint32_t* frozen, size_t n_frozen, int device, pce_encoder** out);
+void pce_destroy(pce_encoder* e);
+int pce_set_error_detection(pce_encoder* e, unsigned size, const char* type); /* same rules as pcd_set_error_detection */
+int pce_set_systematic(pce_encoder* e, int systematic);        /* Encoder::setSystematic */
+int pce_is_systematic(const pce_encoder* e);
+size_t pce_block_length(const pce_encoder* e);                 /* Encoder::blockLength()  */
+size_t pce_info_length(const pce_encoder* e);                  /* Encoder::infoLength()   */
+size_t pce_info_bytes(const pce_encoder* e);                   /* Encoder::informationByteSize(): (K + 7) / 8 */
+size_t pce_code_bytes(const pce_encoder* e);                   /* N / 8 */
+size_t pce_frozen_bits(const pce_encoder* e, uint32_t* out, size_t cap);
+int pce_error_detection_mode(const pce_encoder* e, char* buf, size_t cap);
+
+/* Batched Encoder::encode_vector.
+ *   info : rows x pce_info_bytes() packed information bytes, MSB first (mem = PCD_MEM_HOST | PCD_MEM_DEVICE).
+ *          NOT const: like the reference (Detector::generate on the caller's buffer), the checksum field of every
+ *          row is overwritten in place with the checksum of the bytes before it.
+ *   code : rows x pce_code_bytes() packed code words, code bit i = byte i/8, bit 7 - i%8 (4-byte aligned)
+ *   Device pointers: asynchronous on `stream`; host pointers: staged and synchronised before returning. */
+int pce_encode(pce_encoder* e, uint8_t* info, size_t rows, uint8_t* code, int mem, void* stream);
 
 const char* pcd_last_error(void);
 const char* pcd_version(void);

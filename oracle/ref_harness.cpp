@@ -18,6 +18,11 @@
 //   time  N K L ctor dsnr crcsize crctype ebn0_db rows threads seconds
 //         the reference's own CPU throughput: one decoder object per std::thread
 //         (simulator.cpp:95-101), prints one JSON line.
+//   enc   N K ctor dsnr crcsize crctype systematic count seed out.bin
+//         golden fixture of the ENCODER (ButterflyFipPacked::encode_vector): layout
+//         u32 hdr[10] = {0x31454650 'PFE1', N, K, systematic, nF, count, nb, crcsize, crcnr, 0}, u32 F[nF],
+//         count x { u8 info_in[nb] | u8 info_after[nb] (generate() writes the checksum in place) | u8 cw[N/8] }
+//   enctime N K ctor dsnr crcsize crctype threads seconds     the reference encoder's CPU throughput
 //   frozen N K ctor dsnr          prints the frozen set (one index per line)
 //   crc   size type hexbytes      prints Detector::calculate()/check() for KAT pinning
 //
@@ -250,6 +255,101 @@ static int cmd_time(int argc, char** argv)
     return 0;
 }
 
+static bool load_frozen(Code& c)
+{
+    if (!c.ctor.empty() && c.ctor[0] == '@') {
+        FILE* ff = fopen(c.ctor.c_str() + 1, "r");
+        if (!ff) { perror(c.ctor.c_str() + 1); return false; }
+        unsigned v;
+        while (fscanf(ff, "%u", &v) == 1) c.F.push_back(v);
+        fclose(ff);
+        c.K = c.N - (unsigned)c.F.size();
+    } else {
+        c.F = Construction::frozen_bits(c.N, c.K, c.dsnr, c.ctor);
+    }
+    return true;
+}
+
+static int cmd_enc(int argc, char** argv)
+{
+    if (argc < 12) { fprintf(stderr, "enc: bad args\n"); return 2; }
+    Code c;
+    c.N = atoi(argv[2]); c.K = atoi(argv[3]); c.L = 1; c.ctor = argv[4];
+    c.dsnr = atof(argv[5]); c.crcsize = atoi(argv[6]); c.crctype = argv[7];
+    const int systematic = atoi(argv[8]);
+    const unsigned count = atoi(argv[9]);
+    const uint64_t seed = strtoull(argv[10], nullptr, 10);
+    const char* out = argv[11];
+    if (!load_frozen(c)) return 1;
+    const unsigned nb = (c.K + 7) / 8;
+    Encoding::ButterflyFipPacked enc(c.N, c.F);
+    enc.setErrorDetection(ErrorDetection::create(c.crcsize, c.crctype));
+    enc.setSystematic(systematic != 0);
+    std::mt19937_64 g(seed);
+    FILE* f = fopen(out, "wb");
+    if (!f) { perror(out); return 1; }
+    const bool nr = c.crctype.find("nr") != std::string::npos;
+    uint32_t hdr[10] = { 0x31454650u, c.N, c.K, (uint32_t)systematic, (uint32_t)c.F.size(), count, nb,
+                         c.crcsize, (uint32_t)nr, 0 };
+    fwrite(hdr, 4, 10, f);
+    fwrite(c.F.data(), 4, c.F.size(), f);
+    for (unsigned r = 0; r < count; ++r) {
+        std::vector<uint8_t> info(std::max(nb, 8u) + 8, 0), cw(c.N / 8 + 64, 0);
+        for (unsigned i = 0; i < nb; ++i) info[i] = (uint8_t)(g() & 0xFF);
+        if (r == 0) std::fill(info.begin(), info.end(), 0);
+        if (r == 1) std::fill(info.begin(), info.begin() + nb, 0xFF);
+        if (c.K % 8) info[nb - 1] &= (uint8_t)(0xFF << (8 - c.K % 8));
+        fwrite(info.data(), 1, nb, f);
+        enc.encode_vector(info.data(), cw.data());
+        fwrite(info.data(), 1, nb, f);
+        fwrite(cw.data(), 1, c.N / 8, f);
+    }
+    fclose(f);
+    fprintf(stderr, "%s: N=%u K=%u sys=%d |F|=%zu rows=%u\n", out, c.N, c.K, systematic, c.F.size(), count);
+    return 0;
+}
+
+static int cmd_enctime(int argc, char** argv)
+{
+    if (argc < 10) { fprintf(stderr, "enctime: bad args\n"); return 2; }
+    Code c;
+    c.N = atoi(argv[2]); c.K = atoi(argv[3]); c.L = 1; c.ctor = argv[4];
+    c.dsnr = atof(argv[5]); c.crcsize = atoi(argv[6]); c.crctype = argv[7];
+    const unsigned threads = atoi(argv[8]);
+    const double seconds = atof(argv[9]);
+    if (!load_frozen(c)) return 1;
+    const unsigned nb = (c.K + 7) / 8;
+    std::atomic<uint64_t> total(0);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) {
+        pool.emplace_back([&, t]() {
+            Encoding::ButterflyFipPacked enc(c.N, c.F);
+            enc.setErrorDetection(ErrorDetection::create(c.crcsize, c.crctype));
+            std::mt19937_64 g(1000 + t);
+            const unsigned rows = 256;
+            std::vector<uint8_t> info((size_t)rows * (nb + 8), 0), cw(c.N / 8 + 64, 0);
+            for (auto& b : info) b = (uint8_t)(g() & 0xFF);
+            uint64_t n = 0;
+            for (;;) {
+                for (unsigned r = 0; r < rows; ++r) {
+                    enc.encode_vector(&info[(size_t)r * (nb + 8)], cw.data());
+                    ++n;
+                }
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (el >= seconds) break;
+            }
+            total += n;
+        });
+    }
+    for (auto& th : pool) th.join();
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("{\"kind\": \"reference\", \"op\": \"encode\", \"N\": %u, \"K\": %u, \"threads\": %u, "
+           "\"codewords\": %llu, \"seconds\": %.4f, \"cw_per_s\": %.2f}\n",
+           c.N, c.K, threads, (unsigned long long)total.load(), el, total.load() / el);
+    return 0;
+}
+
 static int cmd_frozen(int argc, char** argv)
 {
     if (argc < 6) return 2;
@@ -276,10 +376,12 @@ static int cmd_crc(int argc, char** argv)
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: ref_harness gen|time|frozen|crc ...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness gen|time|enc|enctime|frozen|crc ...\n"); return 2; }
     const std::string cmd = argv[1];
     if (cmd == "gen") return cmd_gen(argc, argv);
     if (cmd == "time") return cmd_time(argc, argv);
+    if (cmd == "enc") return cmd_enc(argc, argv);
+    if (cmd == "enctime") return cmd_enctime(argc, argv);
     if (cmd == "frozen") return cmd_frozen(argc, argv);
     if (cmd == "crc") return cmd_crc(argc, argv);
     fprintf(stderr, "unknown command %s\n", cmd.c_str());

@@ -1,4 +1,4 @@
-// C++ host-side mirror of the reference's decoder interface over the C ABI (include/polar_amd.h).
+// C++ host-side mirror of the reference's decoder and encoder interfaces over the C ABI (include/polar_amd.h).
 //
 // Mirrors PolarCode::Decoding::Decoder (reference: include/polarcode/decoding/decoder.h:40-180) and the factory
 // PolarCode::Decoding::create (decoder.cpp:26-52) for the float / mixed decoders: same method names, argument
@@ -97,4 +97,68 @@ inline Decoder* create(size_t blockLength, size_t listSize, const std::vector<un
 }
 
 }  // namespace Decoding
+
+namespace Encoding {
+
+// Mirrors PolarCode::Encoding::Encoder / ButterflyFipPacked (reference: include/polarcode/encoding/encoder.h,
+// src/polarcode/encoding/butterfly_fip_packed.cpp:27-59): same method names and argument meaning.
+class Encoder {
+public:
+    Encoder(size_t blockLength, const std::vector<unsigned>& frozenBits, int device = 0)
+    {
+        std::vector<uint32_t> f(frozenBits.begin(), frozenBits.end());
+        check(pce_create(blockLength, f.data(), f.size(), device, &h_));
+    }
+    ~Encoder() { pce_destroy(h_); }
+    Encoder(const Encoder&) = delete;
+    Encoder& operator=(const Encoder&) = delete;
+
+    // Encoder::encode_vector(void* pInfo, void* pCode) encoder.cpp:79-91; the checksum is written into pInfo
+    void encode_vector(void* pInfo, void* pCode)
+    {
+        check(pce_encode(h_, static_cast<uint8_t*>(pInfo), 1, static_cast<uint8_t*>(pCode), PCD_MEM_HOST, nullptr));
+    }
+    // batched form (no reference counterpart): rows x (K+7)/8 bytes -> rows x N/8 bytes
+    void encode_batch(uint8_t* info, size_t rows, uint8_t* code, bool device_pointers = false, void* hip_stream = nullptr)
+    {
+        check(pce_encode(h_, info, rows, code, device_pointers ? PCD_MEM_DEVICE : PCD_MEM_HOST, hip_stream));
+    }
+
+    size_t blockLength() const { return pce_block_length(h_); }
+    size_t infoLength() const { return pce_info_length(h_); }
+    void setSystematic(bool sys) { check(pce_set_systematic(h_, sys ? 1 : 0)); }
+    bool isSystematic() const { return pce_is_systematic(h_) != 0; }
+    std::vector<unsigned> frozenBits() const
+    {
+        std::vector<uint32_t> f(pce_frozen_bits(h_, nullptr, 0));
+        pce_frozen_bits(h_, f.data(), f.size());
+        return std::vector<unsigned>(f.begin(), f.end());
+    }
+    void setErrorDetection(unsigned size = 0, const std::string& type = "crc")
+    {
+        check(pce_set_error_detection(h_, size, type.c_str()));
+    }
+    std::string getErrorDetectionMode() const
+    {
+        char buf[64];
+        pce_error_detection_mode(h_, buf, sizeof buf);
+        return buf;
+    }
+    pce_encoder* handle() { return h_; }
+
+private:
+    static void check(int rc)
+    {
+        if (rc == PCD_OK) return;
+        const std::string msg = pcd_last_error();
+        switch (rc) {
+        case PCD_ERR_CRC_SIZE: throw std::logic_error(msg);
+        case PCD_ERR_INVALID_ARG: throw std::invalid_argument(msg);
+        default: throw std::runtime_error(msg);
+        }
+    }
+    pce_encoder* h_ = nullptr;
+};
+
+}  // namespace Encoding
 }  // namespace PolarAmd

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "internal.h"
 #include "kernels.h"
 #include "program.h"
 
@@ -43,6 +44,8 @@ inline size_t lds_blocks_per_cu(size_t bytes)
 }
 
 }  // namespace
+
+int pamd::set_error(int code, const std::string& msg) { return fail(code, msg); }
 
 struct pcd_decoder {
     unsigned N = 0, logN = 0, L = 1, K = 0, nb = 0;

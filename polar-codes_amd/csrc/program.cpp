@@ -261,6 +261,102 @@ std::vector<uint32_t> Detector::syndrome_table(unsigned K) const
     return tab;
 }
 
+void Detector::generate(uint8_t* p, int bytes) const
+{
+    switch (size) {
+    case 8: p[bytes - 1] = (uint8_t)crc_msb(p, bytes - 1, 8, 0x07); break;  // crc8.cpp:40-47
+    case 11: {                                                              // crc11nr.cpp:25-31
+        const uint32_t c = crc_msb(p, bytes - 2, 11, 0x621);
+        p[bytes - 2] = (uint8_t)(c >> 8);
+        p[bytes - 1] = (uint8_t)c;
+        break;
+    }
+    case 24: {  // crc24nrc.cpp:25-32
+        const uint32_t c = crc_msb(p, bytes - 3, 24, 0xB2B117);
+        p[bytes - 3] = (uint8_t)(c >> 16);
+        p[bytes - 2] = (uint8_t)(c >> 8);
+        p[bytes - 1] = (uint8_t)c;
+        break;
+    }
+    case 32: {  // crc32.cpp:33-41
+        const int w = (bytes >> 2) - 1;
+        const uint32_t c = crc32c_le(p, 4 * w);
+        std::memcpy(p + 4 * w, &c, 4);
+        break;
+    }
+    default: break;  // dummy.cpp: nothing
+    }
+}
+
+unsigned Detector::field_offset(int bytes) const
+{
+    if (size == 0) return (unsigned)bytes;
+    if (size == 32) return 4u * (unsigned)((bytes >> 2) - 1);
+    return (unsigned)bytes - check_bytes();
+}
+
+std::vector<uint32_t> Detector::generator_table(int bytes) const
+{
+    std::vector<uint32_t> tab;
+    if (size == 0) return tab;
+    const unsigned fo = field_offset(bytes), cb = check_bytes();
+    tab.assign(8u * fo, 0u);
+    std::vector<uint8_t> msg((size_t)bytes, 0);
+    for (unsigned t = 0; t < 8u * fo; ++t) {
+        std::fill(msg.begin(), msg.end(), 0);
+        msg[t >> 3] = (uint8_t)(0x80u >> (t & 7));
+        generate(msg.data(), bytes);
+        uint32_t v = 0;
+        for (unsigned i = 0; i < cb; ++i) v |= (uint32_t)msg[fo + i] << (8 * i);
+        tab[t] = v;
+    }
+    return tab;
+}
+
+// ---------------------------------------------------------------------------------------------
+// information-bit placement   PackedContainer::insertPackedInformationBits bitcontainer.cpp (packed LUT walk)
+// ---------------------------------------------------------------------------------------------
+std::vector<DepositWord> deposit_table(unsigned N, const std::vector<uint32_t>& frozen)
+{
+    const unsigned nwords = N >= 32 ? N / 32 : 1;
+    std::vector<DepositWord> tab(nwords);
+    std::vector<uint32_t> mask(nwords, 0u);
+    for (unsigned i = 0; i < N; ++i) mask[i >> 5] |= 1u << (i & 31);
+    for (uint32_t f : frozen) mask[f >> 5] &= ~(1u << (f & 31));
+    uint32_t base = 0;
+    for (unsigned w = 0; w < nwords; ++w) {
+        DepositWord& d = tab[w];
+        d.mask = mask[w];
+        d.base = base;
+        d.pad = 0;
+        base += (uint32_t)__builtin_popcount(mask[w]);
+        // Move masks of the log-step expand: step i moves the bits that must travel a distance with bit i set.
+        // mk marks the zeros to the right of each mask bit; its running parity says whether the count is odd.
+        uint32_t m = mask[w], mk = ~m << 1;
+        for (int i = 0; i < 5; ++i) {
+            uint32_t mp = mk ^ (mk << 1);
+            mp ^= mp << 2;
+            mp ^= mp << 4;
+            mp ^= mp << 8;
+            mp ^= mp << 16;
+            const uint32_t mv = mp & m;
+            d.mv[i] = mv;
+            m = (m ^ mv) | (mv >> (1u << i));
+            mk &= ~mp;
+        }
+    }
+    return tab;
+}
+
+uint32_t deposit_apply(const DepositWord& d, uint32_t x)
+{
+    for (int i = 4; i >= 0; --i) {
+        const uint32_t t = x << (1u << i);
+        x = (x & ~d.mv[i]) | (t & d.mv[i]);
+    }
+    return x & d.mask;
+}
+
 int make_detector(unsigned size, const std::string& type_in, Detector& det, std::string& err)
 {
     // ErrorDetection::create errordetector.cpp:27-88

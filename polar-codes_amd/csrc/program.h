@@ -83,7 +83,30 @@ struct Detector {
     bool check(const uint8_t* data, int bytes) const;
     // syndrome word for info bit t (MSB-first bit t of the packed output), K info bits
     std::vector<uint32_t> syndrome_table(unsigned K) const;
+
+    // ---- encoder side: Detector::generate(void*, int bytes) of the selected reference class -----------
+    // writes the checksum of the leading bytes into the checksum field of data[0..bytes)
+    void generate(uint8_t* data, int bytes) const;
+    // where generate() puts the field for an information word of `bytes` bytes, and how many leading
+    // bits it covers (CRC-32 works on whole little-endian words: crc32.cpp:33-41)
+    unsigned field_offset(int bytes) const;
+    unsigned payload_bits(int bytes) const { return 8u * field_offset(bytes); }
+    // generator word for payload bit t: the checksum field it produces on its own, field byte i in bits
+    // 8i..8i+7.  generate() == XOR of the words of the set payload bits (all detectors are linear, init 0).
+    std::vector<uint32_t> generator_table(int bytes) const;
 };
+
+// Tables that place information bits into a code word 32 positions at a time: for word w of the code
+// block (bit i of the block = bit i%32 of word i/32), `mask` marks the non-frozen positions, `base` is the
+// number of information bits in earlier words, and mv[0..4] are the move masks of the parallel-suffix
+// "expand" (bit deposit) of the next popcount(mask) information bits onto the mask.
+struct DepositWord {
+    uint32_t mask, base, mv[5], pad;
+};
+static_assert(sizeof(DepositWord) == 32, "DepositWord must be 32 bytes");
+std::vector<DepositWord> deposit_table(unsigned N, const std::vector<uint32_t>& frozen);
+// reference model of the device-side expand, for self-checks
+uint32_t deposit_apply(const DepositWord& d, uint32_t x);
 
 // returns 0 or a pcd_status-compatible negative code; fills det
 int make_detector(unsigned size, const std::string& type, Detector& det, std::string& err);

@@ -3,6 +3,8 @@
 Mirrors ``pypolar.PolarDecoder`` (reference: python/bindings/decoder_python.cc:17-75): same constructor
 arguments, method names, overload behaviour of ``decode_vector`` (float32 first, then int8) and the same
 exception types/messages, and adds ``decode_batch`` (B codewords per call, one HIP kernel launch).
+``pypolar.PolarEncoder`` (python/bindings/encoder_python.cc:21-61) is mirrored the same way, with
+``encode_batch`` beside ``encode_vector``.
 
 All decoding happens in hand-written HIP kernels behind the C ABI of ``include/polar_amd.h``
 (``polar-codes_amd/lib/libpolar_amd.so``).  There is no CPU fallback: without the library or without
@@ -16,7 +18,7 @@ import numpy as np
 from .construction import frozen_bits  # noqa: E402,F401  (pypolar.frozen_bits)
 from .detector import Detector          # noqa: E402,F401  (pypolar.Detector)
 
-__all__ = ["PolarDecoder", "Detector", "frozen_bits", "PolarAmdError", "library_path", "load_library", "C_SYMBOLS"]
+__all__ = ["PolarDecoder", "PolarEncoder", "Detector", "frozen_bits", "PolarAmdError", "library_path", "load_library", "C_SYMBOLS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpolar_amd.so")
@@ -30,6 +32,9 @@ C_SYMBOLS = [
     "pcd_block_length", "pcd_info_length", "pcd_list_size", "pcd_frozen_bits", "pcd_error_detection_mode",
     "pcd_out_bytes", "pcd_decode_f32", "pcd_decode_i8", "pcd_program_stats", "pcd_launch_info",
     "pcd_set_timing", "pcd_kernel_times", "pcd_scl_trace", "pcd_scl_profile", "pcd_last_error", "pcd_version",
+    "pce_create", "pce_destroy", "pce_set_error_detection", "pce_set_systematic", "pce_is_systematic",
+    "pce_block_length", "pce_info_length", "pce_info_bytes", "pce_code_bytes", "pce_frozen_bits",
+    "pce_error_detection_mode", "pce_encode",
 ]
 
 
@@ -89,6 +94,25 @@ def load_library():
     lib.pcd_scl_profile.argtypes = [vp, vp, vp, vp, vp, C.c_uint, C.POINTER(C.c_uint)]
     lib.pcd_last_error.restype = C.c_char_p
     lib.pcd_version.restype = C.c_char_p
+    lib.pce_create.restype = C.c_int
+    lib.pce_create.argtypes = [C.c_size_t, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.pce_destroy.restype = None
+    lib.pce_destroy.argtypes = [vp]
+    lib.pce_set_error_detection.restype = C.c_int
+    lib.pce_set_error_detection.argtypes = [vp, C.c_uint, C.c_char_p]
+    lib.pce_set_systematic.restype = C.c_int
+    lib.pce_set_systematic.argtypes = [vp, C.c_int]
+    lib.pce_is_systematic.restype = C.c_int
+    lib.pce_is_systematic.argtypes = [vp]
+    for f in ("pce_block_length", "pce_info_length", "pce_info_bytes", "pce_code_bytes"):
+        getattr(lib, f).restype = C.c_size_t
+        getattr(lib, f).argtypes = [vp]
+    lib.pce_frozen_bits.restype = C.c_size_t
+    lib.pce_frozen_bits.argtypes = [vp, vp, C.c_size_t]
+    lib.pce_error_detection_mode.restype = C.c_int
+    lib.pce_error_detection_mode.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.pce_encode.restype = C.c_int
+    lib.pce_encode.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
     _lib = lib
     return lib
 
@@ -132,7 +156,10 @@ class PolarDecoder:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            self._lib.pcd_destroy(h)
+            try:
+                self._lib.pcd_destroy(h)
+            except Exception:  # interpreter shutdown: the library may already be gone
+                pass
             self._h = None
 
     # ---- accessors (decoder_python.cc:27-33) ---------------------------------------------------
@@ -297,3 +324,121 @@ class PolarDecoder:
         if rc:
             _raise(rc)
         return ms[: n.value].copy()
+
+
+class PolarEncoder:
+    """``pypolar.PolarEncoder(blockLength, frozenBitPositions)`` (encoder_python.cc:21-26).
+
+    A new encoder is systematic and carries the dummy detector (Encoder::Encoder, encoder.cpp:17-26)."""
+
+    def __init__(self, blockLength, frozenBitPositions, device=0):
+        lib = load_library()
+        frozen = np.ascontiguousarray(np.asarray(frozenBitPositions, dtype=np.int64).astype(np.uint32))
+        self._h = C.c_void_p()
+        rc = lib.pce_create(int(blockLength), frozen.ctypes.data_as(C.c_void_p), frozen.size, int(device),
+                            C.byref(self._h))
+        if rc:
+            self._h = None
+            _raise(rc)
+        self._lib = lib
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.pce_destroy(h)
+            except Exception:  # interpreter shutdown: the library may already be gone
+                pass
+            self._h = None
+
+    # ---- accessors (encoder_python.cc:27-40) -------------------------------------------------------
+    def blockLength(self):
+        return int(self._lib.pce_block_length(self._h))
+
+    def infoLength(self):
+        return int(self._lib.pce_info_length(self._h))
+
+    def setSystematic(self, sys):
+        self._lib.pce_set_systematic(self._h, int(bool(sys)))
+
+    def isSystematic(self):
+        return bool(self._lib.pce_is_systematic(self._h))
+
+    def frozenBits(self):
+        n = self._lib.pce_frozen_bits(self._h, None, 0)
+        out = np.zeros(n, np.uint32)
+        self._lib.pce_frozen_bits(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return [int(x) for x in out]
+
+    def getErrorDetectionMode(self):
+        buf = C.create_string_buffer(64)
+        self._lib.pce_error_detection_mode(self._h, buf, 64)
+        return buf.value.decode()
+
+    def setErrorDetection(self, size=0, type="crc"):
+        rc = self._lib.pce_set_error_detection(self._h, int(size), str(type).encode())
+        if rc:
+            _raise(rc)
+
+    # ---- encode_vector (encoder_python.cc:41-60) ---------------------------------------------------
+    def encode_vector(self, array):
+        """One information word: uint8[infoLength // 8] -> packed code word uint8[blockLength // 8].
+
+        Like the reference, a C-contiguous uint8 ndarray is used in place, so the detector's checksum is
+        written into the caller's array (Detector::generate works on the buffer it is handed); any other input
+        is converted first (pybind11 ``forcecast``) and left untouched."""
+        a = np.asarray(array)
+        if a.ndim != 1:
+            raise RuntimeError("Only ONE-dimensional vectors allowed!")
+        if a.size != self.infoLength() // 8:
+            raise RuntimeError("Input vector size != infoSize // 8!")
+        if not (a.dtype == np.uint8 and a.flags.c_contiguous and a.flags.writeable):
+            a = np.ascontiguousarray(a, dtype=np.uint8).copy()
+        nb = int(self._lib.pce_info_bytes(self._h))
+        if a.size == nb:
+            info = a.reshape(1, nb)
+        else:  # K % 8 != 0: the library reads (K + 7) // 8 bytes, the binding only promises K // 8 (SURVEY Q4)
+            info = np.zeros((1, nb), np.uint8)
+            info[0, : a.size] = a
+        return self._encode_host(info)[0]
+
+    # ---- batched entry point (no reference counterpart) --------------------------------------------
+    def encode_batch(self, info, out=None, stream=None):
+        """Encode B information words: ``info`` uint8 ``[B, ceil(K/8)]`` (numpy: host, synchronous; torch CUDA
+        tensor: device pointers, asynchronous).  The checksum fields of ``info`` are filled in place when it
+        is a contiguous uint8 array/tensor.  Returns the packed code words ``[B, N/8]``."""
+        nb = int(self._lib.pce_info_bytes(self._h))
+        if _is_torch(info):
+            import torch
+
+            if not info.is_cuda:
+                return torch.from_numpy(self.encode_batch(info.numpy()))
+            if info.dtype != torch.uint8 or not info.is_contiguous():
+                info = info.to(torch.uint8).contiguous()
+            if info.dim() != 2 or info.shape[1] != nb:
+                raise ValueError("info must have shape [B, ceil(infoLength / 8)]")
+            B = info.shape[0]
+            if out is None:
+                out = torch.empty((B, self.blockLength() // 8), dtype=torch.uint8, device=info.device)
+            if stream is None:
+                stream = torch.cuda.current_stream(info.device).cuda_stream
+            rc = self._lib.pce_encode(self._h, C.c_void_p(info.data_ptr()), B, C.c_void_p(out.data_ptr()),
+                                      PCD_MEM_DEVICE, C.c_void_p(stream))
+            if rc:
+                _raise(rc)
+            return out
+        a = np.asarray(info)
+        if not (a.dtype == np.uint8 and a.flags.c_contiguous and a.flags.writeable):
+            a = np.ascontiguousarray(a, dtype=np.uint8).copy()
+        if a.ndim != 2 or a.shape[1] != nb:
+            raise ValueError("info must have shape [B, ceil(infoLength / 8)]")
+        return self._encode_host(a)
+
+    def _encode_host(self, info):
+        B = info.shape[0]
+        code = np.zeros((B, self.blockLength() // 8), np.uint8)
+        rc = self._lib.pce_encode(self._h, info.ctypes.data_as(C.c_void_p), B, code.ctypes.data_as(C.c_void_p),
+                                  PCD_MEM_HOST, None)
+        if rc:
+            _raise(rc)
+        return code

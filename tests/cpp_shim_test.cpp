@@ -33,6 +33,17 @@ int main(int argc, char** argv)
         threw = true;
     }
     if (!threw) return 6;
+    PolarAmd::Encoding::Encoder enc(8, frozen);
+    if (enc.blockLength() != 8 || enc.infoLength() != 4 || !enc.isSystematic()) return 11;
+    if (enc.getErrorDetectionMode() != "DUMMY-0" || enc.frozenBits() != frozen) return 12;  // encoder.cpp:18
+    if (gpu) {
+        // systematic code word of info bits 1111 on positions {3,5,6,7}: x = u G with u_frozen = 0 is 0x17 -> after
+        // the systematic re-encode the information positions carry the information bits
+        unsigned char info[8] = { 0xF0 }, cw[8] = { 0 };
+        enc.encode_vector(info, cw);
+        const unsigned char infopos = 0x17;  // bits 3,5,6,7 (MSB first)
+        if ((cw[0] & infopos) != infopos) return 13;
+    }
     if (gpu) {
         const float llr[8] = { -5, -6, -4, 1, -4, -5, -7, 2 };
         unsigned char out[8] = { 0 };

@@ -69,7 +69,53 @@ def load(path):
 
 
 def all_files(pattern="*.bin"):
-    return sorted(glob.glob(os.path.join(GOLDEN_DIR, pattern)))
+    """decoder fixtures ('PFX1' records); the encoder fixture enc.bin has its own loader"""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, pattern)) if os.path.basename(f) != "enc.bin")
+
+
+ENC_MAGIC = 0x31454650
+
+
+@dataclass
+class EncFixture:
+    name: str
+    N: int
+    K: int
+    systematic: bool
+    frozen: np.ndarray      # uint32[nF]
+    crc_size: int
+    crc_nr: bool
+    info_in: np.ndarray     # uint8[count, nb]  what the caller handed to encode_vector
+    info_after: np.ndarray  # uint8[count, nb]  the same buffer afterwards (checksum written in place)
+    cw: np.ndarray          # uint8[count, N/8] packed code word, bit i = byte i/8, bit 7 - i%8
+
+    @property
+    def count(self):
+        return self.cw.shape[0]
+
+    @property
+    def crc_type(self):
+        return "crcnr" if self.crc_nr else "crc"
+
+
+def load_enc(path=None):
+    path = path or os.path.join(GOLDEN_DIR, "enc.bin")
+    raw = np.fromfile(path, dtype=np.uint8)
+    pos, idx, out = 0, 0, []
+    while pos < raw.size:
+        hdr = raw[pos:pos + 40].view(np.uint32)
+        assert hdr[0] == ENC_MAGIC, f"bad magic in {path} @ {pos}"
+        _, N, K, sysm, nF, count, nb, crcsize, crcnr, _ = (int(x) for x in hdr)
+        pos += 40
+        frozen = raw[pos:pos + 4 * nF].view(np.uint32).copy()
+        pos += 4 * nF
+        rec = 2 * nb + N // 8
+        body = raw[pos:pos + rec * count].reshape(count, rec)
+        pos += rec * count
+        out.append(EncFixture(f"enc.bin#{idx}", N, K, bool(sysm), frozen, crcsize, bool(crcnr),
+                              body[:, :nb].copy(), body[:, nb:2 * nb].copy(), body[:, 2 * nb:].copy()))
+        idx += 1
+    return out
 
 
 def load_named(name):

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol(built_library):
     import pypolar_amd
     hdr = open(os.path.join(ROOT, "include", "polar_amd.h")).read()
-    declared = sorted(set(re.findall(r"\b(pcd_[a-z0-9_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(pc[de]_[a-z0-9_]+)\s*\(", hdr)))
     assert declared == sorted(pypolar_amd.C_SYMBOLS)
     for sym in declared:
         assert hasattr(built_library, sym), sym
@@ -225,3 +225,34 @@ def test_detector_class_known_answers():
         D(7, "crc")
     with pytest.raises(RuntimeError, match="Unknown Error detector requested!"):
         D(8, "md5")
+
+
+# ---- encoder host side: pypolar.PolarEncoder surface (encoder_python.cc:21-61) ---------------------------------
+def test_encoder_surface_without_gpu(built_library):
+    import pypolar_amd
+    F = _frozen("cfg3_n1024_k512_l8_crc24_awgn.bin")
+    e = pypolar_amd.PolarEncoder(1024, F)
+    assert (e.blockLength(), e.infoLength(), e.isSystematic()) == (1024, 512, True)
+    assert e.getErrorDetectionMode() == "DUMMY-0"          # Encoder::Encoder encoder.cpp:18
+    assert e.frozenBits() == [int(x) for x in F]
+    e.setErrorDetection(24, "crcnr")
+    assert e.getErrorDetectionMode() == "CRCNR-24"
+    e.setSystematic(False)
+    assert not e.isSystematic()
+    with pytest.raises(RuntimeError, match="Only ONE-dimensional vectors allowed!"):
+        e.encode_vector(np.zeros((2, 64), np.uint8))
+    with pytest.raises(RuntimeError, match="Input vector size != infoSize // 8!"):
+        e.encode_vector(np.zeros(63, np.uint8))
+    with pytest.raises(RuntimeError, match="CRC INVALID SIZE!"):
+        e.setErrorDetection(7, "crc")
+    with pytest.raises(RuntimeError, match="Unknown Error detector requested!"):
+        e.setErrorDetection(8, "parity")
+    with pytest.raises(ValueError):
+        pypolar_amd.PolarEncoder(1000, F)
+    with pytest.raises(ValueError):
+        pypolar_amd.PolarEncoder(1024, [5, 3])
+    import torch
+    if not torch.cuda.is_available():  # no CPU fallback
+        with pytest.raises(pypolar_amd.PolarAmdError):
+            e.encode_vector(np.zeros(64, np.uint8))
+

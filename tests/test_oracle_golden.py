@@ -125,3 +125,17 @@ def test_roundtrip_like_qa_pypolar(N, L):
         llr = (1.0 - 2.0 * bits + rng.uniform(-0.2, 0.2, N)).astype(np.float32).reshape(1, N)
         out, ok, _ = ob.decode_batch(N, L, frozen, 8, llr)
         assert ok[0] == 1 and np.array_equal(out[0], info_crc)
+
+
+# ---- encoder: oracle po_encode vs the reference's ButterflyFipPacked::encode_vector (tests/golden/enc.bin) ----
+def test_oracle_encoder_matches_reference_vectors():
+    fxs = gio.load_enc()
+    assert len(fxs) > 60
+    rows = 0
+    for fx in fxs:
+        for r in range(fx.count):
+            info, cw = ob.encode(fx.N, fx.frozen, fx.crc_size, fx.info_in[r], fx.systematic)
+            assert np.array_equal(info, fx.info_after[r]), (fx.name, r)
+            assert np.array_equal(cw, fx.cw[r]), (fx.name, r, fx.N, fx.K, fx.systematic)
+            rows += 1
+    assert rows > 400
