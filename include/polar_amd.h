@@ -133,7 +133,7 @@ int pce_error_detection_mode(const pce_encoder* e, char* buf, size_t cap);
  *   info : rows x pce_info_bytes() packed information bytes, MSB first (mem = PCD_MEM_HOST | PCD_MEM_DEVICE).
  *          NOT const: like the reference (Detector::generate on the caller's buffer), the checksum field of every
  *          row is overwritten in place with the checksum of the bytes before it.
- *   code : rows x pce_code_bytes() packed code words, code bit i = byte i/8, bit 7 - i%8 (4-byte aligned)
+ *   code : rows x pce_code_bytes() packed code words, code bit i = byte i/8, bit 7 - i%8 (16-byte aligned)
  *   Device pointers: asynchronous on `stream`; host pointers: staged and synchronised before returning. */
 int pce_encode(pce_encoder* e, uint8_t* info, size_t rows, uint8_t* code, int mem, void* stream);
 

@@ -120,10 +120,9 @@ int encode_device(pce_encoder* e, uint8_t* info, size_t rows, uint8_t* code, hip
     P.systematic = e->systematic ? 1u : 0u;
     P.iw_words = (e->nb + 3) / 4 + 2;
     P.info_aligned = ((reinterpret_cast<uintptr_t>(info) & 3u) == 0 && (e->nb & 3u) == 0) ? 1u : 0u;
-    if ((reinterpret_cast<uintptr_t>(code) & 3u) != 0 && e->N >= 32)
-        return set_error(PCD_ERR_INVALID_ARG, "code buffer must be 4-byte aligned");
-    const unsigned nwords = e->N >= 32 ? e->N / 32 : 1;
-    const unsigned G = nwords >= 64 ? 1 : 64 / nwords, wpb = 4;
+    if ((reinterpret_cast<uintptr_t>(code) & 15u) != 0)
+        return set_error(PCD_ERR_INVALID_ARG, "code buffer must be 16-byte aligned");
+    const unsigned G = pamd::encode_codewords_per_wave(e->N), wpb = 4;
     const size_t groups = (rows + G - 1) / G;
     const size_t want = (groups + wpb - 1) / wpb;
     const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)e->num_cu * 16);

@@ -23,5 +23,7 @@ struct EncodeParams {
 };
 
 hipError_t launch_encode(const EncodeParams& P, unsigned grid, unsigned waves_per_block, hipStream_t st);
+// code words one wave encodes at a time (launch geometry / LDS sizing)
+unsigned encode_codewords_per_wave(unsigned N);
 
 }  // namespace pamd

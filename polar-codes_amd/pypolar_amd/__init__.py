@@ -21,7 +21,8 @@ from .detector import Detector          # noqa: E402,F401  (pypolar.Detector)
 __all__ = ["PolarDecoder", "PolarEncoder", "Detector", "frozen_bits", "PolarAmdError", "library_path", "load_library", "C_SYMBOLS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpolar_amd.so")
+# PYPOLAR_AMD_LIB: load another build of the same library (kernel experiments); never a fallback
+_LIB_PATH = os.environ.get("PYPOLAR_AMD_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libpolar_amd.so")
 _lib = None
 
 PCD_MEM_HOST, PCD_MEM_DEVICE = 0, 1
