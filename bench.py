@@ -34,10 +34,25 @@ CONFIGS = {
                  name="N=1024 K=512 SC, batch=2^20"),
     "cfg3": dict(N=1024, K=512, L=8, dsnr=0.0, crc=24, crc_type="crcnr", ebn0=2.0, log2_batch=20,
                  name="N=1024 K=512 SCL L=8 + CRC-24C, batch=2^20"),
+    # the 8-GPU configurations of SURVEY 8(d), runnable per GPU (weak scaling: the batch below is per GPU)
+    "cfg4": dict(N=1024, K=176, L=8, dsnr=0.0, crc=11, crc_type="crcnr", ebn0=1.0, log2_batch=19, ctor="5G",
+                 name="5G-table N=1024 K=176 SCL L=8 + CRC-11, batch=2^19 per GPU (2^22 over 8)"),
+    "cfg5": dict(N=4096, K=2048, L=32, dsnr=0.0, crc=32, crc_type="crc", ebn0=1.5, log2_batch=15,
+                 name="N=4096 K=2048 SCL L=32 + CRC-32C, batch=2^15 per GPU (2^18 over 8)"),
     # secondary workload: the encoder side of cfg3
     "enc3": dict(N=1024, K=512, L=0, dsnr=0.0, crc=24, crc_type="crcnr", ebn0=2.0, log2_batch=22,
                  name="N=1024 K=512 + CRC-24C, batch=2^22"),
 }
+
+
+def config_frozen_set(cfg):
+    """BB construction, or (cfg 4) the 5G-table set: the 3GPP reliability table is not shipped, the set is read as
+    data from the golden fixture the reference produced for this configuration"""
+    if cfg.get("ctor") == "5G":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import golden_io as gio
+        return gio.load_named("cfg4_n1024_k176_l8_crc11_awgn.bin").frozen
+    return frozen_bits(cfg["N"], cfg["K"], cfg["dsnr"], "BB")
 
 
 def make_batch(cfg, frozen, B, device, seed):
@@ -157,7 +172,7 @@ def cpu_baseline(cfg, seconds):
     rows = 4096
     if os.path.exists(harness):
         try:
-            out = subprocess.run([harness, "time", str(cfg["N"]), str(cfg["K"]), str(cfg["L"]), "BB", str(cfg["dsnr"]),
+            out = subprocess.run([harness, "time", str(cfg["N"]), str(cfg["K"]), str(cfg["L"]), cfg.get("ctor", "BB"), str(cfg["dsnr"]),
                                   str(cfg["crc"]), cfg["crc_type"], str(cfg["ebn0"]), str(rows), str(cores), str(seconds)],
                                  capture_output=True, text=True, timeout=seconds * 6 + 120, check=True)
             r = json.loads(out.stdout.strip().splitlines()[-1])
@@ -168,7 +183,7 @@ def cpu_baseline(cfg, seconds):
             print(f"[bench] reference harness unavailable ({e}); timing the oracle port", file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
-    frozen = frozen_bits(cfg["N"], cfg["K"], cfg["dsnr"])
+    frozen = config_frozen_set(cfg)
     rng = np.random.default_rng(0)
     llr = rng.normal(1.0, 0.8, (256, cfg["N"])).astype(np.float32)
     t0, n = time.time(), 0
@@ -225,7 +240,7 @@ def main():
     B = 1 << log2b                                   # per GPU (weak scaling: fixed work per GPU)
     N, K, L = cfg["N"], cfg["K"], cfg["L"]
     nb = (K + 7) // 8
-    frozen = frozen_bits(N, K, cfg["dsnr"], "BB")
+    frozen = config_frozen_set(cfg)
     dec = pypolar_amd.PolarDecoder(N, L, frozen, "float", device=dev_index)
     dec.setErrorDetection(cfg["crc"], cfg["crc_type"])
 
@@ -293,7 +308,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"] + (" per GPU" if world > 1 else ""), "block_length": N,
                        "info_bits": K, "list_size": L, "detector": f"{cfg['crc_type']}-{cfg['crc']}",
-                       "ebn0_db": cfg["ebn0"], "codewords_per_gpu": B, "frozen_set": f"BB dSNR {cfg['dsnr']} dB",
+                       "ebn0_db": cfg["ebn0"], "codewords_per_gpu": B,
+                       "frozen_set": "5G reliability table" if cfg.get("ctor") == "5G" else f"BB dSNR {cfg['dsnr']} dB",
                        "parallelism": f"rows sharded over {world} GPU(s), all-gather of decoded bytes" if world > 1
                                       else "single GPU"},
             "info_gbit_per_s": cw_s * K / 1e9, "payload_gbit_per_s": cw_s * payload_bits / 1e9,

@@ -64,6 +64,7 @@ struct pcd_decoder {
     int lpl = 3;
     unsigned lmax = 8, path_stride = 0, wppL = 0, wppR = 0, scl_wave_words = 0, scl_wpb = 1;
     unsigned s0 = 0, arena_path_stride = 0, arena_wave_words = 0;
+    unsigned sb = 0, arena_bits_off = 0, gbit_left_words = 0, gbit_path_words = 0;
     bool virtual_top = false;
     float* d_arena = nullptr;
     size_t d_arena_cap = 0;
@@ -144,32 +145,51 @@ void compute_geometry(pcd_decoder* d)
         const unsigned LP = 64 / lmax;
         const unsigned pad = LP < 32 ? (LP < 4 ? 4 : LP) : 0;  // bank spread; multiple of 4 floats (16-byte LDS vectors)
         auto woff = [](unsigned t) { return t <= 5 ? t : ((1u << (t - 5)) + 4u); };
-        const unsigned topw = d->logN >= 6 ? (1u << (d->logN - 6)) : 1u;  // words of a stage logN-1 block
-        d->wppL = (woff(d->logN) + bitw) | 1u;                             // left children + the root output
-        d->wppR = (woff(d->logN ? d->logN - 1 : 0) + topw) | 1u;           // right children: stages < logN
-        // LLR stages [s0, logN) go to a global arena; pick s0 for the best occupancy (ties: the most LDS)
-        auto lds_words = [&](unsigned s0) {
-            // path LLR buffers | left / right bit areas (rounded to 16 B) | 64 words of scratch
-            return ((lmax * ((1u << s0) + pad) + lmax * (d->wppL + d->wppR) + 3) & ~3u) + 64u;
+        // Bit blocks: stage t of a path at word woff(t) of its area (left children + root | right children).
+        // Stages >= sb go to the global arena (sb = logN + 1: none); LLR stages [s0, logN) likewise.  Pick (sb, s0) for
+        // the most resident waves (up to 16 pay off: measured at cfg 3, s0 = 9 / 8 / 7 / 6 -> 7.5 / 6.3 / 11.1 / 10.8 M
+        // cw/s), then the most LLR stages in LDS, then the most bit stages in LDS.
+        auto words_L = [&](unsigned sb) { return (sb > d->logN ? woff(d->logN) + bitw : woff(sb)) | 1u; };
+        auto words_R = [&](unsigned sb) { return woff(std::min(sb, d->logN)) | 1u; };
+        auto lds_words = [&](unsigned s0, unsigned sb) {
+            // path LLR buffers | left / right bit areas (rounded to 16 B) | selection scratch: 64 candidate keys at
+            // 8 lanes per path, else 64 * (8 / LP) keys + a 32-entry rank table
+            const unsigned scratch = LP == 8 ? 64u : 64u * std::max(1u, 8u / LP) + 32u;
+            return ((lmax * ((1u << s0) + pad) + lmax * (words_L(sb) + words_R(sb)) + 3) & ~3u) + scratch;
         };
-        unsigned best_s0 = d->logN, best_waves = 0;
+        unsigned best_s0 = d->logN, best_sb = d->logN + 1, best_waves = 0;
         const unsigned lo = d->logN < 6 ? d->logN : 6;
-        for (unsigned s0 = d->logN; s0 + 1 > lo; --s0) {
-            const size_t bytes = (size_t)lds_words(s0) * 4;
-            // up to 16 waves per CU pay off (measured at cfg 3: s0 = 9 / 8 / 7 / 6 -> 7.5 / 6.3 / 11.1 / 10.8 M cw/s)
-            const unsigned waves = bytes > kMaxLds ? 0u : (unsigned)std::min<size_t>(16, lds_blocks_per_cu(bytes));
-            if (waves > best_waves) {
-                best_waves = waves;
-                best_s0 = s0;
+        const unsigned sb_lo = 7;  // every op specialised for LDS works on stages <= 6
+        std::vector<unsigned> sbs = { d->logN + 1 };
+        for (unsigned sb = d->logN; sb >= sb_lo; --sb) sbs.push_back(sb);
+        for (unsigned sb : sbs) {
+            for (unsigned s0 = d->logN; s0 + 1 > lo; --s0) {
+                const size_t bytes = (size_t)lds_words(s0, sb) * 4;
+                const unsigned waves = bytes > kMaxLds ? 0u : (unsigned)std::min<size_t>(16, lds_blocks_per_cu(bytes));
+                // bit blocks in the arena turn their accesses into flat_* instructions (measured -4 % at cfg 3):
+                // only taken when they buy resident waves
+                if (waves > best_waves || (waves == best_waves && waves > 0 && s0 > best_s0 && sb == best_sb)) {
+                    best_waves = waves;
+                    best_s0 = s0;
+                    best_sb = sb;
+                }
+                if (s0 == 0) break;
             }
-            if (s0 == 0) break;
         }
         if (const char* dbg = std::getenv("PCD_S0")) best_s0 = (unsigned)std::atoi(dbg);  // experiments
+        if (const char* dbg = std::getenv("PCD_SB")) best_sb = std::max(sb_lo, (unsigned)std::atoi(dbg));
+        if (best_sb > d->logN) best_sb = d->logN + 1;
         d->s0 = best_s0;
+        d->sb = best_sb;
+        d->wppL = words_L(d->sb);
+        d->wppR = words_R(d->sb);
         d->path_stride = (1u << d->s0) + pad;
-        d->scl_wave_words = lds_words(d->s0);
+        d->scl_wave_words = lds_words(d->s0, d->sb);
         d->arena_path_stride = d->s0 < d->logN ? ((1u << d->logN) - (1u << d->s0)) : 0;
-        d->arena_wave_words = lmax * d->arena_path_stride;
+        d->arena_bits_off = lmax * d->arena_path_stride;
+        d->gbit_left_words = d->sb <= d->logN ? woff(d->logN) + bitw - woff(d->sb) : 0;
+        d->gbit_path_words = d->gbit_left_words + (d->sb < d->logN ? woff(d->logN) - woff(d->sb) : 0);
+        d->arena_wave_words = (d->arena_bits_off + lmax * d->gbit_path_words + 3u) & ~3u;
         if (!std::getenv("PCD_NO_SPECIALIZE")) specialize_scl(d);
         d->scl_wpb = 1;
     }
@@ -325,13 +345,17 @@ int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     P.s0 = d->s0;
     P.arena_path_stride = d->arena_path_stride;
     P.arena_wave_words = d->arena_wave_words;
+    P.arena_bits_off = d->arena_bits_off;
+    P.sb = d->sb;
+    P.gbit_left_words = d->gbit_left_words;
+    P.gbit_path_words = d->gbit_path_words;
     const size_t lds = (size_t)d->scl_wpb * d->scl_wave_words * 4;
     if (d->scl_blocks_per_cu == 0) {  // resident workgroups per CU (LDS and VGPR limited)
         int occ = 0;
         HIP_TRY(pamd::launch_scl(P, d->lpl, i8, 1, d->scl_wpb, lds, st, &occ));
         d->scl_blocks_per_cu = std::max(1, std::min(occ, (int)lds_blocks_per_cu(lds)));
         if (const char* e = std::getenv("PCD_BLOCKS_PER_CU")) d->scl_blocks_per_cu = std::max(1, std::atoi(e));  // experiments
-        if (std::getenv("PCD_VERBOSE")) std::fprintf(stderr, "[pcd] scl: s0=%u lds=%zu B occupancy=%d blocks/CU\n", d->s0, lds, occ);
+        if (std::getenv("PCD_VERBOSE")) std::fprintf(stderr, "[pcd] scl: s0=%u sb=%u lds=%zu B occupancy=%d -> %d blocks/CU\n", d->s0, d->sb, lds, occ, d->scl_blocks_per_cu);
     }
     const unsigned need = (unsigned)((P.rows + d->scl_wpb - 1) / d->scl_wpb);
     const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->scl_blocks_per_cu)));

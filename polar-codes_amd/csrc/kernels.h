@@ -23,7 +23,10 @@ struct DecodeParams {
     uint32_t path_stride;    // SCL: floats per path LLR buffer (N + bank padding)
     uint32_t wppL, wppR;     // SCL: bit words per path in the left-child / right-child output areas
     float* arena;            // SCL: global scratch for LLR stages >= s0 (one slice per resident wave)
-    uint32_t arena_wave_words, arena_path_stride;
+    uint32_t arena_wave_words, arena_path_stride;  // words of one wave's slice (LLR stages, then the high-stage bits)
+    uint32_t arena_bits_off;  // SCL: word offset of the bit blocks inside the wave's slice
+    uint32_t sb;              // SCL: first stage whose bit blocks live in the arena (logN + 1 = none)
+    uint32_t gbit_left_words, gbit_path_words;  // SCL: arena bit words per path (left/root outputs; both areas)
     uint32_t s0;             // SCL: first LLR stage kept in the arena (logN = none)
     uint32_t sc_virtual_top; // SC: stage logN-1 is recomputed from the channel row instead of being stored in LDS
     uint32_t prog_root_g0r;  // SC: the root is a ZeroR node (its right child input is a + b)

@@ -671,7 +671,7 @@ struct Wr {
     }
 };
 
-template <int LPL, bool S64>
+template <int LPL, bool S64, bool HB>
 struct SclCtx {
     using SlotT = std::conditional_t<S64, uint64_t, uint32_t>;
     static constexpr int LP = 1 << LPL;     // lanes per path
@@ -684,9 +684,14 @@ struct SclCtx {
     uint32_t* bitsR;
     uint32_t path_stride, wppL, wppR;
     uint32_t ablate;
-    uint32_t* scratch;  // 64 LDS words of per-wave scratch (candidate keys)
+    uint32_t* scratch;  // per-wave LDS scratch (candidate keys + rank table): 64 words at LP = 8, 64 * 8 / LP + 32 below
     float* arena;  // this wave's global scratch (stages >= s0)
     uint32_t arena_path_stride, s0, logN;
+    // bit blocks of stages >= sb live in the global arena too (they are touched by a handful of ops per codeword
+    // but would otherwise take most of the LDS at large N x L): per path gwl words of left-child / root outputs
+    // followed by the right-child outputs, stage t at woff(t) - woff(sb)
+    uint32_t* gbits;
+    uint32_t sb, wsb, gwl, gwpp;
     const void* chan;
     int lane, p, j, base;
     uint32_t P;      // live paths (wave uniform)
@@ -699,6 +704,16 @@ struct SclCtx {
     __device__ __forceinline__ uint32_t* area(uint32_t side, uint32_t q) const
     {
         return side ? bitsR + __umul24(q, wppR) : bitsL + __umul24(q, wppL);
+    }
+    // stage-t bit block of path buffer q (side 0: left children and the root, 1: right children), wherever it lives
+    __device__ __forceinline__ uint32_t* bits(uint32_t side, uint32_t q, uint32_t t) const
+    {
+        // (HB = false: everything is in LDS and the compiler keeps ds_* instructions; with HB the pointer is
+        // generic and these accesses become flat_* -- only worth it where the LDS saved buys resident waves)
+        if constexpr (HB) {
+            if (t >= sb) return gbits + __umul24(q, gwpp) + (side ? gwl : 0u) + (woff(t) - wsb);
+        }
+        return area(side, q) + woff(t);
     }
     __device__ __forceinline__ float* arena_stage(uint32_t q, uint32_t t) const
     {
@@ -1156,6 +1171,70 @@ __device__ __forceinline__ void select_ranked8(const CTX& c, float val, uint32_t
     nidx = ((srcl >> 3) << CS) + (srcl & 7u);
 }
 
+// ---- candidate selection by rank for fewer than 8 lanes per path (list sizes above 8) ------------------------
+// Same idea as select_ranked8 with CPL = CPP / LP candidates per lane: every candidate key goes to the LDS scratch
+// (slot = lane * CPL + register), every lane counts how many keys beat each of its own, the winners write their
+// slot id into a rank table, and new path r reads entry r.  Returns false when two winners share a rank (an exact
+// tie between candidates that matter): the caller then runs the literal emulation.
+template <typename CTX, int LPL, int CPP>
+__device__ __forceinline__ bool select_ranked(const CTX& c, const float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
+                                              uint32_t newP, float& nval, uint32_t& nidx)
+{
+    constexpr int LP = CTX::LP;
+    constexpr int CPL = (CPP >> LPL) ? (CPP >> LPL) : 1;
+    constexpr uint32_t SLOTS = 64u * CPL;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 __attribute__((address_space(3))) lds_u32x4;
+    typedef uint32_t __attribute__((address_space(3))) lds_u32;
+    lds_u32* keys = (lds_u32*)(uintptr_t)c.scratch;
+    lds_u32* rk = keys + SLOTS;
+    uint32_t key[CPL];
+    bool valid[CPL];
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) {
+        const uint32_t q = (uint32_t)c.j * CPL + r;
+        valid[r] = (q < (uint32_t)CPP) && ((uint32_t)c.p < c.P);
+        key[r] = valid[r] ? okey(val[r]) : 0u;  // 0 is below every real key
+        keys[(uint32_t)c.lane * CPL + r] = key[r];
+    }
+    WAVE_SYNC();
+    uint32_t gt[CPL];
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) gt[r] = 0;
+    const uint32_t nslots = (c.P * LP * CPL + 3u) & ~3u;  // slots of dead paths hold 0
+    for (uint32_t s4 = 0; s4 < nslots; s4 += 4) {
+        const u32x4 k = *(const lds_u32x4*)(uintptr_t)(c.scratch + s4);
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            gt[r] += (k.x > key[r]) ? 1u : 0u;
+            gt[r] += (k.y > key[r]) ? 1u : 0u;
+            gt[r] += (k.z > key[r]) ? 1u : 0u;
+            gt[r] += (k.w > key[r]) ? 1u : 0u;
+        }
+    }
+    bool sel[CPL];
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) {
+        sel[r] = valid[r] && gt[r] < newP;
+        if (sel[r]) rk[gt[r]] = (uint32_t)c.lane * CPL + r;
+    }
+    WAVE_SYNC();
+    bool lost = false;
+#pragma unroll
+    for (int r = 0; r < CPL; ++r)
+        if (sel[r]) lost = lost || (rk[gt[r]] != (uint32_t)c.lane * CPL + r);
+    if (ballot64(lost) != 0) return false;
+    nval = 0.0f;
+    nidx = 0;
+    if ((uint32_t)c.p < newP) {
+        const uint32_t id = rk[c.p];
+        nval = unkey(keys[id]);
+        const uint32_t sl = id / CPL, r = id % CPL;
+        nidx = (sl >> LPL) * CPP + (sl & (uint32_t)(LP - 1)) * CPL + r;
+    }
+    return true;
+}
+
 template <typename CTX, int LPL, int CPP>
 __device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
                                                 float pathbest, uint32_t newP, float& nval, uint32_t& nidx)
@@ -1165,8 +1244,15 @@ __device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP 
         nidx = (uint32_t)c.p * CPP;
         return;
     }
-    if constexpr (LPL == 3)
+    if constexpr (LPL == 3) {
         select_ranked8<CTX, CPP>(c, val[0], newP, nval, nidx);
+        return;
+    } else if (c.P * CPP > newP) {
+        // (when every candidate survives, the reference leaves the last position unsorted: literal code below)
+        if (select_ranked<CTX, LPL, CPP>(c, val, newP, nval, nidx)) return;
+    }
+    if constexpr (LPL == 3)
+        ;
     else if constexpr (CPP <= (1 << LPL))
         select_paths_1<CTX, LPL, CPP>(c, val[0], newP, nval, nidx);
     else
@@ -1181,7 +1267,7 @@ __device__ __forceinline__ void write_leaf_bits(const CTX& c, const SRC& x, uint
 {
     constexpr int LP = CTX::LP;
     const uint32_t n = 1u << s;
-    uint32_t* dst = c.area(side, c.p) + woff(s);
+    uint32_t* dst = c.bits(side, c.p, s);
     uint32_t acc = 0;
     for (uint32_t i0 = 0; i0 < n; i0 += LP) {
         const uint32_t i = i0 + c.j;
@@ -1218,10 +1304,10 @@ __device__ __forceinline__ float4 virt_top4(const void* chan, uint32_t halfN, ui
 }
 
 // 4 waves per SIMD (<= 128 VGPRs) for the L <= 8 production kernels: occupancy is what hides the LDS / arena latency
-template <int LPL, bool I8, bool S64, bool DIAG>
+template <int LPL, bool I8, bool S64, bool DIAG, bool HB>
 __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_kernel(DecodeParams P)
 {
-    using Ctx = SclCtx<LPL, S64>;
+    using Ctx = SclCtx<LPL, S64, HB>;
     constexpr int LP = Ctx::LP;
     constexpr int LMAX = Ctx::LMAX;
     constexpr int NACC = Ctx::NACC;
@@ -1241,6 +1327,11 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
     c.wppR = P.wppR;
     c.arena = P.arena + (size_t)(blockIdx.x * wpb + wib) * P.arena_wave_words;
     c.arena_path_stride = P.arena_path_stride;
+    c.gbits = reinterpret_cast<uint32_t*>(c.arena + P.arena_bits_off);
+    c.sb = P.sb;
+    c.wsb = woff(P.sb);
+    c.gwl = P.gbit_left_words;
+    c.gwpp = P.gbit_path_words;
     c.s0 = P.s0;
     c.logN = P.logN;
     c.ablate = DIAG ? P.ablate : 0u;
@@ -1479,9 +1570,9 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
             } else if (ins.op == SCL_C_W) {  // COMBINE, h >= 32
                 if (active && !skip_small) {
                     const uint32_t lq = (uint32_t)(c.slot >> fsh) & (uint32_t)(LMAX - 1);
-                    const uint32_t* lb = c.area(0, lq) + wo_c;
-                    const uint32_t* rb = c.area(1, c.p) + wo_c;
-                    uint32_t* ob = c.area(side, c.p) + wo_s;
+                    const uint32_t* lb = c.bits(0, lq, s - 1);
+                    const uint32_t* rb = c.bits(1, c.p, s - 1);
+                    uint32_t* ob = c.bits(side, c.p, s);
                     const uint32_t hw = h >> 5;
                     for (uint32_t w = c.j; w < hw; w += LP) {
                         const uint32_t r = rb[w];
@@ -1505,7 +1596,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                         const uint32_t q = in ? (e >> ish) : 0u, i = (e & (ipp - 1)) << 2;
                         const uint32_t holder = c.field(c.slot_from_lane((int)(q << LPL)), logN);
                         if (in) {
-                            const uint32_t* rl = c.area(0, holder) + wtop;
+                            const uint32_t* rl = c.bits(0, holder, logN - 1);
                             const float4 a = virt_top4<I8>(chan, N >> 1, i, right, rl), b = virt_top4<I8>(chan, N >> 1, h + i, right, rl);
                             const float4 r = make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z),
                                                          polar_f(a.w, b.w));
@@ -1565,9 +1656,9 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                         const uint32_t q = in ? (e >> ish) : 0u, i = (e & (ipp - 1)) << 2;
                         const uint32_t holder = c.field(c.slot_from_lane((int)(q << LPL)), logN);
                         if (in) {
-                            const uint32_t* rl = c.area(0, holder) + wtop;
+                            const uint32_t* rl = c.bits(0, holder, logN - 1);
                             const float4 a = virt_top4<I8>(chan, N >> 1, i, right, rl), b = virt_top4<I8>(chan, N >> 1, h + i, right, rl);
-                            const uint32_t u = ((c.area(0, q) + wo)[i >> 5] >> (i & 31u)) & 0xFu;
+                            const uint32_t u = (c.bits(0, q, s - 1)[i >> 5] >> (i & 31u)) & 0xFu;
                             const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
                                                          polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, u >> 3));
                             if (dst_arena)
@@ -1591,7 +1682,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                             if (in) {
                                 const Rd<SK> x{ c.template src_base<SK>(s, srcq) };
                                 const float4 a = x.ld4(i), b = x.ld4(h + i);
-                                const uint32_t u = ((c.area(0, q) + wo)[i >> 5] >> (i & 31u)) & 0xFu;
+                                const uint32_t u = (c.bits(0, q, s - 1)[i >> 5] >> (i & 31u)) & 0xFu;
                                 const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
                                                              polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, u >> 3));
                                 if (dst_arena)
@@ -1622,9 +1713,9 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
             } else if (ins.op == SCL_COMBINE) {  // :253-260 CombineBitsLong / CombineBitsShort
                 if (active && !(DIAG && (P.ablate & 16u))) {
                     const uint32_t lq = c.field(c.slot, s);
-                    const uint32_t* lb = c.area(0, lq) + woff(s - 1);
-                    const uint32_t* rb = c.area(1, c.p) + woff(s - 1);
-                    uint32_t* ob = c.area(side, c.p) + woff(s);
+                    const uint32_t* lb = c.bits(0, lq, s - 1);
+                    const uint32_t* rb = c.bits(1, c.p, s - 1);
+                    uint32_t* ob = c.bits(side, c.p, s);
                     if (h >= 32) {
                         const uint32_t hw = h >> 5;
                         for (uint32_t w = c.j; w < hw; w += LP) {
@@ -1659,7 +1750,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                 const float sum = c.lanesum_finish(acc);
                 if (active) {
                     c.metric = c.metric + sum;
-                    uint32_t* ob = c.area(side, c.p) + woff(s);
+                    uint32_t* ob = c.bits(side, c.p, s);
                     const uint32_t nw = n >= 32 ? (n >> 5) : 1u;
                     for (uint32_t w = c.j; w < nw; w += LP) ob[w] = 0u;
                 }
@@ -1732,7 +1823,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
         if (DIAG && (P.ablate & 32u)) continue;
         // ---- SclAvxFloat::extractBestPath :711-750 ---------------------------------------------
         const bool active = (uint32_t)c.p < c.P;
-        uint32_t* cwbits = c.area(0, c.p) + woff(logN);
+        uint32_t* cwbits = c.bits(0, c.p, logN);
         const uint32_t nwords = N >= 32 ? (N >> 5) : 1u;
         if (!P.systematic) {  // re-encode every candidate (:731-746)
             if (active) {
@@ -1759,7 +1850,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
         bool best_passes = false;
         if (P.det_on) {
             // the best path passes for almost every codeword: check it alone with all 64 lanes first
-            const uint32_t* b0 = c.area(0, 0) + woff(logN);
+            const uint32_t* b0 = c.bits(0, 0, logN);
             uint32_t syn0 = 0;
             for (uint32_t t = lane; t < P.K; t += 64) {
                 const uint32_t pos = P.lut[t];
@@ -1787,7 +1878,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
             }
         }
         {
-            const uint32_t* wb = c.area(0, winner) + woff(logN);
+            const uint32_t* wb = c.bits(0, winner, logN);
             uint8_t* orow = P.out + (size_t)row * P.nb;
             for (uint32_t t0 = 0; t0 < P.K; t0 += 64) {
                 const uint32_t t = t0 + lane;
@@ -1828,18 +1919,18 @@ __global__ void collect_failed_kernel(const uint8_t* ok, uint32_t rows, uint32_t
 //  launchers
 // =============================================================================================
 // grid == 0: do not launch, report the resident workgroups per CU for this block size / LDS size in *occ
-template <int LPL, bool I8, bool S64, bool DIAG>
+template <int LPL, bool I8, bool S64, bool DIAG, bool HB>
 static hipError_t launch_scl_k(const DecodeParams& P, dim3 grid, dim3 block, size_t lds, hipStream_t st, int* occ)
 {
     if (occ) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG, HB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, scl_decode_kernel<LPL, I8, S64, DIAG>, (int)block.x, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, scl_decode_kernel<LPL, I8, S64, DIAG, HB>, (int)block.x, lds);
         if (e != hipSuccess) return e;
         // the API over-reports for single-wave workgroups: clamp by the register file (512 VGPRs per SIMD lane,
         // allocation granule 8, at most 8 waves per SIMD; MI355X_MICROARCH.md "Register files")
         hipFuncAttributes fa;
-        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG>));
+        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG, HB>));
         if (e != hipSuccess) return e;
         const int regs = ((fa.numRegs > 0 ? fa.numRegs : 1) + 7) & ~7;
         int waves_per_simd = 512 / regs;
@@ -1849,27 +1940,32 @@ static hipError_t launch_scl_k(const DecodeParams& P, dim3 grid, dim3 block, siz
         if (*occ > by_regs) *occ = by_regs;
         return hipSuccess;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG, HB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((scl_decode_kernel<LPL, I8, S64, DIAG>), grid, block, lds, st, P);
+    hipLaunchKernelGGL((scl_decode_kernel<LPL, I8, S64, DIAG, HB>), grid, block, lds, st, P);
     return hipGetLastError();
 }
 
 // Instantiations: the production kernels (no diagnostics) for every lanes-per-path split, with a 64-bit slot
-// word; a 32-bit slot word variant for L <= 8 when log2(N) * 3 <= 32 (the headline configuration); and a
-// diagnostic variant (trace / cycle stamps / ablation switches) for float input only.
+// word, with and without the high-stage bit blocks in the arena; a 32-bit slot word variant for L <= 8 when
+// log2(N) * 3 <= 32 (the headline configuration); and a diagnostic variant (trace / cycle stamps / ablation
+// switches) for float input only.
 template <int LPL>
 static hipError_t launch_scl_t(const DecodeParams& P, bool i8, bool slot64, bool diag, dim3 grid, dim3 block, size_t lds,
                                hipStream_t st, int* occ)
 {
-    if (diag && !i8) return launch_scl_k<LPL, false, true, true>(P, grid, block, lds, st, occ);
+    const bool hb = P.sb <= P.logN;  // high-stage bit blocks in the arena
+    if (diag && !i8) return launch_scl_k<LPL, false, true, true, true>(P, grid, block, lds, st, occ);
     if constexpr (LPL == 3) {
-        if (!slot64)
-            return i8 ? launch_scl_k<LPL, true, false, false>(P, grid, block, lds, st, occ)
-                      : launch_scl_k<LPL, false, false, false>(P, grid, block, lds, st, occ);
+        if (!slot64 && !hb)
+            return i8 ? launch_scl_k<LPL, true, false, false, false>(P, grid, block, lds, st, occ)
+                      : launch_scl_k<LPL, false, false, false, false>(P, grid, block, lds, st, occ);
     }
-    return i8 ? launch_scl_k<LPL, true, true, false>(P, grid, block, lds, st, occ)
-              : launch_scl_k<LPL, false, true, false>(P, grid, block, lds, st, occ);
+    if (hb)
+        return i8 ? launch_scl_k<LPL, true, true, false, true>(P, grid, block, lds, st, occ)
+                  : launch_scl_k<LPL, false, true, false, true>(P, grid, block, lds, st, occ);
+    return i8 ? launch_scl_k<LPL, true, true, false, false>(P, grid, block, lds, st, occ)
+              : launch_scl_k<LPL, false, true, false, false>(P, grid, block, lds, st, occ);
 }
 
 template <int LCL, bool I8>
