@@ -131,3 +131,14 @@ def test_non_systematic_round_trip(built_library):
     d.setSystematic(False)
     out, ok = d.decode_batch((1.0 - 2.0 * bits).astype(np.float32))
     assert ok.all() and np.array_equal(out, info)
+
+
+def test_empty_and_single_row_batches(built_library):
+    fx = [f for f in gio.load_enc() if f.N == 1024 and f.crc_size == 24 and f.systematic][0]
+    e = _encoder(fx.N, fx.frozen, 24, "crcnr")
+    out = e.encode_batch(np.zeros((0, 64), np.uint8))
+    assert out.shape == (0, 128)
+    one = fx.info_in[:1].copy()
+    assert np.array_equal(e.encode_batch(one), fx.cw[:1]) and np.array_equal(one, fx.info_after[:1])
+    nine = fx.info_in[:9].copy()          # one full wave pass of 8 code words + 1
+    assert np.array_equal(e.encode_batch(nine), fx.cw[:9])
