@@ -525,11 +525,17 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
     }
     if (d->has_scl) {
         const unsigned fb = ilog2(d->lmax);
-        if (d->logN * fb > 64 || (size_t)d->scl_wave_words * 4 > kMaxLds) {
+        if (d->logN * fb > 64) {
+            const std::string msg = "(blockLength, listSize) does not fit the SCL kernel: log2(blockLength) * log2(listSize) = " +
+                                    std::to_string(d->logN * fb) + " bits of path bookkeeping exceed the 64-bit slot word";
             delete d;
-            return fail(PCD_ERR_CAPACITY,
-                        "(blockLength, listSize) does not fit the SCL kernel: needs " +
-                            std::to_string((size_t)d->scl_wave_words * 4) + " B of LDS per codeword (max 163840)");
+            return fail(PCD_ERR_CAPACITY, msg);
+        }
+        if ((size_t)d->scl_wave_words * 4 > kMaxLds) {
+            const std::string msg = "(blockLength, listSize) does not fit the SCL kernel: needs " +
+                                    std::to_string((size_t)d->scl_wave_words * 4) + " B of LDS per codeword (max 163840)";
+            delete d;
+            return fail(PCD_ERR_CAPACITY, msg);
         }
     }
     *out = d;

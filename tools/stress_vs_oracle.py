@@ -16,7 +16,11 @@ SCALE = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 CASES = [(1024, 512, 8, 24, "BB", 6000), (1024, 512, 1, 0, "BB", 20000), (1024, 768, 8, 8, "BB", 3000),
          (1024, 128, 8, 11, "BB", 3000), (512, 256, 4, 8, "BE", 6000), (256, 128, 32, 8, "BB", 1500),
          (2048, 1024, 8, 24, "BB", 1500), (128, 64, 16, 8, "BE", 4000), (64, 32, 2, 8, "BB", 8000),
-         (4096, 2048, 32, 32, "BB", 60)]
+         (4096, 2048, 32, 32, "BB", 60),
+         # list sizes above 8: rank-based selection with several candidates per lane, bit blocks in the arena
+         (1024, 512, 16, 24, "BB", 1500), (1024, 512, 32, 24, "BB", 800), (512, 384, 32, 8, "BE", 800),
+         (2048, 1024, 32, 32, "BB", 200), (4096, 1024, 16, 24, "BB", 150), (256, 64, 12, 8, "BB", 1500),
+         (8192, 4096, 16, 32, "BB", 24)]
 tot = bad = 0
 for N, K, L, det, ctor, B in [(a, b, c, dd, e, f * SCALE) for a, b, c, dd, e, f in CASES]:
     F = frozen_bits(N, K, 0.0, ctor)
