@@ -159,9 +159,53 @@ def bench_encode(args, cfg, dev, dev_index, rank, world, barrier_fn):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "encode_kernel",
                      "kernel_ms_avg": k_ms, "algorithmic_bytes_per_codeword": bytes_per_cw, "codewords_per_launch": B},
     }
+    if world == 1 and args.pmc_traffic:
+        t = pmc_traffic(args.config, log2b, "encode_kernel")
+        if t:
+            res["roofline"].update({"traffic": t["bytes"], "traffic_unit": "bytes per launch at the L2<->fabric "
+                                    "interface (Infinity-Cache hits included): 2 x FETCH_SIZE + WRITE_SIZE",
+                                    "traffic_fetch_size_raw": t["fetch_raw"], "traffic_write_size": t["write"],
+                                    "traffic_over_algorithmic": t["bytes"] / (bytes_per_cw * B)})
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_encode(cfg, args.cpu_seconds)
     print(json.dumps(res))
+
+
+def pmc_traffic(config, log2b, kernel_substr):
+    """L2<->fabric bytes per launch of the dominant kernel from the PMC counters FETCH_SIZE / WRITE_SIZE, each collected in
+    its own rocprofv3 pass (no tracing) around a child run of this script, as MI355X_MICROARCH.md prescribes:
+    the counters are in KiB, count Infinity-Cache hits, and on gfx950 FETCH_SIZE tallies every 128-B request as 64 B
+    (reported value x 2 = bytes).  Returns None if rocprofv3 is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable,
+                            os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "2", "--warmup", "0",
+                            "--no-cpu-baseline", "--log2-batch", str(log2b)],
+                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=900, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            out[counter] = float(np.mean(vals)) * 1024.0
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] PMC pass {counter} failed: {e}", file=sys.stderr)
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return {"fetch_raw": out["FETCH_SIZE"], "write": out["WRITE_SIZE"],
+            "bytes": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]}
 
 
 def cpu_baseline(cfg, seconds):
@@ -204,6 +248,8 @@ def main():
     ap.add_argument("--log2-batch", type=int, default=None, help="codewords per GPU = 2^this (default: BASELINE's 20)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-traffic", action="store_true",
+                    help="also fill roofline.traffic from two rocprofv3 --pmc child passes (N = 1 only; adds about a minute)")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -320,6 +366,13 @@ def main():
                          "kernel_ms_avg": k_ms, "algorithmic_bytes_per_codeword": bytes_per_cw,
                          "codewords_per_launch": B},
         }
+        if world == 1 and args.pmc_traffic:
+            t = pmc_traffic(args.config, log2b, res["roofline"]["kernel"])
+            if t:
+                res["roofline"].update({"traffic": t["bytes"], "traffic_unit": "bytes per launch at the L2<->fabric "
+                                        "interface (Infinity-Cache hits included): 2 x FETCH_SIZE + WRITE_SIZE",
+                                        "traffic_fetch_size_raw": t["fetch_raw"], "traffic_write_size": t["write"],
+                                        "traffic_over_algorithmic": t["bytes"] / (bytes_per_cw * B)})
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
         print(json.dumps(res))
