@@ -269,3 +269,22 @@ def test_handmade_frozen_sets(built_library, N, frozen, L):
     assert np.array_equal(res[0], e_out)
     if L > 1:
         assert np.allclose(res[2], e_met, rtol=METRIC_RTOL, atol=0)
+
+
+@pytest.mark.parametrize("name,reps", [("cfg3_n1024_k512_l8_crc24_awgn.bin", 400), ("mix_n1024_k512_l8_crc24_awgn.bin", 900),
+                                       ("cfg1_n64_k40_sc_awgn.bin", 7000)])
+def test_large_host_pointer_batches(built_library, name, reps):
+    """host (numpy) batches of 100+ MB through the staging path of pcd_decode_f32 (ragged row count): outputs,
+    verdicts and metrics must come out in place"""
+    fx = gio.load_named(name)
+    d = _decoder(fx)
+    llr = np.tile(fx.llr, (reps, 1))[: fx.count * reps - 37]            # ragged tail
+    want_m = fx.L > 1 and fx.dectype == "float"
+    res = d.decode_batch(llr, return_metrics=want_m)
+    exp_out = np.tile(fx.out, (reps, 1))[: llr.shape[0]]
+    exp_ok = np.tile(fx.ok, reps)[: llr.shape[0]]
+    assert np.array_equal(res[0], exp_out)
+    assert np.array_equal(res[1].astype(np.uint8), exp_ok)
+    if want_m:
+        exp_m = np.tile(fx.metrics, (reps, 1))[: llr.shape[0]]
+        assert np.array_equal(res[2].view(np.uint32), exp_m.view(np.uint32))
