@@ -62,6 +62,7 @@ struct pcd_decoder {
     unsigned sc_virtual_top = 0;
     int sc_lcl = 4;                           // log2(lanes per codeword): 4 -> four codewords per wave
     int lpl = 3;
+    unsigned cwl = 0;  // log2 codewords per wave of the list kernel
     unsigned lmax = 8, path_stride = 0, wppL = 0, wppR = 0, scl_wave_words = 0, scl_wpb = 1;
     unsigned s0 = 0, arena_path_stride = 0, arena_wave_words = 0;
     unsigned sb = 0, arena_bits_off = 0, gbit_left_words = 0, gbit_path_words = 0;
@@ -138,8 +139,18 @@ void compute_geometry(pcd_decoder* d)
     d->sc_wpb = 1;  // single-wave workgroups: LDS granularity of one wave, nothing is shared between waves anyway
     if (const char* e = std::getenv("PCD_SC_WPB")) d->sc_wpb = (unsigned)std::max(1, std::atoi(e));
     if (d->L > 1) {
-        unsigned lmax = 2;
-        while (lmax < d->L) lmax <<= 1;
+        unsigned lprime = 2;  // path groups one codeword needs
+        while (lprime < d->L) lprime <<= 1;
+        // Several codewords per wave: every codeword follows the same program, so the interpreter's scalar work and
+        // the skeleton of the small ops are shared.  L <= 2: 8 lanes per path x 4 codewords; L <= 4: 8 x 2;
+        // L <= 8: 4 lanes per path x 2 codewords (measured at cfg 3: 12.0 -> 15.0 M cw/s against 8 lanes x 1).
+        d->cwl = lprime == 2 ? 2u : (lprime <= 8 ? 1u : 0u);
+        if (const char* e = std::getenv("PCD_CWL")) {  // experiments: 0 = one codeword per wave; 1 at L <= 8: 4 lanes per path
+            const unsigned v = (unsigned)std::atoi(e);
+            d->cwl = (lprime == 2 && v <= 2) || (lprime <= 8 && v <= 1) ? v : 0u;
+            if (lprime == 2 && v == 1) d->cwl = 0;  // (8 lanes x 2 paths x 2 codewords has no kernel)
+        }
+        const unsigned lmax = lprime << d->cwl;  // path groups (= path buffers) per wave
         d->lmax = lmax;
         d->lpl = 6 - (int)ilog2(lmax);
         const unsigned LP = 64 / lmax;
@@ -220,10 +231,10 @@ void specialize_scl(pcd_decoder* d)
         }
     }
     auto woff = [](unsigned t) { return t <= 5 ? t : ((1u << (t - 5)) + 4u); };
-    const unsigned fb = 6u - (unsigned)d->lpl;
+    const unsigned fb = 6u - (unsigned)d->lpl - d->cwl;  // bits per slot field: a path buffer of the same codeword
     for (auto& in : d->scl_prog.ins) {
         const unsigned s = in.stage;
-        if ((in.op == pamd::SCL_SPC || in.op == pamd::SCL_R1) && d->lpl == 3 && s <= 3 && s < d->s0 && s < d->logN) {
+        if ((in.op == pamd::SCL_SPC || in.op == pamd::SCL_R1) && (d->lpl == 3 || d->lpl == 2) && s <= 3 && s < d->s0 && s < d->logN) {
             in.op = in.op == pamd::SCL_SPC ? pamd::SCL_SPC_S : pamd::SCL_R1_S;
             continue;
         }
@@ -346,6 +357,7 @@ int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     P.arena_path_stride = d->arena_path_stride;
     P.arena_wave_words = d->arena_wave_words;
     P.arena_bits_off = d->arena_bits_off;
+    P.cwl = d->cwl;
     P.sb = d->sb;
     P.gbit_left_words = d->gbit_left_words;
     P.gbit_path_words = d->gbit_path_words;
@@ -355,9 +367,10 @@ int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
         HIP_TRY(pamd::launch_scl(P, d->lpl, i8, 1, d->scl_wpb, lds, st, &occ));
         d->scl_blocks_per_cu = std::max(1, std::min(occ, (int)lds_blocks_per_cu(lds)));
         if (const char* e = std::getenv("PCD_BLOCKS_PER_CU")) d->scl_blocks_per_cu = std::max(1, std::atoi(e));  // experiments
-        if (std::getenv("PCD_VERBOSE")) std::fprintf(stderr, "[pcd] scl: s0=%u sb=%u lds=%zu B occupancy=%d -> %d blocks/CU\n", d->s0, d->sb, lds, occ, d->scl_blocks_per_cu);
+        if (std::getenv("PCD_VERBOSE")) std::fprintf(stderr, "[pcd] scl: %u lanes/path x %u codewords/wave, s0=%u sb=%u lds=%zu B occupancy=%d -> %d blocks/CU\n", 64u / d->lmax, 1u << d->cwl, d->s0, d->sb, lds, occ, d->scl_blocks_per_cu);
     }
-    const unsigned need = (unsigned)((P.rows + d->scl_wpb - 1) / d->scl_wpb);
+    const unsigned cw_per_block = d->scl_wpb << d->cwl;
+    const unsigned need = (unsigned)((P.rows + cw_per_block - 1) / cw_per_block);
     const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->scl_blocks_per_cu)));
     if (d->arena_wave_words) {
         int rc = grow(d->d_arena, d->d_arena_cap, (size_t)grid * d->scl_wpb * d->arena_wave_words * sizeof(float));
@@ -524,7 +537,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         return fail(PCD_ERR_CAPACITY, "block length too large for the SC kernel's LDS layout");
     }
     if (d->has_scl) {
-        const unsigned fb = ilog2(d->lmax);
+        const unsigned fb = ilog2(d->lmax) - d->cwl;
         if (d->logN * fb > 64) {
             const std::string msg = "(blockLength, listSize) does not fit the SCL kernel: log2(blockLength) * log2(listSize) = " +
                                     std::to_string(d->logN * fb) + " bits of path bookkeeping exceed the 64-bit slot word";
@@ -631,7 +644,7 @@ int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4])
     if (list) {
         if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SCL program");
         info[0] = d->scl_wave_words * 4;
-        info[1] = d->scl_wpb;
+        info[1] = d->scl_wpb << d->cwl;
         info[2] = 64u >> d->lpl;
         info[3] = (unsigned)(kMaxLds / ((size_t)d->scl_wpb * d->scl_wave_words * 4));
     } else {

@@ -25,6 +25,7 @@ struct DecodeParams {
     float* arena;            // SCL: global scratch for LLR stages >= s0 (one slice per resident wave)
     uint32_t arena_wave_words, arena_path_stride;  // words of one wave's slice (LLR stages, then the high-stage bits)
     uint32_t arena_bits_off;  // SCL: word offset of the bit blocks inside the wave's slice
+    uint32_t cwl;             // SCL: log2 of the codewords one wave decodes side by side
     uint32_t sb;              // SCL: first stage whose bit blocks live in the arena (logN + 1 = none)
     uint32_t gbit_left_words, gbit_path_words;  // SCL: arena bit words per path (left/root outputs; both areas)
     uint32_t s0;             // SCL: first LLR stage kept in the arena (logN = none)

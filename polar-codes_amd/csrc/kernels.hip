@@ -671,12 +671,18 @@ struct Wr {
     }
 };
 
-template <int LPL, bool S64, bool HB>
+// CWL: log2 of the codewords one wave decodes side by side.  The 64 >> LPL path groups of the wave are split into
+// 1 << CWL codewords of LCW groups each; a group is BOTH a path buffer (LDS / arena / bit areas, index p) and, at any
+// moment, the home of the path with index pl inside its codeword.  Everything per path is unchanged by CWL; what
+// becomes per codeword is the list management (candidate selection, fork sources), the channel row and the output.
+template <int LPL, bool S64, bool HB, int CWL = 0>
 struct SclCtx {
     using SlotT = std::conditional_t<S64, uint64_t, uint32_t>;
     static constexpr int LP = 1 << LPL;     // lanes per path
     static constexpr int LMAX = 64 >> LPL;  // path groups per wave
-    static constexpr int FB = 6 - LPL;      // bits per slot field
+    static constexpr int CW = 1 << CWL;     // codewords per wave
+    static constexpr int LCW = LMAX >> CWL; // path groups (= list size limit) per codeword
+    static constexpr int FB = 6 - LPL - CWL;  // bits per slot field: a path buffer of the same codeword
     static constexpr int NACC = LP >= 8 ? 1 : 8 / LP;  // AVX-lane accumulators per lane
 
     float* llr;
@@ -694,7 +700,8 @@ struct SclCtx {
     uint32_t sb, wsb, gwl, gwpp;
     const void* chan;
     int lane, p, j, base;
-    uint32_t P;      // live paths (wave uniform)
+    int pl, g0;      // path index inside its codeword; first group of the codeword (p = g0 + pl); CWL = 0: pl = p, g0 = 0
+    uint32_t P;      // live paths per codeword (wave uniform: every codeword follows the same program)
     uint32_t L;      // list size limit
     float metric;
     SlotT slot;
@@ -764,14 +771,15 @@ struct SclCtx {
         else
             fn(Wr<K_LDS>{ path_llr(q) + (1u << t) });
     }
-    __device__ __forceinline__ uint32_t field(SlotT sl, uint32_t s) const
+    // the path buffer named by field s of the slot word sl of a path that lives in group gq
+    __device__ __forceinline__ uint32_t field(SlotT sl, uint32_t s, uint32_t gq) const
     {
-        return (uint32_t)(sl >> ((s - 1) * FB)) & (uint32_t)(LMAX - 1);
+        return (gq & ~(uint32_t)(LCW - 1)) | ((uint32_t)(sl >> ((s - 1) * FB)) & (uint32_t)(LCW - 1));
     }
     __device__ __forceinline__ void set_field(uint32_t s)
     {
         const uint32_t sh = (s - 1) * FB;
-        slot = (slot & ~((SlotT)(LMAX - 1) << sh)) | ((SlotT)p << sh);
+        slot = (slot & ~((SlotT)(LCW - 1) << sh)) | ((SlotT)(p & (LCW - 1)) << sh);
     }
     // the slot word of path group q, as a wave-uniform value / fetched from a per-lane source lane
     __device__ __forceinline__ SlotT slot_of_group(int q) const
@@ -804,6 +812,14 @@ struct SclCtx {
             const float x0 = bitsf(hi ? o0 : b0), x1 = bitsf(hi ? o1 : b1), x2 = bitsf(hi ? o2 : b2),
                         x3 = bitsf(hi ? o3 : b3), x4 = bitsf(hi ? b0 : o0), x5 = bitsf(hi ? b1 : o1),
                         x6 = bitsf(hi ? b2 : o2), x7 = bitsf(hi ? b3 : o3);
+            return ((((((x0 + x1) + x2) + x3) + x4) + x5) + x6) + x7;
+        }
+        if constexpr (LP == 4) {
+            // lane j holds the accumulators of AVX lanes j and j + 4: quad_perm broadcasts, no LDS round trips
+            const uint32_t a = fbits(acc[0]), b = fbits(acc[1]);
+            const float x0 = bitsf(dpp_u32<0x00>(a)), x1 = bitsf(dpp_u32<0x55>(a)), x2 = bitsf(dpp_u32<0xAA>(a)),
+                        x3 = bitsf(dpp_u32<0xFF>(a)), x4 = bitsf(dpp_u32<0x00>(b)), x5 = bitsf(dpp_u32<0x55>(b)),
+                        x6 = bitsf(dpp_u32<0xAA>(b)), x7 = bitsf(dpp_u32<0xFF>(b));
             return ((((((x0 + x1) + x2) + x3) + x4) + x5) + x6) + x7;
         }
         float s = 0.0f;
@@ -928,21 +944,27 @@ __device__ __forceinline__ void find_weak(const CTX& c, const SRC& x, uint32_t n
 // Literal emulation: iteration i finds the first position >= i holding the maximum and swaps it
 // with position i.  On return every lane knows, for ITS OWN new path index p, the winning
 // candidate's metric (nval) and original position (nidx).
+// tg0 = first group of the codeword being sorted (several codewords per wave take turns; lanes of the others idle):
+// on return only the lanes of that codeword hold a result.
 template <typename CTX, int LPL, int CPP>
-__device__ __forceinline__ void select_paths(const CTX& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
-                                             uint32_t newP, float& nval, uint32_t& nidx)
+__device__ __forceinline__ void select_paths(const CTX& c, float (&val_in)[(CPP >> LPL) ? (CPP >> LPL) : 1],
+                                             uint32_t newP, float& nval, uint32_t& nidx, int tg0 = 0)
 {
     constexpr int LP = CTX::LP;
     constexpr int CPL = (CPP >> LPL) ? (CPP >> LPL) : 1;
     const uint32_t size = c.P * CPP;
+    const bool mine = c.g0 == tg0;
+    const uint32_t lane0 = (uint32_t)tg0 << LPL;
     uint32_t idx[CPL], pos[CPL];
+    float val[CPL];
     bool valid[CPL];
 #pragma unroll
     for (int r = 0; r < CPL; ++r) {
         const uint32_t q = (uint32_t)c.j * CPL + r;
-        valid[r] = (q < (uint32_t)CPP) && ((uint32_t)c.p < c.P);
-        pos[r] = (uint32_t)c.p * CPP + q;
+        valid[r] = mine && (q < (uint32_t)CPP) && ((uint32_t)c.pl < c.P);
+        pos[r] = (uint32_t)c.pl * CPP + q;
         idx[r] = pos[r];
+        val[r] = val_in[r];
     }
     const uint32_t lim = (size - 1 < newP) ? size - 1 : newP;
     for (uint32_t i = 0; i < lim; ++i) {
@@ -968,7 +990,7 @@ __device__ __forceinline__ void select_paths(const CTX& c, float (&val)[(CPP >> 
         const uint64_t bal = ballot64(has && lv == m);
         const int wl = __ffsll((long long)bal) - 1;  // lowest lane = lowest position
         // the element currently at position i
-        const uint32_t li = (i / CPP) * LP + ((i % CPP) / CPL), ri = (i % CPP) % CPL;
+        const uint32_t li = lane0 + (i / CPP) * LP + ((i % CPP) / CPL), ri = (i % CPP) % CPL;
         float vi = val[0];
         uint32_t xi = idx[0];
 #pragma unroll
@@ -1004,9 +1026,9 @@ __device__ __forceinline__ void select_paths(const CTX& c, float (&val)[(CPP >> 
                 }
         }
     }
-    // new path p takes the candidate now sitting at position p
-    const uint32_t np = (uint32_t)c.p;
-    const uint32_t ln = (np / CPP) * LP + ((np % CPP) / CPL), rn = (np % CPP) % CPL;
+    // new path pl takes the candidate now sitting at position pl
+    const uint32_t np = (uint32_t)c.pl;
+    const uint32_t ln = lane0 + (np / CPP) * LP + ((np % CPP) / CPL), rn = (np % CPP) % CPL;
     // fetch register rn of lane ln (rn varies per lane -> select after shuffling every register)
     float v = shfl_f32(val[0], (int)ln);
     uint32_t x = shfl_u32(idx[0], (int)ln);
@@ -1019,8 +1041,10 @@ __device__ __forceinline__ void select_paths(const CTX& c, float (&val)[(CPP >> 
             x = xr;
         }
     }
-    nval = v;
-    nidx = x;
+    if (mine) {
+        nval = v;
+        nidx = x;
+    }
 }
 
 // Same selection for the common case of at most one candidate per lane (CPP <= LP): everything that is
@@ -1028,14 +1052,16 @@ __device__ __forceinline__ void select_paths(const CTX& c, float (&val)[(CPP >> 
 // winner of iteration i IS what new path i inherits, so no permute is needed afterwards.
 template <typename CTX, int LPL, int CPP>
 __device__ __forceinline__ void select_paths_1(const CTX& c, float val, uint32_t newP, float& nval,
-                                               uint32_t& nidx)
+                                               uint32_t& nidx, int tg0 = 0)
 {
     constexpr int LP = CTX::LP;
     static_assert(CPP <= LP, "one candidate per lane");
     constexpr int CS = CPP == 8 ? 3 : (CPP == 4 ? 2 : 1);
     const uint32_t size = c.P * CPP;
-    const bool valid = ((uint32_t)c.j < (uint32_t)CPP) && ((uint32_t)c.p < c.P);
-    const uint32_t pos = ((uint32_t)c.p << CS) + (uint32_t)c.j;
+    const bool mine = c.g0 == tg0;
+    const int lane0 = tg0 << LPL;
+    const bool valid = mine && ((uint32_t)c.j < (uint32_t)CPP) && ((uint32_t)c.pl < c.P);
+    const uint32_t pos = ((uint32_t)c.pl << CS) + (uint32_t)c.j;
     uint32_t key = valid ? okey(val) : 0u;
     uint32_t idx = pos;
     uint32_t rkey = 0, ridx = 0;
@@ -1045,7 +1071,7 @@ __device__ __forceinline__ void select_paths_1(const CTX& c, float val, uint32_t
         const uint32_t m = wave_max_u32(el ? key : 0u);
         const uint64_t bal = ballot64(el && key == m);
         const int wl = __ffsll((long long)bal) - 1;                  // lowest lane = lowest position
-        const int li = (int)(((i >> CS) << LPL) + (i & (CPP - 1)));   // lane holding position i
+        const int li = lane0 + (int)(((i >> CS) << LPL) + (i & (CPP - 1)));   // lane holding position i
         const uint32_t ki = readlane_u32(key, li), xi = readlane_u32(idx, li), xw = readlane_u32(idx, wl);
         if (c.lane == wl) {
             key = ki;
@@ -1055,21 +1081,23 @@ __device__ __forceinline__ void select_paths_1(const CTX& c, float val, uint32_t
             key = m;
             idx = xw;
         }
-        if ((uint32_t)c.p == i) {
+        if ((uint32_t)c.pl == i) {
             rkey = m;
             ridx = xw;
         }
     }
     if (lim < newP) {  // every candidate survives: the last position keeps what is left there
-        const int ll = (int)(((lim >> CS) << LPL) + (lim & (CPP - 1)));
+        const int ll = lane0 + (int)(((lim >> CS) << LPL) + (lim & (CPP - 1)));
         const uint32_t kl = readlane_u32(key, ll), xl = readlane_u32(idx, ll);
-        if ((uint32_t)c.p == lim) {
+        if ((uint32_t)c.pl == lim) {
             rkey = kl;
             ridx = xl;
         }
     }
-    nval = unkey(rkey);
-    nidx = ridx;
+    if (mine) {
+        nval = unkey(rkey);
+        nidx = ridx;
+    }
 }
 
 // ---- LP == 8: block of n = 2^S <= 8 LLRs, one per lane (lane j holds |x_j| bits, INFB beyond n) ----------
@@ -1115,6 +1143,59 @@ __device__ __forceinline__ void find_weak_small(uint32_t a, int j, Weak<CNT>& ou
     if constexpr (CNT > 3) step(std::integral_constant<int, 3>{});
 }
 
+// ---- LP == 4: block of n = 2^S <= 8 LLRs, positions j (a0) and j + 4 (a1, n = 8 only) in lane j -----------------
+// Same literal emulation of findWeakLlrs as find_weak_small, reductions and broadcasts inside the quad.
+template <int I>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+    return dpp_u32<I * 0x55>(v);
+}
+template <int S, int CNT>
+__device__ __forceinline__ void find_weak_small4(uint32_t a0, uint32_t a1, int j, Weak<CNT>& out)
+{
+    constexpr uint32_t INFB = 0xFFFFFFFFu;
+    constexpr int n = 1 << S;
+    constexpr int lim = (n - 1 < CNT) ? n - 1 : CNT;
+    uint32_t o0 = (uint32_t)j, o1 = (uint32_t)j + 4u;  // original indices travelling with the values
+    auto step = [&](auto I) {
+        constexpr int i = decltype(I)::value;  // (i <= 3: position i is register 0 of lane i)
+        if constexpr (i < lim) {
+            const uint32_t v0 = (j >= i) ? a0 : INFB, v1 = (S == 3) ? a1 : INFB;
+            const bool second = v1 < v0;  // position j precedes j + 4: ties go to the first
+            const uint32_t lv = second ? v1 : v0;
+            const uint32_t lpo = second ? ((((uint32_t)j + 4u) << 3) | o1) : (((uint32_t)j << 3) | o0);
+            const uint32_t m = group_min_u32<4>(lv);
+            const uint32_t pk = group_min_u32<4>((lv == m) ? lpo : INFB);
+            const uint32_t k = pk >> 3, ok = pk & 7u;
+            const uint32_t ai = quad_bcast<i>(a0), oi = quad_bcast<i>(o0);
+            if ((uint32_t)j == k) {
+                a0 = ai;
+                o0 = oi;
+            }
+            if (S == 3 && (uint32_t)j + 4u == k) {
+                a1 = ai;
+                o1 = oi;
+            }
+            if (j == i) {
+                a0 = m;
+                o0 = ok;
+            }
+            out.v[i] = m;
+            out.ix[i] = ok;
+        } else if constexpr (i < n) {
+            out.v[i] = quad_bcast<i>(a0);
+            out.ix[i] = quad_bcast<i>(o0);
+        } else {
+            out.v[i] = 0;
+            out.ix[i] = 0;
+        }
+    };
+    step(std::integral_constant<int, 0>{});
+    if constexpr (CNT > 1) step(std::integral_constant<int, 1>{});
+    if constexpr (CNT > 2) step(std::integral_constant<int, 2>{});
+    if constexpr (CNT > 3) step(std::integral_constant<int, 3>{});
+}
+
 // ---- LP == 8 candidate selection by rank -------------------------------------------------------------------
 // When no two candidates that matter carry the same metric, the reference's selection sort simply yields the
 // newP largest in descending order, so candidate c becomes new path  rank(c) = #{d : metric_d > metric_c}.
@@ -1123,24 +1204,26 @@ __device__ __forceinline__ void find_weak_small(uint32_t a, int j, Weak<CNT>& ou
 // collide in the scatter below; that is detected and handed to the literal emulation (select_paths_1), which
 // reproduces the reference's swap-order tie behaviour.
 template <typename CTX, int CPP>
-__device__ __forceinline__ void select_ranked8(const CTX& c, float val, uint32_t newP, float& nval,
+__device__ __forceinline__ bool select_ranked8(const CTX& c, float val, uint32_t newP, float& nval,
                                                uint32_t& nidx)
 {
     constexpr int CS = CPP == 8 ? 3 : (CPP == 4 ? 2 : 1);
-    const bool valid = ((uint32_t)c.j < (uint32_t)CPP) && ((uint32_t)c.p < c.P);
+    constexpr int LCW = CTX::LCW;
+    const bool valid = ((uint32_t)c.j < (uint32_t)CPP) && ((uint32_t)c.pl < c.P);
     const uint32_t key = valid ? okey(val) : 0u;  // 0 is below every real key
-    // every lane compares its key with all candidate keys: the keys go through a 64-word LDS scratch and come
-    // back as broadcast 16-byte reads (pure VALU compares, no v_readlane -> SGPR -> v_cmp hazards)
+    // every lane compares its key with all candidate keys of ITS codeword: the keys go through a 64-word LDS scratch
+    // and come back as broadcast 16-byte reads (pure VALU compares, no v_readlane -> SGPR -> v_cmp hazards)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef u32x4 __attribute__((address_space(3))) lds_u32x4;
     typedef uint32_t __attribute__((address_space(3))) lds_u32;
     ((lds_u32*)(uintptr_t)c.scratch)[c.lane] = key;
     WAVE_SYNC();
+    const uint32_t* mykeys = c.scratch + c.g0 * 8;
     uint32_t gt = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < LCW; ++q) {
         if ((uint32_t)q < c.P) {  // wave uniform
-            const u32x4 k0 = *(const lds_u32x4*)(uintptr_t)(c.scratch + q * 8);
+            const u32x4 k0 = *(const lds_u32x4*)(uintptr_t)(mykeys + q * 8);
             gt += (k0.x > key) ? 1u : 0u;
             if constexpr (CPP > 1) gt += (k0.y > key) ? 1u : 0u;
             if constexpr (CPP > 2) {
@@ -1148,7 +1231,7 @@ __device__ __forceinline__ void select_ranked8(const CTX& c, float val, uint32_t
                 gt += (k0.w > key) ? 1u : 0u;
             }
             if constexpr (CPP > 4) {
-                const u32x4 k1 = *(const lds_u32x4*)(uintptr_t)(c.scratch + q * 8 + 4);
+                const u32x4 k1 = *(const lds_u32x4*)(uintptr_t)(mykeys + q * 8 + 4);
                 gt += (k1.x > key) ? 1u : 0u;
                 gt += (k1.y > key) ? 1u : 0u;
                 gt += (k1.z > key) ? 1u : 0u;
@@ -1158,17 +1241,15 @@ __device__ __forceinline__ void select_ranked8(const CTX& c, float val, uint32_t
     }
     const bool sel = valid && gt < newP;
     // new path r inherits the candidate of rank r: scatter the lane ids (ds_permute), spread over the group
-    const uint32_t dst = sel ? (gt << 3) : 1u;  // losers dump into lane 1, which nobody reads
+    const uint32_t dst = sel ? (((uint32_t)c.g0 + gt) << 3) : (((uint32_t)c.g0 << 3) + 1u);  // losers dump into lane 1 of the codeword, which nobody reads
     const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), c.lane);
     const uint32_t srcl = group8_bcast<0>(got, c.j);
     // a selected lane whose id did not arrive lost a collision: two winners share a rank = an exact tie
     const uint32_t back = shfl_u32(got, (int)dst);
-    if (ballot64(sel && back != (uint32_t)c.lane) != 0) {
-        select_paths_1<CTX, 3, CPP>(c, val, newP, nval, nidx);
-        return;
-    }
+    if (ballot64(sel && back != (uint32_t)c.lane) != 0) return false;
     nval = unkey(shfl_u32(key, (int)srcl));
-    nidx = ((srcl >> 3) << CS) + (srcl & 7u);
+    nidx = (((srcl >> 3) - (uint32_t)c.g0) << CS) + (srcl & 7u);
+    return true;
 }
 
 // ---- candidate selection by rank for fewer than 8 lanes per path (list sizes above 8) ------------------------
@@ -1187,13 +1268,14 @@ __device__ __forceinline__ bool select_ranked(const CTX& c, const float (&val)[(
     typedef u32x4 __attribute__((address_space(3))) lds_u32x4;
     typedef uint32_t __attribute__((address_space(3))) lds_u32;
     lds_u32* keys = (lds_u32*)(uintptr_t)c.scratch;
-    lds_u32* rk = keys + SLOTS;
+    lds_u32* rk = keys + SLOTS + (uint32_t)c.g0;  // one rank table per codeword (CTX::LCW entries)
+    const uint32_t slot0 = ((uint32_t)c.g0 << LPL) * CPL;  // first key slot of this lane's codeword
     uint32_t key[CPL];
     bool valid[CPL];
 #pragma unroll
     for (int r = 0; r < CPL; ++r) {
         const uint32_t q = (uint32_t)c.j * CPL + r;
-        valid[r] = (q < (uint32_t)CPP) && ((uint32_t)c.p < c.P);
+        valid[r] = (q < (uint32_t)CPP) && ((uint32_t)c.pl < c.P);
         key[r] = valid[r] ? okey(val[r]) : 0u;  // 0 is below every real key
         keys[(uint32_t)c.lane * CPL + r] = key[r];
     }
@@ -1203,7 +1285,7 @@ __device__ __forceinline__ bool select_ranked(const CTX& c, const float (&val)[(
     for (int r = 0; r < CPL; ++r) gt[r] = 0;
     const uint32_t nslots = (c.P * LP * CPL + 3u) & ~3u;  // slots of dead paths hold 0
     for (uint32_t s4 = 0; s4 < nslots; s4 += 4) {
-        const u32x4 k = *(const lds_u32x4*)(uintptr_t)(c.scratch + s4);
+        const u32x4 k = *(const lds_u32x4*)(uintptr_t)(c.scratch + slot0 + s4);
 #pragma unroll
         for (int r = 0; r < CPL; ++r) {
             gt[r] += (k.x > key[r]) ? 1u : 0u;
@@ -1226,11 +1308,11 @@ __device__ __forceinline__ bool select_ranked(const CTX& c, const float (&val)[(
     if (ballot64(lost) != 0) return false;
     nval = 0.0f;
     nidx = 0;
-    if ((uint32_t)c.p < newP) {
-        const uint32_t id = rk[c.p];
+    if ((uint32_t)c.pl < newP) {
+        const uint32_t id = rk[c.pl];
         nval = unkey(keys[id]);
         const uint32_t sl = id / CPL, r = id % CPL;
-        nidx = (sl >> LPL) * CPP + (sl & (uint32_t)(LP - 1)) * CPL + r;
+        nidx = ((sl >> LPL) - (uint32_t)c.g0) * CPP + (sl & (uint32_t)(LP - 1)) * CPL + r;
     }
     return true;
 }
@@ -1241,22 +1323,25 @@ __device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP 
 {
     if (c.ablate & 1u) {  // perf experiment (diagnostic build only): no selection
         nval = val[0];
-        nidx = (uint32_t)c.p * CPP;
+        nidx = (uint32_t)c.pl * CPP;
         return;
     }
+    nval = 0.0f;
+    nidx = 0;
     if constexpr (LPL == 3) {
-        select_ranked8<CTX, CPP>(c, val[0], newP, nval, nidx);
-        return;
+        if (select_ranked8<CTX, CPP>(c, val[0], newP, nval, nidx)) return;
     } else if (c.P * CPP > newP) {
         // (when every candidate survives, the reference leaves the last position unsorted: literal code below)
         if (select_ranked<CTX, LPL, CPP>(c, val, newP, nval, nidx)) return;
     }
-    if constexpr (LPL == 3)
-        ;
-    else if constexpr (CPP <= (1 << LPL))
-        select_paths_1<CTX, LPL, CPP>(c, val[0], newP, nval, nidx);
-    else
-        select_paths<CTX, LPL, CPP>(c, val, newP, nval, nidx);
+    // literal emulation of the reference's swap order, one codeword of the wave at a time
+#pragma unroll
+    for (int t = 0; t < CTX::CW; ++t) {
+        if constexpr (CPP <= (1 << LPL))
+            select_paths_1<CTX, LPL, CPP>(c, val[0], newP, nval, nidx, t * CTX::LCW);
+        else
+            select_paths<CTX, LPL, CPP>(c, val, newP, nval, nidx, t * CTX::LCW);
+    }
 }
 
 // write the n leaf bits of every (new) path: sign(x_src[i]) ^ flips, packed, into area(side)[stage]
@@ -1304,10 +1389,13 @@ __device__ __forceinline__ float4 virt_top4(const void* chan, uint32_t halfN, ui
 }
 
 // 4 waves per SIMD (<= 128 VGPRs) for the L <= 8 production kernels: occupancy is what hides the LDS / arena latency
-template <int LPL, bool I8, bool S64, bool DIAG, bool HB>
-__global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_kernel(DecodeParams P)
+template <int LPL, bool I8, bool S64, bool DIAG, bool HB, int CWL>
+// (at most 128 VGPRs for the kernels that reach 16 waves per CU; capping at 96 for 20 waves measured slower: spills)
+__global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void scl_decode_kernel(DecodeParams P)
 {
-    using Ctx = SclCtx<LPL, S64, HB>;
+    using Ctx = SclCtx<LPL, S64, HB, CWL>;
+    constexpr int LCW = Ctx::LCW;  // path groups per codeword
+    constexpr int CW = Ctx::CW;    // codewords per wave
     constexpr int LP = Ctx::LP;
     constexpr int LMAX = Ctx::LMAX;
     constexpr int NACC = Ctx::NACC;
@@ -1337,6 +1425,8 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
     c.ablate = DIAG ? P.ablate : 0u;
     c.lane = lane;
     c.p = lane >> LPL;
+    c.pl = c.p & (LCW - 1);
+    c.g0 = c.p & ~(LCW - 1);
     c.j = lane & (LP - 1);
     c.base = lane & ~(LP - 1);
     c.L = P.L;
@@ -1344,10 +1434,29 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
     const uint32_t wave0 = blockIdx.x * wpb + wib, nwaves = gridDim.x * wpb;
     const const_u64_ptr prog64 = (const_u64_ptr)(uintptr_t)P.prog;
 
-    for (uint32_t cw = wave0; cw < P.rows; cw += nwaves) {
-        const uint32_t row = P.rowidx ? P.rowidx[cw] : cw;
-        const void* chan = I8 ? (const void*)(reinterpret_cast<const int8_t*>(P.llr) + (size_t)row * N)
-                              : (const void*)(reinterpret_cast<const float*>(P.llr) + (size_t)row * N);
+    const uint32_t ngroups = (P.rows + CW - 1) / CW;
+    const uint32_t mycw = (uint32_t)c.p >> (6 - LPL - CWL);  // which of the wave's codewords this lane works for
+    for (uint32_t cw = wave0; cw < ngroups; cw += nwaves) {
+        // channel rows of the wave's codewords (wave uniform); the last group may be ragged: idle slots decode the
+        // group's first row again and store nothing
+        const void* chanv[CW];
+#pragma unroll
+        for (int t = 0; t < CW; ++t) {
+            const uint32_t ci = cw * CW + t, cl = ci < P.rows ? ci : cw * CW;
+            const uint32_t r = P.rowidx ? P.rowidx[cl] : cl;
+            chanv[t] = I8 ? (const void*)(reinterpret_cast<const int8_t*>(P.llr) + (size_t)r * N)
+                          : (const void*)(reinterpret_cast<const float*>(P.llr) + (size_t)r * N);
+        }
+        auto chan_of = [&](uint32_t t) -> const void* {  // (t: per lane)
+            const void* r = chanv[0];
+#pragma unroll
+            for (int k = 1; k < CW; ++k) r = (t == (uint32_t)k) ? chanv[k] : r;
+            return r;
+        };
+        const uint32_t cwi = cw * CW + mycw;
+        const bool live = cwi < P.rows;
+        const uint32_t row = P.rowidx ? P.rowidx[live ? cwi : cw * CW] : (live ? cwi : cw * CW);
+        const void* chan = chan_of(mycw);
         c.chan = chan;
         // makeInitialPathList :705-709 -- one path, metric 0 (fresh decoder)
         c.P = 1;
@@ -1368,7 +1477,19 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
             // host flags (capi.cpp, specialize_scl): 2 = the output stage is virtual (nothing to store),
             // 4 = the input stage is virtual (recomputed from the channel row), 8 = ... of the root's RIGHT child
             const uint32_t vflags = ins.side & 0xEu;
-            const bool active = (uint32_t)c.p < c.P;
+            const bool active = (uint32_t)c.pl < c.P;
+            // wide ops walk the live paths of all codewords of the wave: path number ql in [0, CW * P) -> its group
+            // (= path buffer) and codeword t
+            auto item_group = [&](uint32_t ql, uint32_t& t) -> uint32_t {
+                if constexpr (CWL == 0) {
+                    t = 0;
+                    return ql;
+                } else {
+                    t = (ql >= c.P) ? 1u : 0u;
+                    if constexpr (CW > 2) t += ((ql >= 2u * c.P) ? 1u : 0u) + ((ql >= 3u * c.P) ? 1u : 0u);
+                    return t * (uint32_t)LCW + (ql - t * c.P);
+                }
+            };
             uint64_t t_start = 0;
             if (DIAG && P.cycles && cw == 0) t_start = __builtin_amdgcn_s_memtime();
 #define PAMD_STAMP(k)                                                                             \
@@ -1410,6 +1531,37 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                     wk.v[0] = wk.v[1] = wk.v[2] = wk.v[3] = 0x3F800000u;
                     wk.ix[0] = 0; wk.ix[1] = 1; wk.ix[2] = 2; wk.ix[3] = 3;
                 } else
+                if constexpr (LPL == 2) {
+                    if (small && !(DIAG && (P.ablate & 2u))) {  // n <= 8: positions j and j + 4 of the block in lane j
+                        constexpr uint32_t INFB = 0xFFFFFFFFu;
+                        const float* xb = c.path_llr(c.p) + n;
+                        const bool in0 = (uint32_t)c.j < n, in1 = n == 8;
+                        const float x0 = xb[in0 ? c.j : 0], x1 = xb[in1 ? c.j + 4 : 0];
+                        const uint32_t a0 = in0 ? (fbits(x0) & 0x7FFFFFFFu) : INFB, a1 = in1 ? (fbits(x1) & 0x7FFFFFFFu) : INFB;
+                        if (spc) {
+                            if (s == 2)
+                                find_weak_small4<2, 4>(a0, a1, c.j, wk);
+                            else
+                                find_weak_small4<3, 4>(a0, a1, c.j, wk);
+                            const uint64_t sg = ballot64(in0 && sgn(x0)) ^ ballot64(in1 && sgn(x1));
+                            par = (uint32_t)__popc((uint32_t)(sg >> c.base) & 0xFu) & 1u;
+                        } else {
+                            Weak<2> w2;
+                            if (s == 1)
+                                find_weak_small4<1, 2>(a0, a1, c.j, w2);
+                            else if (s == 2)
+                                find_weak_small4<2, 2>(a0, a1, c.j, w2);
+                            else
+                                find_weak_small4<3, 2>(a0, a1, c.j, w2);
+                            wk.v[0] = w2.v[0];
+                            wk.v[1] = w2.v[1];
+                            wk.ix[0] = w2.ix[0];
+                            wk.ix[1] = w2.ix[1];
+                            wk.v[2] = wk.v[3] = 0;
+                            wk.ix[2] = wk.ix[3] = 0;
+                        }
+                    }
+                }
                 if constexpr (LPL == 3) {
                     if (small && !(DIAG && (P.ablate & 2u))) {
                         constexpr uint32_t INFB = 0xFFFFFFFFu;
@@ -1491,7 +1643,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                     select_dispatch<Ctx, LPL, 4>(c, val, m, newP, nval, nidx);
                 }
                 PAMD_STAMP(1)
-                const uint32_t srcp = spc ? (nidx >> 3) : (nidx >> 2);
+                const uint32_t srcp = (uint32_t)c.g0 + (spc ? (nidx >> 3) : (nidx >> 2));  // the source path's group
                 const uint32_t q = spc ? (nidx & 7u) : (nidx & 3u);
                 const int sl = (int)(srcp << LPL);
                 const typename Ctx::SlotT nslot = c.slot_from_lane(sl);
@@ -1509,14 +1661,31 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                     fmask = q;
                 }
                 c.P = newP;
-                const bool nact = (uint32_t)c.p < c.P;
+                const bool nact = (uint32_t)c.pl < c.P;
                 if (nact) {
                     c.metric = nval;
                     c.slot = nslot;
                 }
                 PAMD_STAMP(2)
                 // bits of the new path = signs of the SOURCE path's LLRs (identity buffer) with flips
-                if (small) {  // n <= 8: one LLR of the SOURCE path per lane, one ballot byte per path
+                if (small && LPL == 2) {  // n <= 8: LLRs j and j + 4 of the SOURCE path per lane, two ballot nibbles per path
+                    const float* xs = c.path_llr(srcp) + n;
+                    const bool in0 = (uint32_t)c.j < n, in1 = n == 8;
+                    uint32_t b0 = 0, b1 = 0;
+                    if (nact && in0) {
+                        b0 = sgn(xs[c.j]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) b0 ^= (((fmask >> k) & 1u) && fpos[k] == (uint32_t)c.j) ? 1u : 0u;
+                    }
+                    if (nact && in1) {
+                        b1 = sgn(xs[c.j + 4]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) b1 ^= (((fmask >> k) & 1u) && fpos[k] == (uint32_t)c.j + 4u) ? 1u : 0u;
+                    }
+                    const uint64_t bal0 = ballot64(b0 != 0), bal1 = ballot64(b1 != 0);
+                    if (nact && c.j == 0)
+                        (c.area(side, c.p) + woff(s))[0] = ((uint32_t)(bal0 >> c.base) & 0xFu) | (((uint32_t)(bal1 >> c.base) & 0xFu) << 4);
+                } else if (small) {  // n <= 8: one LLR of the SOURCE path per lane, one ballot byte per path
                     const bool in = (uint32_t)c.j < n;
                     uint32_t b = 0;
                     if (nact && in) {
@@ -1534,7 +1703,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
             const uint32_t aux = (uint32_t)(iw >> 32);
             const uint32_t wo_s = aux & 0x1FFu, wo_c = (aux >> 9) & 0x1FFu, fsh = (aux >> 18) & 0x3Fu;
             const bool skip_small = DIAG && (P.ablate & 16u);
-            if constexpr (LPL == 3) {
+            if constexpr (LPL == 3 || LPL == 2) {
                 if (ins.op == SCL_SPC_S) {
                     fork_leaf(std::true_type{}, std::true_type{});
                     goto op_done;
@@ -1550,26 +1719,26 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                     float* d = c.path_llr(c.p) + h;
                     for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_f(x[i], x[h + i]);
                 }
-                c.slot = (c.slot & ~((typename Ctx::SlotT)(LMAX - 1) << fsh)) | ((typename Ctx::SlotT)c.p << fsh);
+                c.slot = (c.slot & ~((typename Ctx::SlotT)(LCW - 1) << fsh)) | ((typename Ctx::SlotT)c.pl << fsh);
             } else if (ins.op == SCL_G_S) {  // G, both stages in LDS, h <= 32: one left-bit word
                 if (active && !skip_small) {
-                    const uint32_t srcq = (uint32_t)(c.slot >> fsh) & (uint32_t)(LMAX - 1);
+                    const uint32_t srcq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> fsh) & (uint32_t)(LCW - 1));
                     const float* x = c.path_llr(srcq) + n;
                     float* d = c.path_llr(c.p) + h;
                     const uint32_t lw = (c.area(0, c.p) + wo_c)[0];
                     for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
                 }
-                c.slot = (c.slot & ~((typename Ctx::SlotT)(LMAX - 1) << fsh)) | ((typename Ctx::SlotT)c.p << fsh);
+                c.slot = (c.slot & ~((typename Ctx::SlotT)(LCW - 1) << fsh)) | ((typename Ctx::SlotT)c.pl << fsh);
             } else if (ins.op == SCL_C_S) {  // COMBINE, h < 32
                 if (active && c.j == 0 && !skip_small) {
-                    const uint32_t lq = (uint32_t)(c.slot >> fsh) & (uint32_t)(LMAX - 1);
+                    const uint32_t lq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> fsh) & (uint32_t)(LCW - 1));
                     const uint32_t mask = (1u << h) - 1u;
                     const uint32_t r = (c.area(1, c.p) + wo_c)[0] & mask;
                     (c.area(side, c.p) + wo_s)[0] = (((c.area(0, lq) + wo_c)[0] ^ r) & mask) | (r << h);
                 }
             } else if (ins.op == SCL_C_W) {  // COMBINE, h >= 32
                 if (active && !skip_small) {
-                    const uint32_t lq = (uint32_t)(c.slot >> fsh) & (uint32_t)(LMAX - 1);
+                    const uint32_t lq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> fsh) & (uint32_t)(LCW - 1));
                     const uint32_t* lb = c.bits(0, lq, s - 1);
                     const uint32_t* rb = c.bits(1, c.p, s - 1);
                     uint32_t* ob = c.bits(side, c.p, s);
@@ -1586,18 +1755,18 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                 } else if (vflags & 2u) {
                     // the output stage is virtual: its consumers recompute it from the channel row
                 } else if (vflags & 4u) {
-                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
+                    const uint32_t ish = s - 3, ipp = h >> 2, total = (c.P * CW) << ish;
                     const bool right = (vflags & 8u) != 0, dst_arena = (s - 1) >= c.s0;
-                    const uint32_t wtop = woff(logN - 1);
 #pragma unroll 2
                     for (uint32_t e0 = 0; e0 < total; e0 += 64) {
                         const uint32_t e = e0 + lane;
                         const bool in = e < total;
-                        const uint32_t q = in ? (e >> ish) : 0u, i = (e & (ipp - 1)) << 2;
-                        const uint32_t holder = c.field(c.slot_from_lane((int)(q << LPL)), logN);
+                        uint32_t ct;
+                        const uint32_t q = item_group(in ? (e >> ish) : 0u, ct), i = (e & (ipp - 1)) << 2;
+                        const uint32_t holder = c.field(c.slot_from_lane((int)(q << LPL)), logN, q);
                         if (in) {
                             const uint32_t* rl = c.bits(0, holder, logN - 1);
-                            const float4 a = virt_top4<I8>(chan, N >> 1, i, right, rl), b = virt_top4<I8>(chan, N >> 1, h + i, right, rl);
+                            const float4 a = virt_top4<I8>(chan_of(ct), N >> 1, i, right, rl), b = virt_top4<I8>(chan_of(ct), N >> 1, h + i, right, rl);
                             const float4 r = make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z),
                                                          polar_f(a.w, b.w));
                             if (dst_arena)
@@ -1608,14 +1777,15 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                     }
                 } else if (h >= 64) {
                     // 16-byte items: item e = (path q, 4 consecutive LLRs); several loads in flight per lane
-                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
+                    const uint32_t ish = s - 3, ipp = h >> 2, total = (c.P * CW) << ish;
                     c.template with_src_kind<I8>(s, [&](auto KS) {
                         constexpr int SK = decltype(KS)::value;
                         const bool dst_arena = (s - 1) >= c.s0;
 #pragma unroll 2
                         for (uint32_t e = lane; e < total; e += 64) {
-                            const uint32_t q = e >> ish, i = (e & (ipp - 1)) << 2;
-                            const Rd<SK> x{ c.template src_base<SK>(s, q) };
+                            uint32_t ct;
+                            const uint32_t q = item_group(e >> ish, ct), i = (e & (ipp - 1)) << 2;
+                            const Rd<SK> x{ (SK == K_GF32 || SK == K_GI8) ? chan_of(ct) : c.template src_base<SK>(s, q) };
                             const float4 a = x.ld4(i), b = x.ld4(h + i);
                             const float4 r = make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z),
                                                          polar_f(a.w, b.w));
@@ -1646,18 +1816,18 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                 } else if (vflags & 2u) {
                     // virtual output stage: only the slot-word update below remains
                 } else if (vflags & 4u) {
-                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
+                    const uint32_t ish = s - 3, ipp = h >> 2, total = (c.P * CW) << ish;
                     const bool right = (vflags & 8u) != 0, dst_arena = (s - 1) >= c.s0;
-                    const uint32_t wtop = woff(logN - 1);
 #pragma unroll 2
                     for (uint32_t e0 = 0; e0 < total; e0 += 64) {
                         const uint32_t e = e0 + lane;
                         const bool in = e < total;
-                        const uint32_t q = in ? (e >> ish) : 0u, i = (e & (ipp - 1)) << 2;
-                        const uint32_t holder = c.field(c.slot_from_lane((int)(q << LPL)), logN);
+                        uint32_t ct;
+                        const uint32_t q = item_group(in ? (e >> ish) : 0u, ct), i = (e & (ipp - 1)) << 2;
+                        const uint32_t holder = c.field(c.slot_from_lane((int)(q << LPL)), logN, q);
                         if (in) {
                             const uint32_t* rl = c.bits(0, holder, logN - 1);
-                            const float4 a = virt_top4<I8>(chan, N >> 1, i, right, rl), b = virt_top4<I8>(chan, N >> 1, h + i, right, rl);
+                            const float4 a = virt_top4<I8>(chan_of(ct), N >> 1, i, right, rl), b = virt_top4<I8>(chan_of(ct), N >> 1, h + i, right, rl);
                             const uint32_t u = (c.bits(0, q, s - 1)[i >> 5] >> (i & 31u)) & 0xFu;
                             const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
                                                          polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, u >> 3));
@@ -1668,7 +1838,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                         }
                     }
                 } else if (h >= 64) {
-                    const uint32_t ish = s - 3, ipp = h >> 2, total = c.P << ish;
+                    const uint32_t ish = s - 3, ipp = h >> 2, total = (c.P * CW) << ish;
                     c.template with_src_kind<I8>(s, [&](auto KS) {
                         constexpr int SK = decltype(KS)::value;
                         const bool dst_arena = (s - 1) >= c.s0;
@@ -1676,11 +1846,12 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                         for (uint32_t e0 = 0; e0 < total; e0 += 64) {
                             const uint32_t e = e0 + lane;
                             const bool in = e < total;
-                            const uint32_t q = in ? (e >> ish) : 0u, i = (e & (ipp - 1)) << 2;
+                            uint32_t ct;
+                        const uint32_t q = item_group(in ? (e >> ish) : 0u, ct), i = (e & (ipp - 1)) << 2;
                             // LLR[s] of path q lives in the buffer its slot word names (all lanes take part in the move)
-                            const uint32_t srcq = c.field(c.slot_from_lane((int)(q << LPL)), s);
+                            const uint32_t srcq = c.field(c.slot_from_lane((int)(q << LPL)), s, q);
                             if (in) {
-                                const Rd<SK> x{ c.template src_base<SK>(s, srcq) };
+                                const Rd<SK> x{ (SK == K_GF32 || SK == K_GI8) ? chan_of(ct) : c.template src_base<SK>(s, srcq) };
                                 const float4 a = x.ld4(i), b = x.ld4(h + i);
                                 const uint32_t u = (c.bits(0, q, s - 1)[i >> 5] >> (i & 31u)) & 0xFu;
                                 const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
@@ -1694,13 +1865,13 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                     });
                 } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case); h <= 32: one bit word
                     if (active) {
-                        const float* x = c.path_llr(c.field(c.slot, s)) + n;
+                        const float* x = c.path_llr(c.field(c.slot, s, (uint32_t)c.p)) + n;
                         float* d = c.path_llr(c.p) + h;
                         const uint32_t lw = (c.area(0, c.p) + wo)[0];
                         for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
                     }
                 } else if (active) {
-                    const uint32_t srcq = c.field(c.slot, s);
+                    const uint32_t srcq = c.field(c.slot, s, (uint32_t)c.p);
                     const uint32_t* lb = c.area(0, c.p) + wo;
                     c.template with_src<I8>(s, srcq, [&](auto x) {
                         c.with_dst(s - 1, c.p, [&](auto d) {
@@ -1712,7 +1883,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                 c.set_field(s);  // from now on the field names the holder of the LEFT bits
             } else if (ins.op == SCL_COMBINE) {  // :253-260 CombineBitsLong / CombineBitsShort
                 if (active && !(DIAG && (P.ablate & 16u))) {
-                    const uint32_t lq = c.field(c.slot, s);
+                    const uint32_t lq = c.field(c.slot, s, (uint32_t)c.p);
                     const uint32_t* lb = c.bits(0, lq, s - 1);
                     const uint32_t* rb = c.bits(1, c.p, s - 1);
                     uint32_t* ob = c.bits(side, c.p, s);
@@ -1785,10 +1956,10 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                 float nval;
                 uint32_t nidx;
                 select_dispatch<Ctx, LPL, 2>(c, val, (c.metric + z > c.metric - o) ? c.metric + z : c.metric - o, newP, nval, nidx);
-                const uint32_t srcp = nidx >> 1, q = nidx & 1u;
+                const uint32_t srcp = (uint32_t)c.g0 + (nidx >> 1), q = nidx & 1u;
                 const typename Ctx::SlotT nslot = c.slot_from_lane((int)(srcp << LPL));
                 c.P = newP;
-                if ((uint32_t)c.p < c.P) {
+                if ((uint32_t)c.pl < c.P) {
                     c.metric = nval;
                     c.slot = nslot;
                     if (c.j == 0) (c.area(side, c.p) + woff(s))[0] = q ? ((1u << n) - 1u) : 0u;
@@ -1814,7 +1985,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                 if (trace_n < P.trace_cap) {
                     float* t = P.trace + (size_t)trace_n * (1 + P.L);
                     if (lane == 0) t[0] = (float)c.P;
-                    if (c.j == 0 && (uint32_t)c.p < P.L) t[1 + c.p] = ((uint32_t)c.p < c.P) ? c.metric : 0.0f;
+                    if (mycw == 0 && c.j == 0 && (uint32_t)c.pl < P.L) t[1 + c.pl] = ((uint32_t)c.pl < c.P) ? c.metric : 0.0f;
                 }
                 ++trace_n;
             }
@@ -1822,7 +1993,7 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
 
         if (DIAG && (P.ablate & 32u)) continue;
         // ---- SclAvxFloat::extractBestPath :711-750 ---------------------------------------------
-        const bool active = (uint32_t)c.p < c.P;
+        const bool active = (uint32_t)c.pl < c.P;
         uint32_t* cwbits = c.bits(0, c.p, logN);
         const uint32_t nwords = N >= 32 ? (N >> 5) : 1u;
         if (!P.systematic) {  // re-encode every candidate (:731-746)
@@ -1845,19 +2016,21 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
                 WAVE_SYNC();
             }
         }
-        // detector verdict of every path in parallel (syndrome XOR), first passing path wins
-        uint32_t winner = 0, okflag = 1;
+        // detector verdict of every path in parallel (syndrome XOR), first passing path of each codeword wins
+        constexpr int LCWL = 64 >> CWL;                 // lanes per codeword
+        const uint32_t lane0 = (uint32_t)c.g0 << LPL;   // first lane of this lane's codeword
+        uint32_t winner = (uint32_t)c.g0, okflag = 1;   // (group of the winning path; per codeword)
         bool best_passes = false;
         if (P.det_on) {
-            // the best path passes for almost every codeword: check it alone with all 64 lanes first
-            const uint32_t* b0 = c.bits(0, 0, logN);
+            // the best path passes for almost every codeword: check it alone with all lanes of the codeword first
+            const uint32_t* b0 = c.bits(0, (uint32_t)c.g0, logN);
             uint32_t syn0 = 0;
-            for (uint32_t t = lane; t < P.K; t += 64) {
+            for (uint32_t t = (uint32_t)lane - lane0; t < P.K; t += LCWL) {
                 const uint32_t pos = P.lut[t];
                 if ((b0[pos >> 5] >> (pos & 31u)) & 1u) syn0 ^= P.syn[t];
             }
-            syn0 = group_xor_u32<64>(syn0);
-            best_passes = __builtin_amdgcn_readfirstlane(syn0) == 0;
+            syn0 = group_xor_u32<LCWL>(syn0);
+            best_passes = ballot64(syn0 != 0) == 0;  // ... of every codeword of the wave
         }
         if (P.det_on && !best_passes) {
             uint32_t syn = 0;
@@ -1869,34 +2042,40 @@ __global__ __launch_bounds__(256, (LPL == 3 && !DIAG) ? 4 : 1) void scl_decode_k
             }
 #pragma unroll
             for (int m = 1; m < LP; m <<= 1) syn ^= shflx_u32(syn, m);
-            const uint64_t pass = ballot64(active && c.j == 0 && syn == 0);
-            if (pass) {
-                winner = (uint32_t)(__ffsll((long long)pass) - 1) >> LPL;
+            const uint64_t pass = ballot64(active && c.j == 0 && syn == 0) >> lane0;
+            const uint64_t mine = CWL == 0 ? pass : (pass & ((1ull << (LCWL & 63)) - 1ull));
+            if (mine) {
+                winner = (uint32_t)c.g0 + ((uint32_t)(__ffsll((long long)mine) - 1) >> LPL);
             } else {
-                winner = 0;
+                winner = (uint32_t)c.g0;
                 okflag = 0;
             }
         }
-        {
-            const uint32_t* wb = c.bits(0, winner, logN);
-            uint8_t* orow = P.out + (size_t)row * P.nb;
+#pragma unroll
+        for (int t = 0; t < CW; ++t) {  // the information bits of each codeword's winner, 64 at a time with the whole wave
+            const uint32_t ci = cw * CW + t;
+            const bool live_t = ci < P.rows;
+            const uint32_t row_t = P.rowidx ? P.rowidx[live_t ? ci : cw * CW] : ci;
+            const uint32_t wg = CWL == 0 ? winner : readlane_u32(winner, t * LCWL);
+            const uint32_t* wb = c.bits(0, wg, logN);
+            uint8_t* orow = P.out + (size_t)row_t * P.nb;
             for (uint32_t t0 = 0; t0 < P.K; t0 += 64) {
-                const uint32_t t = t0 + lane;
+                const uint32_t tt = t0 + lane;
                 uint32_t bit = 0;
-                if (t < P.K) {
-                    const uint32_t pos = P.lut[t];
+                if (tt < P.K) {
+                    const uint32_t pos = P.lut[tt];
                     bit = (wb[pos >> 5] >> (pos & 31u)) & 1u;
                 }
                 const uint64_t m = ballot64(bit != 0);
-                if (lane < 8) {
+                if (lane < 8 && live_t) {
                     const uint32_t byte = (t0 >> 3) + lane;
                     if (byte < P.nb) orow[byte] = (uint8_t)(__brev((uint32_t)((m >> (8 * lane)) & 0xFFu)) >> 24);
                 }
             }
         }
-        if (lane == 0 && P.ok) P.ok[row] = (uint8_t)okflag;
-        if (P.metrics) {
-            if (c.j == 0 && (uint32_t)c.p < P.L) P.metrics[(size_t)row * P.L + c.p] = active ? c.metric : 0.0f;
+        if ((uint32_t)lane == lane0 && live && P.ok) P.ok[row] = (uint8_t)okflag;
+        if (P.metrics && live) {
+            if (c.j == 0 && (uint32_t)c.pl < P.L) P.metrics[(size_t)row * P.L + c.pl] = active ? c.metric : 0.0f;
         }
         WAVE_SYNC();
     }
@@ -1918,19 +2097,19 @@ __global__ void collect_failed_kernel(const uint8_t* ok, uint32_t rows, uint32_t
 // =============================================================================================
 //  launchers
 // =============================================================================================
-// grid == 0: do not launch, report the resident workgroups per CU for this block size / LDS size in *occ
-template <int LPL, bool I8, bool S64, bool DIAG, bool HB>
+// occ != nullptr: do not launch, report the resident workgroups per CU for this block size / LDS size in *occ
+template <int LPL, bool I8, bool S64, bool DIAG, bool HB, int CWL>
 static hipError_t launch_scl_k(const DecodeParams& P, dim3 grid, dim3 block, size_t lds, hipStream_t st, int* occ)
 {
+    auto kern = scl_decode_kernel<LPL, I8, S64, DIAG, HB, CWL>;
     if (occ) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG, HB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, scl_decode_kernel<LPL, I8, S64, DIAG, HB>, (int)block.x, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kern, (int)block.x, lds);
         if (e != hipSuccess) return e;
         // the API over-reports for single-wave workgroups: clamp by the register file (512 VGPRs per SIMD lane,
         // allocation granule 8, at most 8 waves per SIMD; MI355X_MICROARCH.md "Register files")
         hipFuncAttributes fa;
-        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG, HB>));
+        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
         if (e != hipSuccess) return e;
         const int regs = ((fa.numRegs > 0 ? fa.numRegs : 1) + 7) & ~7;
         int waves_per_simd = 512 / regs;
@@ -1940,32 +2119,38 @@ static hipError_t launch_scl_k(const DecodeParams& P, dim3 grid, dim3 block, siz
         if (*occ > by_regs) *occ = by_regs;
         return hipSuccess;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scl_decode_kernel<LPL, I8, S64, DIAG, HB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((scl_decode_kernel<LPL, I8, S64, DIAG, HB>), grid, block, lds, st, P);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, P);
     return hipGetLastError();
 }
 
-// Instantiations: the production kernels (no diagnostics) for every lanes-per-path split, with a 64-bit slot
-// word, with and without the high-stage bit blocks in the arena; a 32-bit slot word variant for L <= 8 when
-// log2(N) * 3 <= 32 (the headline configuration); and a diagnostic variant (trace / cycle stamps / ablation
-// switches) for float input only.
-template <int LPL>
-static hipError_t launch_scl_t(const DecodeParams& P, bool i8, bool slot64, bool diag, dim3 grid, dim3 block, size_t lds,
+// Instantiations per (lanes per path, codewords per wave): production kernels with a 64-bit slot word, with and
+// without the high-stage bit blocks in the arena; a 32-bit slot word where log2(N) * (bits per slot field) <= 32
+// (the headline configuration among them); and a diagnostic variant (trace / cycle stamps / ablation switches)
+// for float input only.
+template <int LPL, int CWL>
+static hipError_t launch_scl_t(const DecodeParams& P, bool i8, bool diag, dim3 grid, dim3 block, size_t lds,
                                hipStream_t st, int* occ)
 {
-    const bool hb = P.sb <= P.logN;  // high-stage bit blocks in the arena
-    if (diag && !i8) return launch_scl_k<LPL, false, true, true, true>(P, grid, block, lds, st, occ);
-    if constexpr (LPL == 3) {
+    constexpr unsigned fb = 6u - LPL - CWL;    // bits per slot field
+    const bool slot64 = P.logN * fb > 32u;
+    const bool hb = P.sb <= P.logN;            // high-stage bit blocks in the arena
+    if (diag && !i8) return launch_scl_k<LPL, false, true, true, true, CWL>(P, grid, block, lds, st, occ);
+    if constexpr (fb <= 3) {
         if (!slot64 && !hb)
-            return i8 ? launch_scl_k<LPL, true, false, false, false>(P, grid, block, lds, st, occ)
-                      : launch_scl_k<LPL, false, false, false, false>(P, grid, block, lds, st, occ);
+            return i8 ? launch_scl_k<LPL, true, false, false, false, CWL>(P, grid, block, lds, st, occ)
+                      : launch_scl_k<LPL, false, false, false, false, CWL>(P, grid, block, lds, st, occ);
     }
-    if (hb)
-        return i8 ? launch_scl_k<LPL, true, true, false, true>(P, grid, block, lds, st, occ)
-                  : launch_scl_k<LPL, false, true, false, true>(P, grid, block, lds, st, occ);
-    return i8 ? launch_scl_k<LPL, true, true, false, false>(P, grid, block, lds, st, occ)
-              : launch_scl_k<LPL, false, true, false, false>(P, grid, block, lds, st, occ);
+    if constexpr (fb <= 2) {  // log2(N) * fb <= 32 for every supported N: no 64-bit variant needed
+        return i8 ? launch_scl_k<LPL, true, false, false, true, CWL>(P, grid, block, lds, st, occ)
+                  : launch_scl_k<LPL, false, false, false, true, CWL>(P, grid, block, lds, st, occ);
+    } else {
+        if (hb)
+            return i8 ? launch_scl_k<LPL, true, true, false, true, CWL>(P, grid, block, lds, st, occ)
+                      : launch_scl_k<LPL, false, true, false, true, CWL>(P, grid, block, lds, st, occ);
+        return i8 ? launch_scl_k<LPL, true, true, false, false, CWL>(P, grid, block, lds, st, occ)
+                  : launch_scl_k<LPL, false, true, false, false, CWL>(P, grid, block, lds, st, occ);
+    }
 }
 
 template <int LCL, bool I8>
@@ -1995,14 +2180,15 @@ hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, un
 {
     dim3 g(grid), b(64 * waves_per_block);
     const bool diag = P.trace || P.cycles || P.ablate;
-    const unsigned fb = 6u - (unsigned)lpl;
-    const bool slot64 = P.logN * fb > 32u;
-    switch (lpl) {
-    case 1: return launch_scl_t<1>(P, i8, slot64, diag, g, b, lds, st, occupancy);
-    case 2: return launch_scl_t<2>(P, i8, slot64, diag, g, b, lds, st, occupancy);
-    case 3: return launch_scl_t<3>(P, i8, slot64, diag, g, b, lds, st, occupancy);
-    case 4: return launch_scl_t<4>(P, i8, slot64, diag, g, b, lds, st, occupancy);
-    case 5: return launch_scl_t<5>(P, i8, slot64, diag, g, b, lds, st, occupancy);
+    switch (lpl * 4 + (int)P.cwl) {  // (log2 lanes per path, log2 codewords per wave)
+    case 1 * 4 + 0: return launch_scl_t<1, 0>(P, i8, diag, g, b, lds, st, occupancy);
+    case 2 * 4 + 0: return launch_scl_t<2, 0>(P, i8, diag, g, b, lds, st, occupancy);
+    case 3 * 4 + 0: return launch_scl_t<3, 0>(P, i8, diag, g, b, lds, st, occupancy);
+    case 4 * 4 + 0: return launch_scl_t<4, 0>(P, i8, diag, g, b, lds, st, occupancy);
+    case 5 * 4 + 0: return launch_scl_t<5, 0>(P, i8, diag, g, b, lds, st, occupancy);
+    case 2 * 4 + 1: return launch_scl_t<2, 1>(P, i8, diag, g, b, lds, st, occupancy);  // L <= 8: 4 lanes per path, 2 codewords
+    case 3 * 4 + 1: return launch_scl_t<3, 1>(P, i8, diag, g, b, lds, st, occupancy);  // L <= 4: 8 lanes per path, 2 codewords
+    case 3 * 4 + 2: return launch_scl_t<3, 2>(P, i8, diag, g, b, lds, st, occupancy);  // L <= 2: 8 lanes per path, 4 codewords
     default: return hipErrorInvalidValue;
     }
 }
