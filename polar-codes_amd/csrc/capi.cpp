@@ -143,8 +143,9 @@ void compute_geometry(pcd_decoder* d)
         while (lprime < d->L) lprime <<= 1;
         // Several codewords per wave: every codeword follows the same program, so the interpreter's scalar work and
         // the skeleton of the small ops are shared.  L <= 2: 8 lanes per path x 4 codewords; L <= 4: 8 x 2;
-        // L <= 8: 4 lanes per path x 2 codewords (measured at cfg 3: 12.0 -> 15.0 M cw/s against 8 lanes x 1).
-        d->cwl = lprime == 2 ? 2u : (lprime <= 8 ? 1u : 0u);
+        // L <= 8: 4 lanes per path x 2 codewords up to N = 2048 (measured at cfg 3: 12.0 -> 15.4 M cw/s against 8 lanes
+        // x 1; from N = 4096 on the wide F / G passes dominate and 8 lanes x 1 codeword is 5-10 % faster).
+        d->cwl = lprime == 2 ? 2u : (lprime == 4 ? 1u : (lprime == 8 && d->logN <= 11 ? 1u : 0u));
         if (const char* e = std::getenv("PCD_CWL")) {  // experiments: 0 = one codeword per wave; 1 at L <= 8: 4 lanes per path
             const unsigned v = (unsigned)std::atoi(e);
             d->cwl = (lprime == 2 && v <= 2) || (lprime <= 8 && v <= 1) ? v : 0u;
@@ -171,21 +172,38 @@ void compute_geometry(pcd_decoder* d)
         unsigned best_s0 = d->logN, best_sb = d->logN + 1, best_waves = 0;
         const unsigned lo = d->logN < 6 ? d->logN : 6;
         const unsigned sb_lo = 7;  // every op specialised for LDS works on stages <= 6
-        std::vector<unsigned> sbs = { d->logN + 1 };
-        for (unsigned sb = d->logN; sb >= sb_lo; --sb) sbs.push_back(sb);
-        for (unsigned sb : sbs) {
-            for (unsigned s0 = d->logN; s0 + 1 > lo; --s0) {
-                const size_t bytes = (size_t)lds_words(s0, sb) * 4;
-                const unsigned waves = bytes > kMaxLds ? 0u : (unsigned)std::min<size_t>(16, lds_blocks_per_cu(bytes));
-                // bit blocks in the arena turn their accesses into flat_* instructions (measured -4 % at cfg 3):
-                // only taken when they buy resident waves
-                if (waves > best_waves || (waves == best_waves && waves > 0 && s0 > best_s0 && sb == best_sb)) {
-                    best_waves = waves;
-                    best_s0 = s0;
-                    best_sb = sb;
-                }
-                if (s0 == 0) break;
+        auto waves_of = [&](unsigned s0, unsigned sb) {
+            const size_t bytes = (size_t)lds_words(s0, sb) * 4;
+            return bytes > kMaxLds ? 0u : (unsigned)std::min<size_t>(16, lds_blocks_per_cu(bytes));
+        };
+        // all bit blocks in LDS: most waves, then the most LLR stages in LDS
+        for (unsigned s0 = d->logN; s0 + 1 > lo; --s0) {
+            const unsigned waves = waves_of(s0, d->logN + 1);
+            if (waves > best_waves) {
+                best_waves = waves;
+                best_s0 = s0;
             }
+            if (s0 == 0) break;
+        }
+        // bit blocks of stages >= sb in the arena turn their accesses into flat_* instructions (measured -4 % at
+        // cfg 3 with one codeword per wave): only taken when it buys resident waves; then the most LLR stages in
+        // LDS, then the most bit stages (cfg 3, two codewords per wave: s0 = 7 / sb = 7 15.9 M cw/s, 6 / 10 15.4 M)
+        unsigned hb_s0 = 0, hb_sb = 0, hb_waves = 0;
+        for (unsigned s0 = d->logN; s0 + 1 > lo; --s0) {
+            for (unsigned sb = d->logN; sb >= sb_lo; --sb) {
+                const unsigned waves = waves_of(s0, sb);
+                if (waves > hb_waves) {
+                    hb_waves = waves;
+                    hb_s0 = s0;
+                    hb_sb = sb;
+                }
+            }
+            if (s0 == 0) break;
+        }
+        if (hb_waves > best_waves) {
+            best_waves = hb_waves;
+            best_s0 = hb_s0;
+            best_sb = hb_sb;
         }
         if (const char* dbg = std::getenv("PCD_S0")) best_s0 = (unsigned)std::atoi(dbg);  // experiments
         if (const char* dbg = std::getenv("PCD_SB")) best_sb = std::max(sb_lo, (unsigned)std::atoi(dbg));
@@ -643,7 +661,7 @@ int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4])
     if (!d || !info) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (list) {
         if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SCL program");
-        info[0] = d->scl_wave_words * 4;
+        info[0] = (d->scl_wave_words * 4) >> d->cwl;
         info[1] = d->scl_wpb << d->cwl;
         info[2] = 64u >> d->lpl;
         info[3] = (unsigned)(kMaxLds / ((size_t)d->scl_wpb * d->scl_wave_words * 4));

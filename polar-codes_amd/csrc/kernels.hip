@@ -2140,10 +2140,12 @@ static hipError_t launch_scl_t(const DecodeParams& P, bool i8, bool diag, dim3 g
         if (!slot64 && !hb)
             return i8 ? launch_scl_k<LPL, true, false, false, false, CWL>(P, grid, block, lds, st, occ)
                       : launch_scl_k<LPL, false, false, false, false, CWL>(P, grid, block, lds, st, occ);
+        if (!slot64)
+            return i8 ? launch_scl_k<LPL, true, false, false, true, CWL>(P, grid, block, lds, st, occ)
+                      : launch_scl_k<LPL, false, false, false, true, CWL>(P, grid, block, lds, st, occ);
     }
     if constexpr (fb <= 2) {  // log2(N) * fb <= 32 for every supported N: no 64-bit variant needed
-        return i8 ? launch_scl_k<LPL, true, false, false, true, CWL>(P, grid, block, lds, st, occ)
-                  : launch_scl_k<LPL, false, false, false, true, CWL>(P, grid, block, lds, st, occ);
+        return hipErrorInvalidValue;
     } else {
         if (hb)
             return i8 ? launch_scl_k<LPL, true, true, false, true, CWL>(P, grid, block, lds, st, occ)

@@ -89,7 +89,9 @@ def test_accessors_and_defaults(built_library):
     # listSize < 2 with a non-char type selects float SC (decoder.cpp:48-50)
     assert pypolar_amd.PolarDecoder(1024, 1, F, "mixed").listSize() == 1
     info = d.launch_info(True)
-    assert info["path_groups"] == 8 and info["lds_bytes_per_codeword"] * info["workgroups_per_cu_by_lds"] <= 160 * 1024
+    # 8 path groups per codeword; the list kernel decodes two codewords per wave at this size
+    assert info["path_groups"] == 8 * info["codewords_per_workgroup"]
+    assert info["lds_bytes_per_codeword"] * info["codewords_per_workgroup"] * info["workgroups_per_cu_by_lds"] <= 160 * 1024
 
 
 def test_error_mapping(built_library):
