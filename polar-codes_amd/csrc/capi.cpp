@@ -516,7 +516,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
     if (N < 8 || (N & (N - 1)) != 0 || N > 32768)
         return fail(PCD_ERR_INVALID_ARG, "blockLength must be a power of two in [8, 32768]");
     if (list_size == 0) return fail(PCD_ERR_INVALID_ARG, "listSize must be >= 1");
-    if (list_size > 32) return fail(PCD_ERR_CAPACITY, "listSize > 32 does not fit one wavefront per codeword");
+    if (list_size > 32) return fail(PCD_ERR_CAPACITY, "listSize > 32 does not fit the 64 lanes of a wavefront");
     if (n_frozen > N) return fail(PCD_ERR_INVALID_ARG, "more frozen positions than code bits");
     if (n_frozen && !frozen) return fail(PCD_ERR_INVALID_ARG, "null frozen set");
     for (size_t i = 0; i < n_frozen; ++i) {

@@ -31,7 +31,7 @@ struct DecodeParams {
     uint32_t s0;             // SCL: first LLR stage kept in the arena (logN = none)
     uint32_t sc_virtual_top; // SC: stage logN-1 is recomputed from the channel row instead of being stored in LDS
     uint32_t prog_root_g0r;  // SC: the root is a ZeroR node (its right child input is a + b)
-    uint32_t wave_lds_words; // LDS words one codeword owns (SCL: one wave = one codeword; SC: 64/LC codewords per wave)
+    uint32_t wave_lds_words; // SCL: LDS words of one wave (all its codewords); SC: of one codeword (64/LC codewords per wave)
     float* trace;            // diagnostics (nullable): row 0 only, (1 + L) floats after every SCL leaf
     uint32_t trace_cap;
     uint32_t prog_len;
