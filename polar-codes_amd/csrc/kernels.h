@@ -1,4 +1,4 @@
-// Kernel parameter block and launchers shared by kernels.hip (device) and capi.cpp (host).
+// Kernel parameter block and launchers shared by the device code (sc_kernel.hip, scl_kernel.h) and capi.cpp (host).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,0 +1,485 @@
+// Fast-SSC kernel, the "mixed" helper kernel, and the launch dispatch of both decoder families.
+#include "device_common.h"
+#include "scl_launch.h"
+
+namespace pamd {
+
+// =============================================================================================
+//  Fast-SSC
+// =============================================================================================
+// LC = 2^LCL lanes work on one codeword, so a wave decodes 64/LC codewords side by side (LC = 16 for
+// N <= 1024: the tree ops below stage 6 have at most 16 elements, and every wave-uniform cost -- program
+// fetch, dispatch, address arithmetic -- is shared by the four codewords).  Control flow is identical for
+// all codewords, so nothing diverges.
+// LDS per codeword: llr[N] floats (stage s < logN at offset 1<<s; the channel row is read from global
+// memory by the root ops) + max(1, N/32) words of packed partial sums (code bit i = word i>>5, bit i&31).
+template <int LCL>
+struct ScLanes {
+    static constexpr int LC = 1 << LCL;
+    static constexpr uint64_t MASK = LC == 64 ? ~0ull : ((1ull << LC) - 1ull);
+    int l;       // lane inside the codeword group
+    int lbase;   // first wave lane of the group
+    __device__ __forceinline__ uint64_t slice(uint64_t ballot) const { return (ballot >> lbase) & MASK; }
+    // store `cnt` (<= LC) bits of m at code-bit offset off (off % cnt == 0 when cnt < 32)
+    __device__ __forceinline__ void put_bits(uint32_t* bits, uint32_t off, uint32_t cnt, uint64_t m) const
+    {
+        if (cnt >= 64) {
+            if (l < 2) bits[(off >> 5) + l] = (uint32_t)(m >> (32 * l));
+        } else if (cnt == 32) {
+            if (l == 0) bits[off >> 5] = (uint32_t)m;
+        } else if (l == 0) {
+            const uint32_t sh = off & 31u, mask = ((1u << cnt) - 1u) << sh;
+            const uint32_t w = bits[off >> 5];
+            bits[off >> 5] = (w & ~mask) | (((uint32_t)m << sh) & mask);
+        }
+    }
+    __device__ __forceinline__ void flip_bit(uint32_t* bits, uint32_t pos) const
+    {
+        if (l == 0) bits[pos >> 5] ^= 1u << (pos & 31u);
+    }
+    // fill n bits at off with a repeating 32-bit pattern (pattern period divides 32 and n)
+    __device__ __forceinline__ void fill_pattern(uint32_t* bits, uint32_t off, uint32_t n, uint32_t pat) const
+    {
+        if (n >= 32) {
+            for (uint32_t w = l; w < (n >> 5); w += LC) bits[(off >> 5) + w] = pat;
+        } else {
+            put_bits(bits, off, n, pat & ((1u << n) - 1u));
+        }
+    }
+    // the reference's fold8 (8 strided AVX accumulators, acc = 0; acc += x[8k+v]); result broadcast in the group
+    template <typename X>
+    __device__ __forceinline__ void fold8(const X& x, uint32_t n, float a[8]) const
+    {
+        float acc = 0.0f;
+        if (l < 8)
+            for (uint32_t i = l; i < n; i += 8) acc = acc + x(i);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) a[v] = shfl_f32(acc, lbase + v);
+    }
+    // lexicographic (value, index) minimum over the group; key of a lane without candidates = (inf, ~0)
+    __device__ __forceinline__ uint32_t min_index(uint32_t best, uint32_t bidx, bool any) const
+    {
+        uint64_t key = any ? (((uint64_t)best << 32) | bidx) : (((uint64_t)0x7F800000u << 32) | 0xFFFFFFFFu);
+#pragma unroll
+        for (int m = 1; m < LC; m <<= 1) {
+            const uint64_t o = shflx_u64(key, m);
+            key = o < key ? o : key;
+        }
+        const uint32_t idx = (uint32_t)key;
+        return idx == 0xFFFFFFFFu ? 0u : idx;
+    }
+    // first index of the minimum of |x[0..n)| (SpcDecoder::decode :342-373)
+    template <typename X>
+    __device__ __forceinline__ uint32_t firstmin_abs(const X& x, uint32_t n) const
+    {
+        uint32_t best = 0x7F800000u, bidx = 0;  // +inf, index 0 (reference start values)
+        bool any = false;
+        for (uint32_t i = l; i < n; i += LC) {
+            const uint32_t a = fbits(x(i)) & 0x7FFFFFFFu;
+            if (a < best) {
+                best = a;
+                bidx = i;
+                any = true;
+            }
+        }
+        return min_index(best, bidx, any);
+    }
+};
+__device__ __forceinline__ float reduce_add8(const float a[8])
+{
+    return ((((((a[0] + a[1]) + a[2]) + a[3]) + a[4]) + a[5]) + a[6]) + a[7];
+}
+
+template <int LCL, bool I8>
+__global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
+{
+    constexpr int LC = 1 << LCL;
+    constexpr int CW = 64 >> LCL;  // codewords per wave
+    extern __shared__ uint32_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const uint32_t wpb = blockDim.x >> 6;
+    ScLanes<LCL> g;
+    g.l = lane & (LC - 1);
+    g.lbase = lane & ~(LC - 1);
+    const int l = g.l;
+    const uint32_t slot = (uint32_t)lane >> LCL;
+    const uint32_t N = P.N, logN = P.logN;
+    const uint32_t nwords = N >= 32 ? (N >> 5) : 1u;
+    // this codeword's LDS slice
+    uint32_t* wl = smem + ((size_t)wib * CW + slot) * P.wave_lds_words;
+    float* llr = reinterpret_cast<float*>(wl);
+    const bool virt = P.sc_virtual_top != 0;          // stage logN-1 recomputed from the channel, not stored
+    uint32_t* bits = wl + (virt ? (N >> 1) : N);
+    const uint32_t wave0 = blockIdx.x * wpb + wib, nwaves = gridDim.x * wpb;
+    const const_u64_ptr prog64 = (const_u64_ptr)(uintptr_t)P.prog;
+    const uint32_t ngroups = (P.rows + CW - 1) / CW;
+
+    for (uint32_t grp = wave0; grp < ngroups; grp += nwaves) {
+        const uint32_t cwi = grp * CW + slot;
+        const bool live = cwi < P.rows;  // the last group may be ragged: idle slots decode row 0 and store nothing
+        const uint32_t row = live ? (P.rowidx ? P.rowidx[cwi] : cwi) : (P.rowidx ? P.rowidx[0] : 0u);
+        const void* chan = I8 ? (const void*)(reinterpret_cast<const int8_t*>(P.llr) + (size_t)row * N)
+                              : (const void*)(reinterpret_cast<const float*>(P.llr) + (size_t)row * N);
+
+        uint64_t iw_next = prog64[0];
+        for (uint32_t pc = 0;; ++pc) {
+            const uint64_t iw = iw_next;
+            const uint32_t op = (uint32_t)(iw & 0xFF);
+            if (op == OP_END) break;
+            iw_next = prog64[pc + 1];  // scalar load, in flight while this instruction executes
+            const uint32_t s = (uint32_t)((iw >> 8) & 0xFF), n = 1u << s, h = n >> 1, off = (uint32_t)(iw >> 32);
+
+            // the op body, instantiated for the two kinds of input: an LDS stage buffer, or (root) the channel row
+            auto run = [&](auto x) {
+                switch (op) {
+                case SC_F:
+                    for (uint32_t i = l; i < h; i += LC) llr[h + i] = polar_f(x(i), x(h + i));
+                    break;
+                case SC_G:
+                    for (uint32_t i = l; i < h; i += LC) {
+                        const uint32_t b = off + i;
+                        llr[h + i] = polar_g(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
+                    }
+                    break;
+                case SC_G0R:
+                    for (uint32_t i = l; i < h; i += LC) llr[h + i] = x(i) + x(h + i);
+                    break;
+                case SC_COMBINE:
+                case SC_COMBINE0R: {
+                    const bool copy = op == SC_COMBINE0R;
+                    if (h >= 32) {
+                        const uint32_t w0 = off >> 5, hw = h >> 5;
+                        for (uint32_t w = l; w < hw; w += LC) {
+                            const uint32_t r = bits[w0 + hw + w];
+                            bits[w0 + w] = copy ? r : (bits[w0 + w] ^ r);
+                        }
+                    } else if (l == 0) {
+                        const uint32_t sh = off & 31u, mask = (1u << h) - 1u;
+                        uint32_t w = bits[off >> 5];
+                        const uint32_t r = (w >> (sh + h)) & mask;
+                        if (copy)
+                            w = (w & ~(mask << sh)) | (r << sh);
+                        else
+                            w ^= r << sh;
+                        bits[off >> 5] = w;
+                    }
+                    break;
+                }
+                case SC_RONE: {  // h >= 8
+                    for (uint32_t i0 = 0; i0 < h; i0 += LC) {
+                        const uint32_t i = i0 + l;
+                        const bool act = i < h;
+                        uint32_t u = 0, sl = 0;
+                        if (act) {
+                            const uint32_t b = off + i;
+                            u = (bits[b >> 5] >> (b & 31u)) & 1u;
+                            sl = sgn(polar_g(x(i), x(h + i), u));
+                        }
+                        const uint64_t mr = g.slice(ballot64(act && sl));
+                        const uint64_t ml = g.slice(ballot64(act && (sl ^ u)));
+                        WAVE_SYNC();
+                        const uint32_t cnt = h < (uint32_t)LC ? h : (uint32_t)LC;
+                        g.put_bits(bits, off + i0, cnt, ml);
+                        g.put_bits(bits, off + h + i0, cnt, mr);
+                    }
+                    break;
+                }
+                case SC_R0:
+                    g.fill_pattern(bits, off, n, 0u);
+                    break;
+                case SC_R1:
+                    for (uint32_t i0 = 0; i0 < n; i0 += LC) {
+                        const uint32_t i = i0 + l;
+                        const uint64_t m = g.slice(ballot64(i < n && sgn(x(i < n ? i : 0))));
+                        g.put_bits(bits, off + i0, n < (uint32_t)LC ? n : (uint32_t)LC, m);
+                    }
+                    break;
+                case SC_REP: {
+                    float a[8];
+                    g.fold8(x, n, a);
+                    g.fill_pattern(bits, off, n, sgn(reduce_add8(a)) ? 0xFFFFFFFFu : 0u);
+                    break;
+                }
+                case SC_SPC: {
+                    uint32_t par = 0;
+                    for (uint32_t i0 = 0; i0 < n; i0 += LC) {
+                        const uint32_t i = i0 + l;
+                        const uint64_t m = g.slice(ballot64(i < n && sgn(x(i < n ? i : 0))));
+                        par ^= (uint32_t)__popcll(m) & 1u;
+                        g.put_bits(bits, off + i0, n < (uint32_t)LC ? n : (uint32_t)LC, m);
+                    }
+                    const uint32_t im = g.firstmin_abs(x, n);
+                    if (par) g.flip_bit(bits, off + im);
+                    break;
+                }
+                case SC_DREP: {
+                    float a[8];
+                    g.fold8(x, n, a);
+                    float e, o;
+                    if (n >= 8) {
+                        e = (a[0] + a[4]) + (a[2] + a[6]);
+                        o = (a[1] + a[5]) + (a[3] + a[7]);
+                    } else {
+                        e = ((a[0] + a[2]) + a[4]) + a[6];
+                        o = ((a[1] + a[3]) + a[5]) + a[7];
+                    }
+                    g.fill_pattern(bits, off, n, (sgn(e) ? 0x55555555u : 0u) | (sgn(o) ? 0xAAAAAAAAu : 0u));
+                    break;
+                }
+                case SC_DSPC8: {  // flip EVERY class member tied for the class minimum
+                    const int l8 = l & 7;
+                    const float v = x(l8);
+                    float m = absf(v);
+                    uint32_t p = sgn(v);
+#pragma unroll
+                    for (int k = 2; k < 8; k <<= 1) {
+                        const float om = shflx_f32(m, k);
+                        m = om < m ? om : m;
+                        p ^= shflx_u32(p, k);
+                    }
+                    const uint32_t bit = sgn(v) ^ ((p && absf(v) == m) ? 1u : 0u);
+                    g.put_bits(bits, off, 8, g.slice(ballot64(l < 8 && bit)));
+                    break;
+                }
+                case SC_DSPC: {  // n > 8: per AVX lane the LAST row with the lane minimum, lowest lane wins
+                    float minv = 3.402823466e+38f;
+                    uint32_t mini = 0;
+                    if (l < 8) {
+                        for (uint32_t i = l; i < n; i += 8) {
+                            const float a = absf(x(i));
+                            if (!(a > minv)) {
+                                minv = a;
+                                mini = i;
+                            }
+                        }
+                    }
+                    float cm = minv;  // class minimum over lanes of equal parity (within lanes 0..7 of the group)
+#pragma unroll
+                    for (int k = 2; k < 8; k <<= 1) {
+                        const float om = shflx_f32(cm, k);
+                        cm = om < cm ? om : cm;
+                    }
+                    const uint64_t tie = g.slice(ballot64(l < 8 && minv == cm));
+                    const int le = __ffsll((long long)(tie & 0x55ull)) - 1;
+                    const int lo = __ffsll((long long)(tie & 0xAAull)) - 1;
+                    const uint32_t ie = shfl_u32(mini, g.lbase + (le < 0 ? 0 : le)), io = shfl_u32(mini, g.lbase + (lo < 0 ? 1 : lo));
+                    uint32_t pe = 0, po = 0;
+                    for (uint32_t i0 = 0; i0 < n; i0 += LC) {
+                        const uint32_t i = i0 + l;
+                        const uint64_t m = g.slice(ballot64(i < n && sgn(x(i < n ? i : 0))));
+                        pe ^= (uint32_t)__popcll(m & 0x5555555555555555ull) & 1u;
+                        po ^= (uint32_t)__popcll(m & 0xAAAAAAAAAAAAAAAAull) & 1u;
+                        g.put_bits(bits, off + i0, n < (uint32_t)LC ? n : (uint32_t)LC, m);
+                    }
+                    if (pe) g.flip_bit(bits, off + ie);
+                    if (po) g.flip_bit(bits, off + io);
+                    break;
+                }
+                case SC_TREP: {
+                    float a[8], t[4];
+                    g.fold8(x, n, a);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = a[j] + a[j + 4];
+                    g.fill_pattern(bits, off, n, spc4_signs(t) * 0x11111111u);
+                    break;
+                }
+                case SC_TYPE5:
+                case SC_REPONE8: {
+                    float v8[8], q[4], gg[4];
+                    if (op == SC_TYPE5) {
+                        g.fold8(x, n, v8);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) v8[v] = x(v);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[j] = polar_f(v8[j], v8[j + 4]);
+                    const float rho = (q[0] + q[1]) + (q[2] + q[3]);
+                    const uint32_t sr = sgn(rho);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gg[j] = polar_g(v8[j], v8[j + 4], sr);
+                    uint32_t ss;
+                    if (op == SC_TYPE5)
+                        ss = spc4_signs(gg);
+                    else
+                        ss = sgn(gg[0]) | (sgn(gg[1]) << 1) | (sgn(gg[2]) << 2) | (sgn(gg[3]) << 3);
+                    const uint32_t byte = ((sr ? (ss ^ 0xFu) : ss) & 0xFu) | (ss << 4);
+                    g.fill_pattern(bits, off, n, byte * 0x01010101u);
+                    break;
+                }
+                case SC_ZSPC8: {
+                    float t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = x(j) + x(j + 4);
+                    const uint32_t r = spc4_signs(t);
+                    g.put_bits(bits, off, 8, (uint64_t)(r | (r << 4)));
+                    break;
+                }
+                case SC_ZEROSPC: {  // n > 8; outputs the RIGHT half's signs
+                    uint32_t par = 0;
+                    uint32_t best = 0x7F800000u, bidx = 0;
+                    bool any = false;
+                    for (uint32_t i0 = 0; i0 < h; i0 += LC) {
+                        const uint32_t i = i0 + l;
+                        const bool act = i < h;
+                        float y = 0.0f, r = 0.0f;
+                        if (act) {
+                            r = x(h + i);
+                            y = x(i) + r;
+                            const uint32_t a = fbits(y) & 0x7FFFFFFFu;
+                            if (a < best) {
+                                best = a;
+                                bidx = i;
+                                any = true;
+                            }
+                        }
+                        par ^= (uint32_t)__popcll(g.slice(ballot64(act && sgn(y)))) & 1u;
+                        const uint64_t m = g.slice(ballot64(act && sgn(r)));
+                        const uint32_t cnt = h < (uint32_t)LC ? h : (uint32_t)LC;
+                        g.put_bits(bits, off + i0, cnt, m);
+                        g.put_bits(bits, off + h + i0, cnt, m);
+                    }
+                    const uint32_t im = g.min_index(best, bidx, any);
+                    if (par) {
+                        g.flip_bit(bits, off + im);
+                        g.flip_bit(bits, off + h + im);
+                    }
+                    break;
+                }
+                default: break;
+                }
+            };
+            auto ch = [&](uint32_t i) -> float {
+                if constexpr (I8)
+                    return (float)reinterpret_cast<const int8_t*>(chan)[i];
+                else
+                    return reinterpret_cast<const float*>(chan)[i];
+            };
+            if (s == logN) {
+                // the stage below the root is never stored (see below), so the root's F / G / G0R have nothing to do
+                if (!(virt && (op == SC_F || op == SC_G || op == SC_G0R))) run(ch);
+            } else if (virt && s + 1 == logN) {
+                // "virtual" stage logN-1: its LLRs are recomputed from the channel row (L2-resident) on every use
+                // instead of living in LDS -- left half: f(x_i, x_{i+N/2}); right half: g(.., root-left bit i) where
+                // the root's left output still sits untouched in bits[0, N/2)
+                const uint32_t hN = N >> 1;
+                if (off == 0)
+                    run([&](uint32_t i) { return polar_f(ch(i), ch(hN + i)); });
+                else if (P.prog_root_g0r)
+                    run([&](uint32_t i) { return ch(i) + ch(hN + i); });
+                else
+                    run([&](uint32_t i) { return polar_g(ch(i), ch(hN + i), (bits[i >> 5] >> (i & 31u)) & 1u); });
+            } else {
+                const float* xs = llr + n;
+                run([&](uint32_t i) { return xs[i]; });
+            }
+            WAVE_SYNC();
+        }
+
+        // ---- output: FastSscAvxFloat::decode :940-955 ------------------------------------------
+        if (!P.systematic) {  // re-encode (butterfly_fip.cpp:15-63) on the packed words
+            for (uint32_t w = l; w < nwords; w += LC) {
+                uint32_t v = bits[w];
+                if (N >= 2) v ^= (v >> 1) & 0x55555555u;
+                if (N >= 4) v ^= (v >> 2) & 0x33333333u;
+                if (N >= 8) v ^= (v >> 4) & 0x0F0F0F0Fu;
+                if (N >= 16) v ^= (v >> 8) & 0x00FF00FFu;
+                if (N >= 32) v ^= (v >> 16) & 0x0000FFFFu;
+                bits[w] = v;
+            }
+            WAVE_SYNC();
+            for (uint32_t hw = 1; hw < nwords; hw <<= 1) {
+                for (uint32_t w = l; w < nwords; w += LC)
+                    if (!(w & hw)) bits[w] ^= bits[w + hw];
+                WAVE_SYNC();
+            }
+        }
+        uint32_t syn = 0;
+        uint8_t* orow = P.out + (size_t)row * P.nb;
+        for (uint32_t t0 = 0; t0 < P.K; t0 += LC) {
+            const uint32_t t = t0 + l;
+            uint32_t bit = 0;
+            if (t < P.K) {
+                const uint32_t pos = P.lut[t];
+                bit = (bits[pos >> 5] >> (pos & 31u)) & 1u;
+                if (bit) syn ^= P.syn[t];
+            }
+            const uint64_t m = g.slice(ballot64(bit != 0));
+            if (l < LC / 8) {
+                const uint32_t byte = (t0 >> 3) + l;
+                if (live && byte < P.nb) orow[byte] = (uint8_t)(__brev((uint32_t)((m >> (8 * l)) & 0xFFu)) >> 24);
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < LC; m <<= 1) syn ^= shflx_u32(syn, m);
+        if (live && l == 0 && P.ok) P.ok[row] = (syn == 0) ? 1 : 0;
+        WAVE_SYNC();
+    }
+}
+
+// =============================================================================================
+//  small helper kernels
+// =============================================================================================
+// "mixed" (AdaptiveFloat::decode adaptive_float.cpp:33-45): gather the rows the SC pass failed on
+__global__ void collect_failed_kernel(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows && !ok[i]) {
+        const uint32_t k = atomicAdd(count, 1u);
+        list[k] = i;
+    }
+}
+
+// =============================================================================================
+//  launchers
+// =============================================================================================
+template <int LCL, bool I8>
+static hipError_t launch_sc_k(const DecodeParams& P, dim3 g, dim3 b, size_t lds, hipStream_t st, int* occupancy)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<LCL, I8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<LCL, I8>, (int)b.x, lds);
+    hipLaunchKernelGGL((sc_decode_kernel<LCL, I8>), g, b, lds, st, P);
+    return hipGetLastError();
+}
+
+// lcl: log2 of the lanes that share one codeword (4 -> four codewords per wave, 6 -> one)
+hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, unsigned waves_per_block, size_t lds,
+                     hipStream_t st, int* occupancy)
+{
+    dim3 g(grid), b(64 * waves_per_block);
+    if (lcl == 3)
+        return i8 ? launch_sc_k<3, true>(P, g, b, lds, st, occupancy) : launch_sc_k<3, false>(P, g, b, lds, st, occupancy);
+    if (lcl == 4)
+        return i8 ? launch_sc_k<4, true>(P, g, b, lds, st, occupancy) : launch_sc_k<4, false>(P, g, b, lds, st, occupancy);
+    return i8 ? launch_sc_k<6, true>(P, g, b, lds, st, occupancy) : launch_sc_k<6, false>(P, g, b, lds, st, occupancy);
+}
+
+hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, unsigned waves_per_block,
+                      size_t lds, hipStream_t st, int* occupancy)
+{
+    dim3 g(grid), b(64 * waves_per_block);
+    const bool diag = P.trace || P.cycles || P.ablate;
+    switch (lpl * 4 + (int)P.cwl) {  // (log2 lanes per path, log2 codewords per wave)
+    case 1 * 4 + 0: return launch_scl_inst_1_0(P, i8, diag, g, b, lds, st, occupancy);
+    case 2 * 4 + 0: return launch_scl_inst_2_0(P, i8, diag, g, b, lds, st, occupancy);
+    case 3 * 4 + 0: return launch_scl_inst_3_0(P, i8, diag, g, b, lds, st, occupancy);
+    case 4 * 4 + 0: return launch_scl_inst_4_0(P, i8, diag, g, b, lds, st, occupancy);
+    case 5 * 4 + 0: return launch_scl_inst_5_0(P, i8, diag, g, b, lds, st, occupancy);
+    case 2 * 4 + 1: return launch_scl_inst_2_1(P, i8, diag, g, b, lds, st, occupancy);  // L <= 8: 4 lanes per path, 2 codewords
+    case 3 * 4 + 1: return launch_scl_inst_3_1(P, i8, diag, g, b, lds, st, occupancy);  // L <= 4: 8 lanes per path, 2 codewords
+    case 3 * 4 + 2: return launch_scl_inst_3_2(P, i8, diag, g, b, lds, st, occupancy);  // L <= 2: 8 lanes per path, 4 codewords
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,
+                                 hipStream_t st)
+{
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(collect_failed_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, ok, rows, list, count);
+    return hipGetLastError();
+}
+
+}  // namespace pamd
