@@ -104,11 +104,6 @@ __device__ __forceinline__ uint32_t partner_u32(uint32_t v)
     else
         return shflx_u32(v, M);
 }
-template <int M>
-__device__ __forceinline__ uint64_t partner_u64(uint64_t v)
-{
-    return ((uint64_t)partner_u32<M>((uint32_t)(v >> 32)) << 32) | partner_u32<M>((uint32_t)v);
-}
 #define PAMD_GROUP_REDUCE(T, NAME, PARTNER, EXPR)                          \
     template <int G>                                                       \
     __device__ __forceinline__ T NAME(T v)                                 \
@@ -122,10 +117,8 @@ __device__ __forceinline__ uint64_t partner_u64(uint64_t v)
         return v;                                                          \
     }
 PAMD_GROUP_REDUCE(uint32_t, group_xor_u32, partner_u32, v ^ o)
-PAMD_GROUP_REDUCE(uint32_t, group_or_u32, partner_u32, v | o)
 PAMD_GROUP_REDUCE(uint32_t, group_max_u32, partner_u32, o > v ? o : v)
 PAMD_GROUP_REDUCE(uint32_t, group_min_u32, partner_u32, o < v ? o : v)
-PAMD_GROUP_REDUCE(uint64_t, group_min_u64, partner_u64, o < v ? o : v)
 
 // wave-wide maximum of a u32 as a wave-uniform value: DPP inside the 16-lane rows, then 4 readlanes
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
@@ -134,13 +127,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     const uint32_t a = readlane_u32(v, 0), b = readlane_u32(v, 16), c = readlane_u32(v, 32), d = readlane_u32(v, 48);
     const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
     return ab > cd ? ab : cd;
-}
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-    v = group_min_u32<16>(v);
-    const uint32_t a = readlane_u32(v, 0), b = readlane_u32(v, 16), c = readlane_u32(v, 32), d = readlane_u32(v, 48);
-    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
-    return ab < cd ? ab : cd;
 }
 // value held by lane I of each 8-lane group, delivered to all 8 lanes (two DPP moves and a select)
 template <int I>
@@ -161,13 +147,6 @@ __device__ __forceinline__ uint32_t okey(float f)
     return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 __device__ __forceinline__ float unkey(uint32_t k) { return bitsf((k >> 31) ? (k ^ 0x80000000u) : ~k); }
-
-__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
-{
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v ^= shflx_u32(v, m);
-    return v;
-}
 
 // _mm256_spc_right4_ps avx_float.h:289-302 on four wave-uniform values: returns the 4 output signs
 __device__ __forceinline__ uint32_t spc4_signs(const float in[4])

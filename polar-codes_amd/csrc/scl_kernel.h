@@ -187,14 +187,7 @@ struct SclCtx {
         const uint32_t sh = (s - 1) * FB;
         slot = (slot & ~((SlotT)(LCW - 1) << sh)) | ((SlotT)(p & (LCW - 1)) << sh);
     }
-    // the slot word of path group q, as a wave-uniform value / fetched from a per-lane source lane
-    __device__ __forceinline__ SlotT slot_of_group(int q) const
-    {
-        if constexpr (S64)
-            return ((uint64_t)readlane_u32((uint32_t)(slot >> 32), q << LPL) << 32) | readlane_u32((uint32_t)slot, q << LPL);
-        else
-            return readlane_u32(slot, q << LPL);
-    }
+    // the slot word held by lane src (per-lane source)
     __device__ __forceinline__ SlotT slot_from_lane(int src) const
     {
         if constexpr (S64)
