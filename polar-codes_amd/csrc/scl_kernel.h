@@ -595,6 +595,57 @@ __device__ __forceinline__ void find_weak_small4(uint32_t a0, uint32_t a1, int j
     if constexpr (CNT > 3) step(std::integral_constant<int, 3>{});
 }
 
+// Fast form of the same search when no two LLR magnitudes of a block are equal (the usual case for real-valued
+// input): the reference's selection then simply yields ascending order, so every element is ranked against the other
+// n - 1 (quad rotations), the four smallest go through the LDS scratch by rank, and every lane reads them back as
+// two 16-byte broadcasts.  Any exact tie inside a block of the wave sends the whole wave to the literal emulation.
+template <typename CTX, int S, int CNT>
+__device__ __forceinline__ void weak_small4(const CTX& c, uint32_t a0, uint32_t a1, Weak<CNT>& out)
+{
+    constexpr uint32_t INFB = 0xFFFFFFFFu;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 __attribute__((address_space(3))) lds_u32x4;
+    typedef uint32_t __attribute__((address_space(3))) lds_u32;
+    const uint32_t j = (uint32_t)c.j;
+    // values of lanes j+1, j+2, j+3 (mod 4) of the quad
+    const uint32_t p1 = dpp_u32<0x39>(a0), p2 = dpp_u32<0x4E>(a0), p3 = dpp_u32<0x93>(a0);
+    uint32_t r0 = ((p1 < a0) ? 1u : 0u) + ((p2 < a0) ? 1u : 0u) + ((p3 < a0) ? 1u : 0u), r1 = 8u;
+    bool tie = (a0 != INFB) && (p1 == a0 || p2 == a0 || p3 == a0);
+    if constexpr (S == 3) {
+        const uint32_t q1 = dpp_u32<0x39>(a1), q2 = dpp_u32<0x4E>(a1), q3 = dpp_u32<0x93>(a1);
+        r0 += ((a1 < a0) ? 1u : 0u) + ((q1 < a0) ? 1u : 0u) + ((q2 < a0) ? 1u : 0u) + ((q3 < a0) ? 1u : 0u);
+        r1 = ((a0 < a1) ? 1u : 0u) + ((p1 < a1) ? 1u : 0u) + ((p2 < a1) ? 1u : 0u) + ((p3 < a1) ? 1u : 0u) +
+             ((q1 < a1) ? 1u : 0u) + ((q2 < a1) ? 1u : 0u) + ((q3 < a1) ? 1u : 0u);
+        tie = tie || a1 == a0 || q1 == a0 || q2 == a0 || q3 == a0 || p1 == a1 || p2 == a1 || p3 == a1 || q1 == a1 ||
+              q2 == a1 || q3 == a1;
+    }
+    if (ballot64(tie && (uint32_t)c.pl < c.P) != 0) {  // (stale buffers of dead paths do not count)
+        find_weak_small4<S, CNT>(a0, a1, c.j, out);
+        return;
+    }
+    // per path: words 0..3 = the four smallest values, 4..7 = their indices (lanes beyond n hold INFB and rank last)
+    lds_u32* slotp = (lds_u32*)(uintptr_t)c.scratch + (uint32_t)c.p * 8u;
+    if (r0 < 4u) {
+        slotp[r0] = a0;
+        slotp[4u + r0] = j;
+    }
+    if (S == 3 && r1 < 4u) {
+        slotp[r1] = a1;
+        slotp[4u + r1] = j + 4u;
+    }
+    WAVE_SYNC();
+    const u32x4 v = *(const lds_u32x4*)(uintptr_t)(c.scratch + (uint32_t)c.p * 8u);
+    const u32x4 x = *(const lds_u32x4*)(uintptr_t)(c.scratch + (uint32_t)c.p * 8u + 4u);
+    WAVE_SYNC();  // (the scratch is reused by the candidate ranking)
+    constexpr int n = 1 << S;
+    const uint32_t vv[4] = { v.x, v.y, v.z, v.w }, xx[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        out.v[i] = i < n ? vv[i] : 0u;
+        out.ix[i] = i < n ? xx[i] : 0u;
+    }
+}
+
 // ---- LP == 8 candidate selection by rank -------------------------------------------------------------------
 // When no two candidates that matter carry the same metric, the reference's selection sort simply yields the
 // newP largest in descending order, so candidate c becomes new path  rank(c) = #{d : metric_d > metric_c}.
@@ -939,19 +990,19 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         const uint32_t a0 = in0 ? (fbits(x0) & 0x7FFFFFFFu) : INFB, a1 = in1 ? (fbits(x1) & 0x7FFFFFFFu) : INFB;
                         if (spc) {
                             if (s == 2)
-                                find_weak_small4<2, 4>(a0, a1, c.j, wk);
+                                weak_small4<Ctx, 2, 4>(c, a0, a1, wk);
                             else
-                                find_weak_small4<3, 4>(a0, a1, c.j, wk);
+                                weak_small4<Ctx, 3, 4>(c, a0, a1, wk);
                             const uint64_t sg = ballot64(in0 && sgn(x0)) ^ ballot64(in1 && sgn(x1));
                             par = (uint32_t)__popc((uint32_t)(sg >> c.base) & 0xFu) & 1u;
                         } else {
                             Weak<2> w2;
                             if (s == 1)
-                                find_weak_small4<1, 2>(a0, a1, c.j, w2);
+                                weak_small4<Ctx, 1, 2>(c, a0, a1, w2);
                             else if (s == 2)
-                                find_weak_small4<2, 2>(a0, a1, c.j, w2);
+                                weak_small4<Ctx, 2, 2>(c, a0, a1, w2);
                             else
-                                find_weak_small4<3, 2>(a0, a1, c.j, w2);
+                                weak_small4<Ctx, 3, 2>(c, a0, a1, w2);
                             wk.v[0] = w2.v[0];
                             wk.v[1] = w2.v[1];
                             wk.ix[0] = w2.ix[0];
