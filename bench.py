@@ -110,7 +110,7 @@ def cpu_baseline_encode(cfg, seconds):
             "sample": f"{n} encodes by the scalar C oracle in {el:.1f} s"}
 
 
-def bench_encode(args, cfg, dev, dev_index, rank, world, barrier_fn):
+def bench_encode(args, cfg, dev, dev_index, rank, world, barrier_fn, emit):
     """secondary workload: batched systematic encoding + checksum generation"""
     N, K = cfg["N"], cfg["K"]
     nb = (K + 7) // 8
@@ -168,7 +168,7 @@ def bench_encode(args, cfg, dev, dev_index, rank, world, barrier_fn):
                                     "traffic_over_algorithmic": t["bytes"] / (bytes_per_cw * B)})
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_encode(cfg, args.cpu_seconds)
-    print(json.dumps(res))
+    emit(res)
 
 
 def pmc_traffic(config, log2b, kernel_substr):
@@ -240,6 +240,15 @@ def cpu_baseline(cfg, seconds):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON result: everything libraries print while the benchmark runs (RCCL
+    # writes a version banner to stdout when the first communicator is created) goes to stderr instead
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -263,9 +272,14 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # BENCH_FORCE_GATHER=1: run the N > 1 exchange code with a single rank (rehearsal of the stream overlap on one GPU)
+    exchange = world > 1 or bool(os.environ.get("BENCH_FORCE_GATHER"))
+    if exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -277,7 +291,7 @@ def main():
             if world > 1:
                 torch.distributed.barrier(device_ids=[dev_index]) if backend == "nccl" else torch.distributed.barrier()
             torch.cuda.synchronize()
-        bench_encode(args, cfg, dev, dev_index, rank, world, enc_barrier)
+        bench_encode(args, cfg, dev, dev_index, rank, world, enc_barrier, emit)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -295,24 +309,42 @@ def main():
     ok = torch.empty((B,), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    # N > 1: the only exchange of the path -- decoded bytes + verdict of every rank (RCCL all-gather over xGMI)
-    packed = torch.empty((B, nb + 1), dtype=torch.uint8, device=dev) if world > 1 else None
-    gathered = torch.empty((B * world, nb + 1), dtype=torch.uint8, device=dev) if world > 1 else None
+    # N > 1: the only exchange of the path -- decoded bytes + verdict of every rank (RCCL all-gather over xGMI).
+    # It runs on its own stream, double buffered, so that the gather of step k overlaps the decode of step k + 1;
+    # the closing barrier synchronises the whole device, so every gather lies inside the timed region.
+    packed = [torch.empty((B, nb + 1), dtype=torch.uint8, device=dev) for _ in range(2)] if exchange else None
+    gathered = [torch.empty((B * world, nb + 1), dtype=torch.uint8, device=dev) for _ in range(2)] if exchange else None
+    comm = torch.cuda.Stream(device=dev) if exchange and backend == "nccl" else None
+    ev_ready = [torch.cuda.Event() for _ in range(2)]
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    state = {"k": 0}
 
     def step():
         dec.decode_batch(llr, out=out, ok=ok)
-        if world > 1:
-            packed[:, :nb].copy_(out)
-            packed[:, nb].copy_(ok)
-            if backend != "nccl":  # rehearsal path: gloo gathers host tensors
-                host = torch.empty((B * world, nb + 1), dtype=torch.uint8)
-                torch.distributed.all_gather_into_tensor(host, packed.cpu())
-                return host
-            return sharding.gather_decoded(packed, equal_rows=True, out=gathered)
-        return None
+        if not exchange:
+            return None
+        b = state["k"] & 1
+        state["k"] += 1
+        main = torch.cuda.current_stream(dev)
+        if state["k"] > 2:
+            main.wait_event(ev_done[b])          # the gather that last read packed[b] has finished
+        packed[b][:, :nb].copy_(out)
+        packed[b][:, nb].copy_(ok)
+        if backend != "nccl":  # rehearsal path: gloo gathers host tensors
+            host = torch.empty((B * world, nb + 1), dtype=torch.uint8)
+            torch.distributed.all_gather_into_tensor(host, packed[b].cpu())
+            return host
+        ev_ready[b].record(main)
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev_ready[b])
+            # (= sharding.gather_decoded(packed[b], equal_rows=True, out=gathered[b]): one collective, no host sync)
+            torch.distributed.all_gather_into_tensor(gathered[b], packed[b])
+            res = gathered[b]
+            ev_done[b].record(comm)
+        return res
 
     def barrier():
-        if world > 1:
+        if exchange:
             if backend == "nccl":
                 torch.distributed.barrier(device_ids=[dev_index])
             else:
@@ -328,7 +360,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -375,8 +407,8 @@ def main():
                                         "traffic_over_algorithmic": t["bytes"] / (bytes_per_cw * B)})
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
-        print(json.dumps(res))
-    if world > 1:
+        emit(res)
+    if exchange:
         torch.distributed.destroy_process_group()
 
 
