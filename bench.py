@@ -39,6 +39,9 @@ CONFIGS = {
                  name="5G-table N=1024 K=176 SCL L=8 + CRC-11, batch=2^19 per GPU (2^22 over 8)"),
     "cfg5": dict(N=4096, K=2048, L=32, dsnr=0.0, crc=32, crc_type="crc", ebn0=1.5, log2_batch=15,
                  name="N=4096 K=2048 SCL L=32 + CRC-32C, batch=2^15 per GPU (2^18 over 8)"),
+    # secondary workload: rate matching in front of the decoder (PolarCode::Puncturer::depuncture<float>)
+    "dep3": dict(N=1024, K=512, L=0, dsnr=0.0, crc=0, crc_type="crc", ebn0=2.0, log2_batch=20, M=864,
+                 name="depuncture 864 -> 1024 float LLRs (160 frozen positions removed), batch=2^20"),
     # secondary workload: the encoder side of cfg3
     "enc3": dict(N=1024, K=512, L=0, dsnr=0.0, crc=24, crc_type="crcnr", ebn0=2.0, log2_batch=22,
                  name="N=1024 K=512 + CRC-24C, batch=2^22"),
@@ -108,6 +111,68 @@ def cpu_baseline_encode(cfg, seconds):
     el = time.time() - t0
     return {"value": n / el, "unit": "codewords/s", "cores": 1, "kind": "port",
             "sample": f"{n} encodes by the scalar C oracle in {el:.1f} s"}
+
+
+def bench_depuncture(args, cfg, dev, dev_index, rank, world, barrier_fn, emit):
+    """secondary workload: batched depuncturing of float LLRs (pure data movement, HBM-bound)"""
+    N, M = cfg["N"], cfg["M"]
+    log2b = args.log2_batch if args.log2_batch is not None else cfg["log2_batch"]
+    B = 1 << log2b
+    frozen = frozen_bits(N, cfg["K"], cfg["dsnr"], "BB")
+    punc = pypolar_amd.Puncturer(M, frozen, device=dev_index)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99 + rank)
+    x = torch.randn((B, M), generator=g, device=dev, dtype=torch.float32)
+    out = torch.empty((B, N), dtype=torch.float32, device=dev)
+    for _ in range(args.warmup):
+        punc.depuncture_batch(x, out=out)
+    barrier_fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:  # launched on torch's current stream, so torch events bracket the kernel
+        a.record()
+        punc.depuncture_batch(x, out=out)
+        b.record()
+    barrier_fn()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    if rank != 0:
+        return
+    bytes_per_row = 4 * (M + N)          # punctured row in, parent row out
+    achieved = bytes_per_row * B / (k_ms * 1e-3) / 1e9
+    res = {
+        "metric": f"rows/sec, {cfg['name']}", "value": B * world * args.steps / elapsed, "unit": "rows/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["name"] + (" per GPU" if world > 1 else ""), "parent_block_length": N,
+                   "block_length": M, "rows_per_gpu": B},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "gather_rows4_kernel",
+                     "kernel_ms_avg": k_ms, "algorithmic_bytes_per_row": bytes_per_row, "rows_per_launch": B},
+    }
+    if world == 1 and args.pmc_traffic:
+        t = pmc_traffic(args.config, log2b, "gather_rows4_kernel")
+        if t:
+            res["roofline"].update({"traffic": t["bytes"], "traffic_unit": "bytes per launch at the L2<->fabric "
+                                    "interface (Infinity-Cache hits included): 2 x FETCH_SIZE + WRITE_SIZE",
+                                    "traffic_over_algorithmic": t["bytes"] / (bytes_per_row * B)})
+    if world == 1 and not args.no_cpu_baseline:
+        cores = len(os.sched_getaffinity(0))
+        harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+        try:
+            o = subprocess.run([harness, "punctime", str(M), str(N), str(cfg["K"]), "BB", str(cfg["dsnr"]), str(cores),
+                                str(min(args.cpu_seconds, 8.0))], capture_output=True, text=True, timeout=120, check=True)
+            r = json.loads(o.stdout.strip().splitlines()[-1])
+            res["cpu_baseline"] = {"value": r["rows_per_s"], "unit": "rows/s", "cores": cores, "kind": "reference",
+                                   "sample": f"256 rows per thread cycled for {r['seconds']:.1f} s through the reference's "
+                                             f"Puncturer::depuncture<float> ({cores} threads), {r['rows']} rows"}
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] reference harness unavailable ({e})", file=sys.stderr)
+    emit(res)
 
 
 def bench_encode(args, cfg, dev, dev_index, rank, world, barrier_fn, emit):
@@ -292,6 +357,15 @@ def main():
                 torch.distributed.barrier(device_ids=[dev_index]) if backend == "nccl" else torch.distributed.barrier()
             torch.cuda.synchronize()
         bench_encode(args, cfg, dev, dev_index, rank, world, enc_barrier, emit)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    if args.config.startswith("dep"):
+        def dep_barrier():
+            if world > 1:
+                torch.distributed.barrier(device_ids=[dev_index]) if backend == "nccl" else torch.distributed.barrier()
+            torch.cuda.synchronize()
+        bench_depuncture(args, cfg, dev, dev_index, rank, world, dep_barrier, emit)
         if world > 1:
             torch.distributed.destroy_process_group()
         return

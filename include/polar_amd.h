@@ -1,5 +1,5 @@
 /*
- * polar_amd.h -- C ABI of the MI355X-native batched polar SC / SCL decoder (pcd_*) and encoder (pce_*).
+ * polar_amd.h -- C ABI of the MI355X-native batched polar SC / SCL decoder (pcd_*), encoder (pce_*) and puncturer (ppu_*).
  *
  * Drop-in boundary for the reference's decode path (ant-uni-bremen/polar-codes):
  *   PolarCode::Decoding::create()            src/polarcode/decoding/decoder.cpp:26-52
@@ -37,7 +37,8 @@ typedef enum {
     PCD_ERR_UNKNOWN_DETECTOR = -6, /* reference: std::runtime_error("Unknown Error detector requested!") */
     PCD_ERR_NO_DEVICE = -7,     /* no HIP device / HIP runtime error: the product path never falls back */
     PCD_ERR_HIP = -8,
-    PCD_ERR_CAPACITY = -9       /* (N, L) exceeds what the kernels can hold            */
+    PCD_ERR_CAPACITY = -9,      /* (N, L) exceeds what the kernels can hold            */
+    PCD_ERR_PUNCTURE = -10      /* reference: std::out_of_range from Puncturer::Puncturer               */
 } pcd_status;
 
 /* memory-space tags for the pointers handed to pcd_decode_* */
@@ -136,6 +137,29 @@ int pce_error_detection_mode(const pce_encoder* e, char* buf, size_t cap);
  *   code : rows x pce_code_bytes() packed code words, code bit i = byte i/8, bit 7 - i%8 (16-byte aligned)
  *   Device pointers: asynchronous on `stream`; host pointers: staged and synchronised before returning. */
 int pce_encode(pce_encoder* e, uint8_t* info, size_t rows, uint8_t* code, int mem, void* stream);
+
+/* =====================================================================================================
+ * Batched PUNCTURER: PolarCode::Puncturer behind pypolar.Puncturer (rate matching either side of the codec)
+ *   Puncturer(blockLength, frozenBitPositions)     src/polarcode/puncturer.cpp:51-65
+ *   puncture<T> / depuncture<T>                    include/polarcode/puncturer.h:66-97
+ *   puncturePacked                                 src/polarcode/puncturer.cpp:69-89
+ *   pypolar.Puncturer                              python/bindings/puncturer_python.cc:21-150
+ * The parent block length N is blockLength rounded up to a power of two; the first N - blockLength frozen positions
+ * are removed.  One HIP kernel launch moves `rows` rows.
+ * ===================================================================================================== */
+typedef struct ppu_puncturer ppu_puncturer;
+/* PCD_ERR_PUNCTURE if N - block_length exceeds n_frozen (reference: std::out_of_range) */
+int ppu_create(size_t block_length, const uint32_t* frozen, size_t n_frozen, int device, ppu_puncturer** out);
+void ppu_destroy(ppu_puncturer* u);
+size_t ppu_block_length(const ppu_puncturer* u);          /* Puncturer::blockLength()          */
+size_t ppu_parent_block_length(const ppu_puncturer* u);   /* Puncturer::parentBlockLength()    */
+size_t ppu_output_positions(const ppu_puncturer* u, uint32_t* out, size_t cap); /* blockOutputPositions() */
+/* puncture<T>: rows x N elements -> rows x blockLength elements; elem_bytes = 1 (uint8), 4 (float), 8 (double) */
+int ppu_puncture(ppu_puncturer* u, const void* in, size_t rows, void* out, unsigned elem_bytes, int mem, void* stream);
+/* depuncture<T>: rows x blockLength -> rows x N, punctured positions = 0 */
+int ppu_depuncture(ppu_puncturer* u, const void* in, size_t rows, void* out, unsigned elem_bytes, int mem, void* stream);
+/* puncturePacked: rows x N/8 bytes -> rows x blockLength/8 bytes, bits MSB first (both lengths multiples of 8) */
+int ppu_puncture_packed(ppu_puncturer* u, const uint8_t* in, size_t rows, uint8_t* out, int mem, void* stream);
 
 const char* pcd_last_error(void);
 const char* pcd_version(void);

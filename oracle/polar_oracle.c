@@ -924,3 +924,48 @@ void po_encode(unsigned N, const uint32_t* frozen, unsigned nF, int det, int sys
         if (u[i]) codeword[i >> 3] |= (uint8_t)(0x80u >> (i & 7));
     free(u);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Puncturer   src/polarcode/puncturer.cpp, include/polarcode/puncturer.h
+ * ---------------------------------------------------------------------------------------- */
+int po_punc_positions(unsigned M, const uint32_t* frozen, unsigned nF, uint32_t* positions, unsigned* parent)
+{
+    unsigned N = 1; /* round_up_power_of_two puncturer.cpp:24-34 */
+    while (N < M) N <<= 1;
+    if (parent) *parent = N;
+    const unsigned np = N - M; /* Puncturer::Puncturer :51-65 */
+    if (np > nF) return -1;
+    /* inverse_set_difference :36-49: ascending positions not among the first np frozen ones (sorted input) */
+    unsigned f = 0, k = 0;
+    for (unsigned i = 0; i < N; ++i) {
+        if (f < np && frozen[f] == i) {
+            ++f;
+            continue;
+        }
+        positions[k++] = i;
+    }
+    return k == M ? 0 : -1;
+}
+
+void po_puncture_f32(const uint32_t* positions, unsigned M, const float* in, float* out)
+{
+    for (unsigned i = 0; i < M; ++i) out[i] = in[positions[i]]; /* puncturer.h:66-74 */
+}
+
+void po_depuncture_f32(const uint32_t* positions, unsigned M, unsigned N, const float* in, float* out)
+{
+    for (unsigned i = 0; i < N; ++i) out[i] = 0.0f; /* puncturer.h:89-96 */
+    for (unsigned i = 0; i < M; ++i) out[positions[i]] = in[i];
+}
+
+void po_puncture_packed(const uint32_t* positions, unsigned M, const uint8_t* in, uint8_t* out)
+{
+    for (unsigned b = 0; b < M / 8; ++b) { /* puncturer.cpp:69-89 */
+        uint8_t o = 0;
+        for (unsigned i = 0; i < 8; ++i) {
+            const unsigned p = positions[8 * b + i];
+            if ((in[p >> 3] >> (7 - (p & 7))) & 1u) o |= (uint8_t)(0x80u >> i);
+        }
+        out[b] = o;
+    }
+}

@@ -74,4 +74,12 @@ int po_tree_stats(unsigned N, const uint32_t* frozen, unsigned nF, int list, uns
 #ifdef __cplusplus
 }
 #endif
+/* ---- Puncturer (puncturer.cpp:51-89, puncturer.h:66-97) ------------------------------------------------------
+ * positions[M]: the parent-block positions copied to the output = {0..N-1} minus the first N - M frozen positions
+ * (N = M rounded up to a power of two).  Returns 0, or -1 if N - M exceeds nF (the reference throws). */
+int po_punc_positions(unsigned M, const uint32_t* frozen, unsigned nF, uint32_t* positions, unsigned* parent);
+void po_puncture_f32(const uint32_t* positions, unsigned M, const float* in, float* out);
+void po_depuncture_f32(const uint32_t* positions, unsigned M, unsigned N, const float* in, float* out);
+void po_puncture_packed(const uint32_t* positions, unsigned M, const uint8_t* in, uint8_t* out);
+
 #endif

@@ -23,6 +23,11 @@
 //         u32 hdr[10] = {0x31454650 'PFE1', N, K, systematic, nF, count, nb, crcsize, crcnr, 0}, u32 F[nF],
 //         count x { u8 info_in[nb] | u8 info_after[nb] (generate() writes the checksum in place) | u8 cw[N/8] }
 //   enctime N K ctor dsnr crcsize crctype threads seconds     the reference encoder's CPU throughput
+//   punc  M N K ctor dsnr count seed out.bin
+//         golden fixture of the PUNCTURER (puncturer.cpp:51-89, puncturer.h:66-97) for punctured length M <= N:
+//         u32 hdr[10] = {0x31504650 'PFP1', M, N, K, nF, count, 0, 0, 0, 0}, u32 F[nF], u32 positions[M],
+//         count x { f32 in[N] | f32 punctured[M] | f32 depunctured[N] (of `punctured`) | u8 packed_in[N/8] | u8 packed_out[M/8] }
+//   punctime M N K ctor dsnr threads seconds     CPU throughput of depuncture<float> (rows/s)
 //   frozen N K ctor dsnr          prints the frozen set (one index per line)
 //   crc   size type hexbytes      prints Detector::calculate()/check() for KAT pinning
 //
@@ -65,6 +70,7 @@
 #include <polarcode/construction/constructor.h>
 #include <polarcode/encoding/butterfly_fip_packed.h>
 #include <polarcode/errordetection/errordetector.h>
+#include <polarcode/puncturer.h>
 
 using namespace PolarCode;
 
@@ -350,6 +356,82 @@ static int cmd_enctime(int argc, char** argv)
     return 0;
 }
 
+static int cmd_punc(int argc, char** argv)
+{
+    if (argc < 10) { fprintf(stderr, "punc: bad args\n"); return 2; }
+    const unsigned M = atoi(argv[2]);
+    Code c;
+    c.N = atoi(argv[3]); c.K = atoi(argv[4]); c.L = 1; c.ctor = argv[5]; c.dsnr = atof(argv[6]);
+    const unsigned count = atoi(argv[7]);
+    const uint64_t seed = strtoull(argv[8], nullptr, 10);
+    const char* out = argv[9];
+    if (!load_frozen(c)) return 1;
+    Puncturer punc(M, c.F);
+    if (punc.parentBlockLength() != c.N) { fprintf(stderr, "punc: parent length %zu != N\n", punc.parentBlockLength()); return 1; }
+    const std::vector<unsigned> pos = punc.blockOutputPositions();
+    FILE* f = fopen(out, "wb");
+    if (!f) { perror(out); return 1; }
+    uint32_t hdr[10] = { 0x31504650u, M, c.N, c.K, (uint32_t)c.F.size(), count, 0, 0, 0, 0 };
+    fwrite(hdr, 4, 10, f);
+    fwrite(c.F.data(), 4, c.F.size(), f);
+    fwrite(pos.data(), 4, pos.size(), f);
+    std::mt19937_64 g(seed);
+    for (unsigned r = 0; r < count; ++r) {
+        std::vector<float> in(c.N), pun(M), dep(c.N);
+        for (auto& v : in) v = (float)((double)(int64_t)(g() % 2001) - 1000.0) / 64.0f;
+        punc.puncture<float>(pun.data(), in.data());
+        punc.depuncture<float>(dep.data(), pun.data());
+        std::vector<uint8_t> pin(c.N / 8), pout(M / 8 + 1, 0);
+        for (auto& b : pin) b = (uint8_t)(g() & 0xFF);
+        if (M % 8 == 0) punc.puncturePacked(pout.data(), pin.data());
+        fwrite(in.data(), 4, c.N, f);
+        fwrite(pun.data(), 4, M, f);
+        fwrite(dep.data(), 4, c.N, f);
+        fwrite(pin.data(), 1, c.N / 8, f);
+        fwrite(pout.data(), 1, M / 8, f);
+    }
+    fclose(f);
+    fprintf(stderr, "%s: M=%u N=%u |F|=%zu rows=%u\n", out, M, c.N, c.F.size(), count);
+    return 0;
+}
+
+static int cmd_punctime(int argc, char** argv)
+{
+    if (argc < 9) { fprintf(stderr, "punctime: bad args\n"); return 2; }
+    const unsigned M = atoi(argv[2]);
+    Code c;
+    c.N = atoi(argv[3]); c.K = atoi(argv[4]); c.L = 1; c.ctor = argv[5]; c.dsnr = atof(argv[6]);
+    const unsigned threads = atoi(argv[7]);
+    const double seconds = atof(argv[8]);
+    if (!load_frozen(c)) return 1;
+    std::atomic<uint64_t> total(0);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) {
+        pool.emplace_back([&, t]() {
+            Puncturer punc(M, c.F);
+            const unsigned rows = 256;
+            std::vector<float> in((size_t)rows * M, 1.0f), outv((size_t)rows * c.N);
+            uint64_t n = 0;
+            for (;;) {
+                for (unsigned r = 0; r < rows; ++r) {
+                    punc.depuncture<float>(&outv[(size_t)r * c.N], &in[(size_t)r * M]);
+                    ++n;
+                }
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (el >= seconds) break;
+            }
+            total += n;
+        });
+    }
+    for (auto& th : pool) th.join();
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("{\"kind\": \"reference\", \"op\": \"depuncture\", \"M\": %u, \"N\": %u, \"threads\": %u, "
+           "\"rows\": %llu, \"seconds\": %.4f, \"rows_per_s\": %.2f}\n",
+           M, c.N, threads, (unsigned long long)total.load(), el, total.load() / el);
+    return 0;
+}
+
 static int cmd_frozen(int argc, char** argv)
 {
     if (argc < 6) return 2;
@@ -376,12 +458,14 @@ static int cmd_crc(int argc, char** argv)
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: ref_harness gen|time|enc|enctime|frozen|crc ...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness gen|time|enc|enctime|punc|punctime|frozen|crc ...\n"); return 2; }
     const std::string cmd = argv[1];
     if (cmd == "gen") return cmd_gen(argc, argv);
     if (cmd == "time") return cmd_time(argc, argv);
     if (cmd == "enc") return cmd_enc(argc, argv);
     if (cmd == "enctime") return cmd_enctime(argc, argv);
+    if (cmd == "punc") return cmd_punc(argc, argv);
+    if (cmd == "punctime") return cmd_punctime(argc, argv);
     if (cmd == "frozen") return cmd_frozen(argc, argv);
     if (cmd == "crc") return cmd_crc(argc, argv);
     fprintf(stderr, "unknown command %s\n", cmd.c_str());

@@ -161,4 +161,55 @@ private:
 };
 
 }  // namespace Encoding
+
+// Mirrors PolarCode::Puncturer (include/polarcode/puncturer.h, src/polarcode/puncturer.cpp): same method names.
+class Puncturer {
+public:
+    Puncturer(size_t blockLength, const std::vector<unsigned>& frozenBitPositions, int device = 0)
+    {
+        std::vector<uint32_t> f(frozenBitPositions.begin(), frozenBitPositions.end());
+        const int rc = ppu_create(blockLength, f.data(), f.size(), device, &h_);
+        if (rc == PCD_ERR_PUNCTURE) throw std::out_of_range(pcd_last_error());  // as the reference does
+        if (rc == PCD_ERR_INVALID_ARG) throw std::invalid_argument(pcd_last_error());
+        if (rc) throw std::runtime_error(pcd_last_error());
+    }
+    ~Puncturer() { ppu_destroy(h_); }
+    Puncturer(const Puncturer&) = delete;
+    Puncturer& operator=(const Puncturer&) = delete;
+
+    size_t blockLength() const { return ppu_block_length(h_); }
+    size_t parentBlockLength() const { return ppu_parent_block_length(h_); }
+    std::vector<unsigned> blockOutputPositions() const
+    {
+        std::vector<uint32_t> p(ppu_output_positions(h_, nullptr, 0));
+        ppu_output_positions(h_, p.data(), p.size());
+        return std::vector<unsigned>(p.begin(), p.end());
+    }
+    template <typename T>
+    void puncture(T* pOutput, const T* pInput, size_t rows = 1, bool device_pointers = false, void* hip_stream = nullptr)
+    {
+        static_assert(sizeof(T) == 1 || sizeof(T) == 4 || sizeof(T) == 8, "uint8, float or double elements");
+        check(ppu_puncture(h_, pInput, rows, pOutput, sizeof(T), device_pointers ? PCD_MEM_DEVICE : PCD_MEM_HOST, hip_stream));
+    }
+    template <typename T>
+    void depuncture(T* pOutput, const T* pInput, size_t rows = 1, bool device_pointers = false, void* hip_stream = nullptr)
+    {
+        static_assert(sizeof(T) == 1 || sizeof(T) == 4 || sizeof(T) == 8, "uint8, float or double elements");
+        check(ppu_depuncture(h_, pInput, rows, pOutput, sizeof(T), device_pointers ? PCD_MEM_DEVICE : PCD_MEM_HOST, hip_stream));
+    }
+    void puncturePacked(unsigned char* pOutput, const unsigned char* pInput, size_t rows = 1)
+    {
+        check(ppu_puncture_packed(h_, pInput, rows, pOutput, PCD_MEM_HOST, nullptr));
+    }
+
+private:
+    static void check(int rc)
+    {
+        if (rc == PCD_OK) return;
+        if (rc == PCD_ERR_INVALID_ARG) throw std::invalid_argument(pcd_last_error());
+        throw std::runtime_error(pcd_last_error());
+    }
+    ppu_puncturer* h_ = nullptr;
+};
+
 }  // namespace PolarAmd

@@ -18,7 +18,7 @@ import numpy as np
 from .construction import frozen_bits  # noqa: E402,F401  (pypolar.frozen_bits)
 from .detector import Detector          # noqa: E402,F401  (pypolar.Detector)
 
-__all__ = ["PolarDecoder", "PolarEncoder", "Detector", "frozen_bits", "PolarAmdError", "library_path", "load_library", "C_SYMBOLS"]
+__all__ = ["PolarDecoder", "PolarEncoder", "Puncturer", "Detector", "frozen_bits", "PolarAmdError", "library_path", "load_library", "C_SYMBOLS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PYPOLAR_AMD_LIB: load another build of the same library (kernel experiments); never a fallback
@@ -36,6 +36,8 @@ C_SYMBOLS = [
     "pce_create", "pce_destroy", "pce_set_error_detection", "pce_set_systematic", "pce_is_systematic",
     "pce_block_length", "pce_info_length", "pce_info_bytes", "pce_code_bytes", "pce_frozen_bits",
     "pce_error_detection_mode", "pce_encode",
+    "ppu_create", "ppu_destroy", "ppu_block_length", "ppu_parent_block_length", "ppu_output_positions",
+    "ppu_puncture", "ppu_depuncture", "ppu_puncture_packed",
 ]
 
 
@@ -114,6 +116,20 @@ def load_library():
     lib.pce_error_detection_mode.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.pce_encode.restype = C.c_int
     lib.pce_encode.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
+    lib.ppu_create.restype = C.c_int
+    lib.ppu_create.argtypes = [C.c_size_t, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.ppu_destroy.restype = None
+    lib.ppu_destroy.argtypes = [vp]
+    for f in ("ppu_block_length", "ppu_parent_block_length"):
+        getattr(lib, f).restype = C.c_size_t
+        getattr(lib, f).argtypes = [vp]
+    lib.ppu_output_positions.restype = C.c_size_t
+    lib.ppu_output_positions.argtypes = [vp, vp, C.c_size_t]
+    for f in ("ppu_puncture", "ppu_depuncture"):
+        getattr(lib, f).restype = C.c_int
+        getattr(lib, f).argtypes = [vp, vp, C.c_size_t, vp, C.c_uint, C.c_int, vp]
+    lib.ppu_puncture_packed.restype = C.c_int
+    lib.ppu_puncture_packed.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
     _lib = lib
     return lib
 
@@ -129,6 +145,8 @@ def _raise(code):
         raise RuntimeError(msg)
     if code == -6:      # std::runtime_error("Unknown Error detector requested!")
         raise RuntimeError(msg)
+    if code == -10:     # std::out_of_range from Puncturer::Puncturer             -> IndexError via pybind11
+        raise IndexError(msg)
     if code == -1:
         raise ValueError(msg)
     if code == -3:
@@ -443,3 +461,144 @@ class PolarEncoder:
         if rc:
             _raise(rc)
         return code
+
+
+class Puncturer:
+    """``pypolar.Puncturer(blockLength, frozenBitPositions)`` (puncturer_python.cc:21-150): rate matching by removing
+    the first ``parentBlockLength - blockLength`` frozen positions of the parent code."""
+
+    _DTYPES = (np.float64, np.float32, np.uint8)   # overload order of the binding: double, float, uint8
+
+    def __init__(self, blockLength, frozenBitPositions, device=0):
+        lib = load_library()
+        frozen = np.ascontiguousarray(np.asarray(frozenBitPositions, dtype=np.int64).astype(np.uint32))
+        self._h = C.c_void_p()
+        rc = lib.ppu_create(int(blockLength), frozen.ctypes.data_as(C.c_void_p), frozen.size, int(device), C.byref(self._h))
+        if rc:
+            self._h = None
+            _raise(rc)
+        self._lib = lib
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.ppu_destroy(h)
+            except Exception:  # interpreter shutdown: the library may already be gone
+                pass
+            self._h = None
+
+    def blockLength(self):
+        return int(self._lib.ppu_block_length(self._h))
+
+    def parentBlockLength(self):
+        return int(self._lib.ppu_parent_block_length(self._h))
+
+    def blockOutputPositions(self):
+        n = self._lib.ppu_output_positions(self._h, None, 0)
+        out = np.zeros(n, np.uint32)
+        self._lib.ppu_output_positions(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return [int(x) for x in out]
+
+    @classmethod
+    def _as_supported(cls, array):
+        """pybind11 picks the overload whose dtype matches exactly, otherwise converts to the first one (double)"""
+        a = np.asarray(array)
+        if a.dtype.type not in cls._DTYPES:
+            a = a.astype(np.float64)
+        return np.ascontiguousarray(a)
+
+    def _run(self, fn, a, out_cols):
+        out = np.zeros((a.shape[0], out_cols), a.dtype)
+        rc = fn(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0], out.ctypes.data_as(C.c_void_p), a.dtype.itemsize,
+                PCD_MEM_HOST, None)
+        if rc:
+            _raise(rc)
+        return out
+
+    # ---- one vector (the reference's interface) --------------------------------------------------------
+    def puncture(self, array):
+        a = self._as_supported(array)
+        if a.ndim != 1:
+            raise RuntimeError("Only ONE-dimensional vectors allowed!")
+        if a.size != self.parentBlockLength():
+            raise RuntimeError("Input vector size != parentBlockSize!")
+        return self._run(self._lib.ppu_puncture, a.reshape(1, -1), self.blockLength())[0]
+
+    def depuncture(self, array):
+        a = self._as_supported(array)
+        if a.ndim != 1:
+            raise RuntimeError("Only ONE-dimensional vectors allowed!")
+        if a.size != self.blockLength():
+            raise RuntimeError("Input vector size != blockSize!")
+        return self._run(self._lib.ppu_depuncture, a.reshape(1, -1), self.parentBlockLength())[0]
+
+    def puncturePacked(self, array):
+        a = np.ascontiguousarray(np.asarray(array), dtype=np.uint8)
+        if a.ndim != 1:
+            raise RuntimeError("Only ONE-dimensional vectors allowed!")
+        if a.size != self.parentBlockLength() // 8:
+            raise RuntimeError("Input vector size != parentBlockSize!")
+        return self.puncture_packed_batch(a.reshape(1, -1))[0]
+
+    # ---- batched entry points (no reference counterpart): numpy (host) or torch CUDA tensors (device) ----
+    def _batch(self, fn, x, in_cols, out_cols, out, stream):
+        if _is_torch(x):
+            import torch
+
+            if not x.is_cuda:
+                return torch.from_numpy(self._batch(fn, x.numpy(), in_cols, out_cols, None, None))
+            if x.dtype not in (torch.float64, torch.float32, torch.uint8):
+                x = x.double()
+            x = x.contiguous()
+            if x.dim() != 2 or x.shape[1] != in_cols:
+                raise ValueError(f"expected shape [B, {in_cols}]")
+            if out is None:
+                out = torch.empty((x.shape[0], out_cols), dtype=x.dtype, device=x.device)
+            if stream is None:
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+            rc = fn(self._h, C.c_void_p(x.data_ptr()), x.shape[0], C.c_void_p(out.data_ptr()), x.element_size(),
+                    PCD_MEM_DEVICE, C.c_void_p(stream))
+            if rc:
+                _raise(rc)
+            return out
+        a = self._as_supported(x)
+        if a.ndim != 2 or a.shape[1] != in_cols:
+            raise ValueError(f"expected shape [B, {in_cols}]")
+        return self._run(fn, a, out_cols)
+
+    def puncture_batch(self, x, out=None, stream=None):
+        """[B, parentBlockLength] -> [B, blockLength] (float64 / float32 / uint8 elements)"""
+        return self._batch(self._lib.ppu_puncture, x, self.parentBlockLength(), self.blockLength(), out, stream)
+
+    def depuncture_batch(self, x, out=None, stream=None):
+        """[B, blockLength] -> [B, parentBlockLength], punctured positions 0 (e.g. LLRs for PolarDecoder.decode_batch)"""
+        return self._batch(self._lib.ppu_depuncture, x, self.blockLength(), self.parentBlockLength(), out, stream)
+
+    def puncture_packed_batch(self, x, out=None, stream=None):
+        """packed code words uint8 [B, parentBlockLength / 8] -> [B, blockLength / 8]"""
+        nin, nout = self.parentBlockLength() // 8, self.blockLength() // 8
+        if _is_torch(x) and x.is_cuda:
+            import torch
+
+            x = x.to(torch.uint8).contiguous()
+            if x.dim() != 2 or x.shape[1] != nin:
+                raise ValueError(f"expected shape [B, {nin}]")
+            if out is None:
+                out = torch.empty((x.shape[0], nout), dtype=torch.uint8, device=x.device)
+            if stream is None:
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+            rc = self._lib.ppu_puncture_packed(self._h, C.c_void_p(x.data_ptr()), x.shape[0], C.c_void_p(out.data_ptr()),
+                                               PCD_MEM_DEVICE, C.c_void_p(stream))
+            if rc:
+                _raise(rc)
+            return out
+        a = np.ascontiguousarray(np.asarray(x), dtype=np.uint8)
+        if a.ndim != 2 or a.shape[1] != nin:
+            raise ValueError(f"expected shape [B, {nin}]")
+        o = np.zeros((a.shape[0], nout), np.uint8)
+        rc = self._lib.ppu_puncture_packed(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0], o.ctypes.data_as(C.c_void_p),
+                                           PCD_MEM_HOST, None)
+        if rc:
+            _raise(rc)
+        return o

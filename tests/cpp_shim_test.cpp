@@ -36,6 +36,34 @@ int main(int argc, char** argv)
     PolarAmd::Encoding::Encoder enc(8, frozen);
     if (enc.blockLength() != 8 || enc.infoLength() != 4 || !enc.isSystematic()) return 11;
     if (enc.getErrorDetectionMode() != "DUMMY-0" || enc.frozenBits() != frozen) return 12;  // encoder.cpp:18
+    {
+        PolarAmd::Puncturer punc(6, frozen);   // parent 8, positions 0 and 1 removed
+        if (punc.blockLength() != 6 || punc.parentBlockLength() != 8) return 14;
+        if (punc.blockOutputPositions() != std::vector<unsigned>({ 2, 3, 4, 5, 6, 7 })) return 15;
+        threw = false;
+        try {
+            PolarAmd::Puncturer bad(3, std::vector<unsigned>{ 0 });  // parent 4 needs 1 position: ok; 
+        } catch (const std::out_of_range&) {
+            threw = true;
+        }
+        if (threw) return 16;
+        threw = false;
+        try {
+            PolarAmd::Puncturer bad(5, std::vector<unsigned>{ 0, 1 });  // parent 8 needs 3 positions, 2 frozen
+        } catch (const std::out_of_range&) {
+            threw = true;
+        }
+        if (!threw) return 17;
+        if (gpu) {
+            const float in[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
+            float pun[6], dep[8];
+            punc.puncture<float>(pun, in);
+            punc.depuncture<float>(dep, pun);
+            for (int i = 0; i < 6; ++i)
+                if (pun[i] != (float)(i + 2)) return 18;
+            if (dep[0] != 0.0f || dep[1] != 0.0f || dep[7] != 7.0f) return 19;
+        }
+    }
     if (gpu) {
         // systematic code word of info bits 1111 on positions {3,5,6,7}: x = u G with u_frozen = 0 is 0x17 -> after
         // the systematic re-encode the information positions carry the information bits

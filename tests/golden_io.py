@@ -70,7 +70,7 @@ def load(path):
 
 def all_files(pattern="*.bin"):
     """decoder fixtures ('PFX1' records); the encoder fixture enc.bin has its own loader"""
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, pattern)) if os.path.basename(f) != "enc.bin")
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, pattern)) if os.path.basename(f) not in ("enc.bin", "punc.bin"))
 
 
 ENC_MAGIC = 0x31454650
@@ -122,3 +122,48 @@ def load_named(name):
     fx = load(os.path.join(GOLDEN_DIR, name))
     assert len(fx) == 1
     return fx[0]
+
+
+PUNC_MAGIC = 0x31504650
+
+
+@dataclass
+class PuncFixture:
+    name: str
+    M: int                   # punctured block length
+    N: int                   # parent block length
+    frozen: np.ndarray       # uint32[nF]
+    positions: np.ndarray    # uint32[M]  Puncturer::blockOutputPositions()
+    x: np.ndarray            # float32[count, N]
+    punctured: np.ndarray    # float32[count, M]   puncture(x)
+    depunctured: np.ndarray  # float32[count, N]   depuncture(punctured)
+    packed_in: np.ndarray    # uint8[count, N/8]
+    packed_out: np.ndarray   # uint8[count, M/8]   puncturePacked(packed_in)  (only meaningful if M % 8 == 0)
+
+    @property
+    def count(self):
+        return self.x.shape[0]
+
+
+def load_punc(path=None):
+    path = path or os.path.join(GOLDEN_DIR, "punc.bin")
+    raw = np.fromfile(path, dtype=np.uint8)
+    pos, idx, out = 0, 0, []
+    while pos < raw.size:
+        hdr = raw[pos:pos + 40].view(np.uint32)
+        assert hdr[0] == PUNC_MAGIC, f"bad magic in {path} @ {pos}"
+        _, M, N, K, nF, count = (int(x) for x in hdr[:6])
+        pos += 40
+        frozen = raw[pos:pos + 4 * nF].view(np.uint32).copy(); pos += 4 * nF
+        positions = raw[pos:pos + 4 * M].view(np.uint32).copy(); pos += 4 * M
+        rec = 4 * N + 4 * M + 4 * N + N // 8 + M // 8
+        body = raw[pos:pos + rec * count].reshape(count, rec); pos += rec * count
+        o = 0
+        x = body[:, o:o + 4 * N].copy().view(np.float32).reshape(count, N); o += 4 * N
+        pu = body[:, o:o + 4 * M].copy().view(np.float32).reshape(count, M); o += 4 * M
+        de = body[:, o:o + 4 * N].copy().view(np.float32).reshape(count, N); o += 4 * N
+        pi = body[:, o:o + N // 8].copy(); o += N // 8
+        po = body[:, o:o + M // 8].copy()
+        out.append(PuncFixture(f"punc.bin#{idx}", M, N, frozen, positions, x, pu, de, pi, po))
+        idx += 1
+    return out

@@ -103,3 +103,40 @@ def scl_trace(N, L, frozen, llr_row, cap=4096):
     tr = np.zeros((cap, 1 + L), np.float32)
     n = lib().po_scl_trace(N, L, _p(frozen), frozen.size, _p(a), _p(tr), cap)
     return tr[:n]
+
+
+def punc_positions(M, frozen):
+    """-> (positions uint32[M], parent block length) or raises IndexError like the reference (std::out_of_range)"""
+    frozen = np.ascontiguousarray(frozen, dtype=np.uint32)
+    N = 1
+    while N < M:
+        N <<= 1
+    pos = np.zeros(M, np.uint32)
+    par = C.c_uint()
+    L = lib()
+    L.po_punc_positions.restype = C.c_int
+    rc = L.po_punc_positions(C.c_uint(M), _p(frozen), C.c_uint(frozen.size), _p(pos), C.byref(par))
+    if rc:
+        raise IndexError("Number of required puncturing positions exceeds frozen bit positions!")
+    return pos, int(par.value)
+
+
+def puncture_f32(pos, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(pos.size, np.float32)
+    lib().po_puncture_f32(_p(pos), C.c_uint(pos.size), _p(x), _p(out))
+    return out
+
+
+def depuncture_f32(pos, N, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(N, np.float32)
+    lib().po_depuncture_f32(_p(pos), C.c_uint(pos.size), C.c_uint(N), _p(x), _p(out))
+    return out
+
+
+def puncture_packed(pos, x):
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    out = np.zeros(pos.size // 8, np.uint8)
+    lib().po_puncture_packed(_p(pos), C.c_uint(pos.size), _p(x), _p(out))
+    return out

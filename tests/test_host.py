@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol(built_library):
     import pypolar_amd
     hdr = open(os.path.join(ROOT, "include", "polar_amd.h")).read()
-    declared = sorted(set(re.findall(r"\b(pc[de]_[a-z0-9_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(p(?:cd|ce|pu)_[a-z0-9_]+)\s*\(", hdr)))
     assert declared == sorted(pypolar_amd.C_SYMBOLS)
     for sym in declared:
         assert hasattr(built_library, sym), sym
@@ -258,3 +258,26 @@ def test_encoder_surface_without_gpu(built_library):
         with pytest.raises(pypolar_amd.PolarAmdError):
             e.encode_vector(np.zeros(64, np.uint8))
 
+
+
+# ---- puncturer host side: pypolar.Puncturer surface (puncturer_python.cc:21-150, qa_pypolar_puncturer.py:29-52) ----
+def test_puncturer_surface_without_gpu(built_library):
+    import pypolar_amd
+    for fx in gio.load_punc():
+        p = pypolar_amd.Puncturer(fx.M, fx.frozen)
+        assert (p.blockLength(), p.parentBlockLength()) == (fx.M, fx.N)
+        assert p.blockOutputPositions() == [int(x) for x in fx.positions]
+    F = _frozen("cfg3_n1024_k512_l8_crc24_awgn.bin")
+    p = pypolar_amd.Puncturer(864, F)
+    with pytest.raises(RuntimeError, match="Only ONE-dimensional vectors allowed!"):
+        p.puncture(np.zeros((2, 1024), np.float32))
+    with pytest.raises(RuntimeError, match="Input vector size != parentBlockSize!"):
+        p.puncture(np.zeros(1000, np.float32))
+    with pytest.raises(RuntimeError, match="Input vector size != blockSize!"):
+        p.depuncture(np.zeros(1024, np.float32))
+    with pytest.raises(IndexError, match="Number of required puncturing positions exceeds frozen bit positions!"):
+        pypolar_amd.Puncturer(513, F[:100])
+    import torch
+    if not torch.cuda.is_available():  # no CPU fallback
+        with pytest.raises(pypolar_amd.PolarAmdError):
+            p.puncture(np.zeros(1024, np.float32))

@@ -139,3 +139,19 @@ def test_oracle_encoder_matches_reference_vectors():
             assert np.array_equal(cw, fx.cw[r]), (fx.name, r, fx.N, fx.K, fx.systematic)
             rows += 1
     assert rows > 400
+
+
+# ---- puncturer: oracle vs the reference's Puncturer (tests/golden/punc.bin) -------------------------------------
+def test_oracle_puncturer_matches_reference_vectors():
+    fxs = gio.load_punc()
+    assert len(fxs) >= 15
+    for fx in fxs:
+        pos, parent = ob.punc_positions(fx.M, fx.frozen)
+        assert parent == fx.N and np.array_equal(pos, fx.positions), fx.name
+        for r in range(fx.count):
+            assert np.array_equal(ob.puncture_f32(pos, fx.x[r]), fx.punctured[r]), fx.name
+            assert np.array_equal(ob.depuncture_f32(pos, fx.N, fx.punctured[r]), fx.depunctured[r]), fx.name
+            if fx.M % 8 == 0:
+                assert np.array_equal(ob.puncture_packed(pos, fx.packed_in[r]), fx.packed_out[r]), fx.name
+    with pytest.raises(IndexError):   # std::out_of_range puncturer.cpp:56-59
+        ob.punc_positions(513, np.arange(10, dtype=np.uint32))
