@@ -49,13 +49,8 @@ CONFIGS = {
 
 
 def config_frozen_set(cfg):
-    """BB construction, or (cfg 4) the 5G-table set: the 3GPP reliability table is not shipped, the set is read as
-    data from the golden fixture the reference produced for this configuration"""
-    if cfg.get("ctor") == "5G":
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import golden_io as gio
-        return gio.load_named("cfg4_n1024_k176_l8_crc11_awgn.bin").frozen
-    return frozen_bits(cfg["N"], cfg["K"], cfg["dsnr"], "BB")
+    """BB construction, or (cfg 4) the 5G construction (3GPP TS 38.212 polar sequence)"""
+    return frozen_bits(cfg["N"], cfg["K"], cfg["dsnr"], cfg.get("ctor", "BB"))
 
 
 def make_batch(cfg, frozen, B, device, seed):

@@ -28,6 +28,9 @@
 //         u32 hdr[10] = {0x31504650 'PFP1', M, N, K, nF, count, 0, 0, 0, 0}, u32 F[nF], u32 positions[M],
 //         count x { f32 in[N] | f32 punctured[M] | f32 depunctured[N] (of `punctured`) | u8 packed_in[N/8] | u8 packed_out[M/8] }
 //   punctime M N K ctor dsnr threads seconds     CPU throughput of depuncture<float> (rows/s)
+//   nrseq out.u16                 the order in which the "5G" construction (3GPP TS 38.212 Table 5.3.1.2-1 as
+//         implemented by Construction::frozen_bits(1024, K, *, "5G")) freezes the 1024 positions: entry i is the
+//         position that joins the frozen set when K drops from 1024 - i to 1023 - i; 1024 little-endian u16
 //   frozen N K ctor dsnr          prints the frozen set (one index per line)
 //   crc   size type hexbytes      prints Detector::calculate()/check() for KAT pinning
 //
@@ -432,6 +435,26 @@ static int cmd_punctime(int argc, char** argv)
     return 0;
 }
 
+static int cmd_nrseq(int argc, char** argv)
+{
+    if (argc < 3) return 2;
+    std::vector<uint16_t> seq;
+    std::vector<unsigned> prev;
+    for (unsigned i = 0; i < 1024; ++i) {
+        auto cur = Construction::frozen_bits(1024, 1024 - (i + 1), 0.0f, "5G");
+        std::vector<unsigned> diff;
+        std::set_difference(cur.begin(), cur.end(), prev.begin(), prev.end(), std::back_inserter(diff));
+        if (diff.size() != 1) { fprintf(stderr, "nrseq: step %u adds %zu positions\n", i, diff.size()); return 1; }
+        seq.push_back((uint16_t)diff[0]);
+        prev = cur;
+    }
+    FILE* f = fopen(argv[2], "wb");
+    if (!f) { perror(argv[2]); return 1; }
+    fwrite(seq.data(), 2, seq.size(), f);
+    fclose(f);
+    return 0;
+}
+
 static int cmd_frozen(int argc, char** argv)
 {
     if (argc < 6) return 2;
@@ -465,6 +488,7 @@ int main(int argc, char** argv)
     if (cmd == "enc") return cmd_enc(argc, argv);
     if (cmd == "enctime") return cmd_enctime(argc, argv);
     if (cmd == "punc") return cmd_punc(argc, argv);
+    if (cmd == "nrseq") return cmd_nrseq(argc, argv);
     if (cmd == "punctime") return cmd_punctime(argc, argv);
     if (cmd == "frozen") return cmd_frozen(argc, argv);
     if (cmd == "crc") return cmd_crc(argc, argv);

@@ -7,6 +7,7 @@ parameter recursion in double precision from a float32 initial value, a STABLE d
 Checked against the frozen sets stored in the golden fixtures (tests/test_host.py).
 """
 import math
+import os
 
 import numpy as np
 
@@ -32,8 +33,7 @@ def frozen_bits(blockLength, infoLength, designSNR=0.0, constructor_type="BB"):
     if "be" in t:
         return beta_expansion_frozen_bits(N, K)
     if "5g" in t:
-        raise NotImplementedError("the 5G reliability table is not shipped; pass that frozen set explicitly "
-                                  "(it is a plain index list)")
+        return nr_sequence_frozen_bits(N, K)
     z = bhattacharyya_parameters(N, K, designSNR)
     order = np.argsort(-z, kind="stable")     # stable descending: ties keep ascending index order
     return np.sort(order[: N - K]).astype(np.uint32)
@@ -54,3 +54,32 @@ def beta_expansion_frozen_bits(N, K):
         weights[i] = acc
     order = np.argsort(weights, kind="stable")
     return np.sort(order[: N - K]).astype(np.uint32)
+
+
+_NR_SEQUENCE = None
+
+
+def nr_polar_sequence():
+    """The polar sequence of 3GPP TS 38.212 Table 5.3.1.2-1 (positions in ascending reliability), as the reference's
+    "5G" construction uses it.  Shipped as data (``data/nr_polar_sequence_1024.u16``, produced by running the
+    reference: ``oracle/_ref/ref_harness nrseq``)."""
+    global _NR_SEQUENCE
+    if _NR_SEQUENCE is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "nr_polar_sequence_1024.u16")
+        q = np.fromfile(path, dtype="<u2").astype(np.uint32)
+        assert q.size == 1024 and np.array_equal(np.sort(q), np.arange(1024))
+        _NR_SEQUENCE = q
+    return _NR_SEQUENCE
+
+
+def nr_sequence_frozen_bits(N, K):
+    """``frozen_bits(N, K, _, "5G")`` (reference: src/polarcode/construction/fiveGList.cpp:20-43): the first N - K
+    entries of the 1024-entry sequence, sorted.  Like the reference, entries are NOT filtered by ``< N``, so the
+    result is only a valid frozen set for N = 1024; N > 1024 raises as the reference does."""
+    if N <= 0 or (1 << int(math.log2(N))) != N:
+        raise ValueError("new blockLength is not a power of 2!")
+    if N > 1024:
+        raise ValueError("5G standard does not allow for block size N > 1024!")
+    if N < K:
+        raise ValueError(f"Invalid polar code({N}, {K})")
+    return np.sort(nr_polar_sequence()[: N - K]).astype(np.uint32)

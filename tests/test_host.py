@@ -281,3 +281,17 @@ def test_puncturer_surface_without_gpu(built_library):
     if not torch.cuda.is_available():  # no CPU fallback
         with pytest.raises(pypolar_amd.PolarAmdError):
             p.puncture(np.zeros(1024, np.float32))
+
+
+def test_frozen_bits_5g_matches_reference_sets():
+    """pypolar.frozen_bits(..., "5G"): the cfg 4 fixture (K = 176) and the encoder / puncturer fixtures built on 5G sets"""
+    from pypolar_amd.construction import frozen_bits
+    fx = gio.load_named("cfg4_n1024_k176_l8_crc11_awgn.bin")
+    assert np.array_equal(frozen_bits(1024, 176, 0.0, "5G"), fx.frozen)
+    for e in gio.load_enc():
+        if e.N == 1024 and e.K == 176:
+            assert np.array_equal(frozen_bits(1024, 176, 1.0, "5g"), e.frozen)
+    with pytest.raises(ValueError, match="5G standard does not allow for block size N > 1024!"):
+        frozen_bits(2048, 1024, 0.0, "5G")
+    q = frozen_bits(1024, 1000, 0.0, "5G")
+    assert q.tolist() == sorted([0, 1, 2, 4, 8, 16, 32, 3, 5, 64, 9, 6, 17, 10, 18, 128, 12, 33, 65, 20, 256, 34, 24, 36])
