@@ -31,6 +31,8 @@
 //   nrseq out.u16                 the order in which the "5G" construction (3GPP TS 38.212 Table 5.3.1.2-1 as
 //         implemented by Construction::frozen_bits(1024, K, *, "5G")) freezes the 1024 positions: entry i is the
 //         position that joins the frozen set when K drops from 1024 - i to 1023 - i; 1024 little-endian u16
+//   sccheck in.txt out.txt        every input line "N f0 f1 ..." is a frozen set; the output repeats the line with a leading
+//         1 (FastSscAvxFloat(N, F) constructs) or 0 (it throws std::invalid_argument, fastssc_avx_float.cpp:820-844)
 //   frozen N K ctor dsnr          prints the frozen set (one index per line)
 //   crc   size type hexbytes      prints Detector::calculate()/check() for KAT pinning
 //
@@ -455,6 +457,43 @@ static int cmd_nrseq(int argc, char** argv)
     return 0;
 }
 
+static int cmd_sccheck(int argc, char** argv)
+{
+    if (argc < 4) return 2;
+    FILE* in = fopen(argv[2], "r");
+    FILE* out = fopen(argv[3], "w");
+    if (!in || !out) { perror("sccheck"); return 1; }
+    char* line = nullptr;
+    size_t cap = 0;
+    while (getline(&line, &cap, in) > 0) {
+        std::vector<unsigned> v;
+        char* p = line;
+        for (;;) {
+            char* e;
+            const unsigned long x = strtoul(p, &e, 10);
+            if (e == p) break;
+            v.push_back((unsigned)x);
+            p = e;
+        }
+        if (v.empty()) continue;
+        const unsigned N = v[0];
+        std::vector<unsigned> F(v.begin() + 1, v.end());
+        int ok = 1;
+        try {
+            Decoding::FastSscAvxFloat dec(N, F);
+        } catch (const std::invalid_argument&) {
+            ok = 0;
+        }
+        fprintf(out, "%d %u", ok, N);
+        for (unsigned f : F) fprintf(out, " %u", f);
+        fprintf(out, "\n");
+    }
+    free(line);
+    fclose(in);
+    fclose(out);
+    return 0;
+}
+
 static int cmd_frozen(int argc, char** argv)
 {
     if (argc < 6) return 2;
@@ -489,6 +528,7 @@ int main(int argc, char** argv)
     if (cmd == "enctime") return cmd_enctime(argc, argv);
     if (cmd == "punc") return cmd_punc(argc, argv);
     if (cmd == "nrseq") return cmd_nrseq(argc, argv);
+    if (cmd == "sccheck") return cmd_sccheck(argc, argv);
     if (cmd == "punctime") return cmd_punctime(argc, argv);
     if (cmd == "frozen") return cmd_frozen(argc, argv);
     if (cmd == "crc") return cmd_crc(argc, argv);

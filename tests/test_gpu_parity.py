@@ -288,3 +288,42 @@ def test_large_host_pointer_batches(built_library, name, reps):
     if want_m:
         exp_m = np.tile(fx.metrics, (reps, 1))[: llr.shape[0]]
         assert np.array_equal(res[2].view(np.uint32), exp_m.view(np.uint32))
+
+
+@pytest.mark.parametrize("N", [16, 32, 64, 128, 256, 512])
+def test_random_frozen_sets_all_list_sizes(built_library, N):
+    """frozen sets no construction would produce (arbitrary subsets): every tree shape the node-selection rules can
+    emit, incl. the sets for which the reference's SC builder throws (both sides must refuse the same sets)"""
+    import pypolar_amd
+    rng = np.random.default_rng(7000 + N)
+    refused = 0
+    for trial in range(10):
+        K = int(rng.integers(1, N))
+        if trial == 0:
+            K = N - 1
+        if trial == 1:
+            K = 1
+        frozen = np.sort(rng.choice(N, N - K, replace=False)).astype(np.uint32)
+        nb = (K + 7) // 8
+        det = 8 if (nb >= 2 and K % 8 == 0) else 0
+        B = 20
+        llr = np.concatenate([rng.normal(0.3, 1.0, (B // 2, N)), rng.choice([-2.0, -1.0, 1.0, 2.0], (B // 2, N))]).astype(np.float32)
+        for L in (1, 2, 4, 8, 16):
+            try:
+                e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, det, llr)
+            except ValueError:
+                assert L == 1
+                with pytest.raises(ValueError):
+                    pypolar_amd.PolarDecoder(N, L, frozen, "float")
+                refused += 1
+                continue
+            d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
+            d.setErrorDetection(det, "crc")
+            if L == 1:
+                out, ok = d.decode_batch(llr)
+            else:
+                out, ok, met = d.decode_batch(llr, return_metrics=True)
+                assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), (N, K, L, trial)
+            assert np.array_equal(out, e_out), (N, K, L, trial)
+            assert np.array_equal(ok.astype(np.uint8), e_ok), (N, K, L, trial)
+    print(f"N={N}: {refused} sets refused by both SC builders")

@@ -295,3 +295,27 @@ def test_frozen_bits_5g_matches_reference_sets():
         frozen_bits(2048, 1024, 0.0, "5G")
     q = frozen_bits(1024, 1000, 0.0, "5G")
     assert q.tolist() == sorted([0, 1, 2, 4, 8, 16, 32, 3, 5, 64, 9, 6, 17, 10, 18, 128, 12, 33, 65, 20, 256, 34, 24, 36])
+
+
+def test_sc_builder_refuses_the_sets_the_reference_refuses(built_library):
+    """tests/golden/sc_accept.txt: 360 random frozen sets with the verdict of the reference's FastSscAvxFloat constructor
+    (SURVEY Q6).  The oracle's builder and the product's decode-program compiler must refuse exactly the same sets."""
+    import pypolar_amd
+    n_ok = n_bad = 0
+    for line in open(os.path.join(gio.GOLDEN_DIR, "sc_accept.txt")):
+        v = [int(x) for x in line.split()]
+        accepted, N, F = v[0], v[1], np.asarray(v[2:], np.uint32)
+        rc = ob.tree_stats(N, F, False)[0]
+        assert (rc == 0) == bool(accepted), (N, F.tolist())
+        if accepted:
+            d = pypolar_amd.PolarDecoder(N, 1, F, "float")
+            assert d.program_stats(False) == ob.tree_stats(N, F, False)[1:]
+            n_ok += 1
+        else:
+            with pytest.raises(ValueError):
+                pypolar_amd.PolarDecoder(N, 1, F, "float")
+            n_bad += 1
+        # the list decoder's builder accepts every set (createDecoder scl_avx_float.cpp:624-651 never throws)
+        d8 = pypolar_amd.PolarDecoder(N, 8, F, "float")
+        assert d8.program_stats(True) == ob.tree_stats(N, F, True)[1:]
+    assert n_ok >= 40 and n_bad >= 200
