@@ -257,7 +257,10 @@ void specialize_scl(pcd_decoder* d)
             continue;
         }
         if (in.op != pamd::SCL_F && in.op != pamd::SCL_G && in.op != pamd::SCL_COMBINE) continue;
-        const uint32_t aux = woff(s) | (woff(s - 1) << 9) | (((s - 1) * fb) << 18);
+        // 9-bit word offsets are only read by the ops on small stages (C_S, F_S, G_S: s <= 6); C_W takes just the
+        // slot shift -- woff(14) = 516 no longer fits 9 bits and used to spill into the shift field at N = 32768
+        const bool small = s <= 6;
+        const uint32_t aux = (small ? (woff(s) | (woff(s - 1) << 9)) : 0u) | (((s - 1) * fb) << 18);
         if (in.op == pamd::SCL_COMBINE) {
             in.op = (s - 1 < 5) ? pamd::SCL_C_S : pamd::SCL_C_W;
             in.off = aux;

@@ -327,3 +327,28 @@ def test_random_frozen_sets_all_list_sizes(built_library, N):
             assert np.array_equal(out, e_out), (N, K, L, trial)
             assert np.array_equal(ok.astype(np.uint8), e_ok), (N, K, L, trial)
     print(f"N={N}: {refused} sets refused by both SC builders")
+
+
+@pytest.mark.parametrize("L", [1, 2, 4, 8, 16])
+def test_maximum_block_length(built_library, L):
+    """N = 32768 (the largest block length the ABI accepts): SC and list decoding against the oracle"""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    N, K = 32768, 16384
+    frozen = frozen_bits(N, K, 0.0, "BB")
+    rng = np.random.default_rng(50 + L)
+    info = rng.integers(0, 256, (6, K // 8), dtype=np.uint8)
+    llr = np.empty((6, N), np.float32)
+    for r in range(6):
+        _, cw = ob.encode(N, frozen, 32, info[r])
+        llr[r] = 1.0 - 2.0 * np.unpackbits(cw)[:N] + rng.normal(0, 0.75 if r < 4 else 1.5, N)
+    d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
+    d.setErrorDetection(32, "crc")
+    e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, 32, llr)
+    if L == 1:
+        out, ok = d.decode_batch(llr)
+    else:
+        out, ok, met = d.decode_batch(llr, return_metrics=True)
+        assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32))
+    assert np.array_equal(out, e_out) and np.array_equal(ok.astype(np.uint8), e_ok)
+    assert e_ok[:4].all()
