@@ -352,3 +352,75 @@ def test_maximum_block_length(built_library, L):
         assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32))
     assert np.array_equal(out, e_out) and np.array_equal(ok.astype(np.uint8), e_ok)
     assert e_ok[:4].all()
+
+
+@pytest.mark.parametrize("N", [8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768])
+def test_grid_of_block_lengths_list_sizes_and_rates(built_library, N):
+    """every kernel instantiation and geometry once: all list sizes (incl. the ones between powers of two) x three
+    rates per block length, float / int8 input, systematic or not, a few noisy and tie-heavy rows each"""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    rng = np.random.default_rng(900 + N)
+    logN = N.bit_length() - 1
+    combos = 0
+    for L in (1, 2, 3, 4, 5, 7, 8, 12, 16, 24, 32):
+        lp = 1
+        while lp < L:
+            lp <<= 1
+        if L > 1 and logN * (lp.bit_length() - 1) > 64:
+            with pytest.raises(pypolar_amd.PolarAmdError):      # PCD_ERR_CAPACITY: documented limit
+                pypolar_amd.PolarDecoder(N, L, frozen_bits(N, N // 2, 0.0, "BB"), "float")
+            continue
+        for R in (1, 2, 3):
+            K = max(1, (N * R // 4) // 8 * 8) if N >= 32 else max(1, N * R // 4)
+            if K >= N:
+                continue
+            frozen = frozen_bits(N, K, 0.0, "BE" if (L + R) % 2 else "BB")
+            nb = (K + 7) // 8
+            det = 8 if (K % 8 == 0 and nb >= 2) else 0
+            variant = (L + R + logN) % 3            # 0: float, 1: non-systematic, 2: int8 input
+            B = 4 if N >= 8192 else 6
+            llr = np.concatenate([rng.normal(0.4, 1.0, (B // 2, N)) * 8.0, rng.choice([-3.0, -1.0, 1.0, 3.0], (B - B // 2, N))])
+            if variant == 2:
+                x = np.clip(np.round(llr), -127, 127).astype(np.int8)
+                ref_in = x.astype(np.float32)
+            else:
+                x = llr.astype(np.float32)
+                ref_in = x
+            d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
+            d.setErrorDetection(det, "crc")
+            d.setSystematic(variant != 1)
+            e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, det, ref_in, systematic=(variant != 1))
+            if L == 1:
+                out, ok = d.decode_batch(x)
+            else:
+                out, ok, met = d.decode_batch(x, return_metrics=True)
+                assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), (N, K, L, variant)
+            assert np.array_equal(out, e_out), (N, K, L, variant)
+            assert np.array_equal(ok.astype(np.uint8), e_ok), (N, K, L, variant)
+            combos += 1
+    assert combos >= 20
+
+
+@pytest.mark.parametrize("N,L", [(64, 2), (256, 4), (1024, 8), (1024, 32), (4096, 8), (4096, 16)])
+def test_mixed_decoder_grid(built_library, N, L):
+    """AdaptiveFloat (SC first, list decoding for the rows the detector rejects) against the oracle at several sizes:
+    rows near the SC failure threshold so that both branches are taken"""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    K = N // 2
+    frozen = frozen_bits(N, K, 0.0, "BB")
+    rng = np.random.default_rng(31 * N + L)
+    B = 48
+    info = rng.integers(0, 256, (B, K // 8), dtype=np.uint8)
+    llr = np.empty((B, N), np.float32)
+    for r in range(B):
+        _, cw = ob.encode(N, frozen, 8, info[r])
+        llr[r] = 1.0 - 2.0 * np.unpackbits(cw)[:N] + rng.normal(0, 0.55 + 0.5 * (r % 4) / 3.0, N)
+    d = pypolar_amd.PolarDecoder(N, L, frozen, "mixed")
+    d.setErrorDetection(8, "crc")
+    out, ok = d.decode_batch(llr)
+    e_out, e_ok, _ = ob.decode_batch(N, L, frozen, 8, llr, dectype="mixed")
+    assert np.array_equal(out, e_out) and np.array_equal(ok.astype(np.uint8), e_ok)
+    sc_out, sc_ok, _ = ob.decode_batch(N, 1, frozen, 8, llr)
+    assert 0 < int(sc_ok.sum()) < B      # the batch exercises both the SC-only and the SC + list branch
