@@ -161,6 +161,10 @@ int ppu_depuncture(ppu_puncturer* u, const void* in, size_t rows, void* out, uns
 /* puncturePacked: rows x N/8 bytes -> rows x blockLength/8 bytes, bits MSB first (both lengths multiples of 8) */
 int ppu_puncture_packed(ppu_puncturer* u, const uint8_t* in, size_t rows, uint8_t* out, int mem, void* stream);
 
+/* the same for the SC decode program (16 lanes per codeword, i.e. N <= 2048) */
+int pcd_sc_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
+                   unsigned cap, unsigned* count);
+
 const char* pcd_last_error(void);
 const char* pcd_version(void);
 

@@ -764,6 +764,40 @@ int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t*
     return rc;
 }
 
+int pcd_sc_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
+                   unsigned cap, unsigned* count)
+{
+    if (!d || !llr_row || !cycles || !count) return fail(PCD_ERR_INVALID_ARG, "null argument");
+    if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
+    if (d->sc_lcl != 4) return fail(PCD_ERR_UNSUPPORTED, "the SC cycle profile exists for 16 lanes per codeword (N <= 2048) only");
+    int rc = ensure_device(d);
+    if (rc) return rc;
+    const unsigned n = (unsigned)d->sc_prog.ins.size();
+    *count = n;
+    uint32_t* dcyc = nullptr;
+    if ((rc = grow(d->d_in, d->d_in_cap, (size_t)d->N * 4))) return rc;
+    if ((rc = grow(d->d_out, d->d_out_cap, d->nb))) return rc;
+    if ((rc = grow(d->d_ok, d->d_ok_cap, 4))) return rc;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dcyc), (size_t)n * 4));
+    HIP_TRY(hipMemset(dcyc, 0, (size_t)n * 4));
+    HIP_TRY(hipMemcpy(d->d_in, llr_row, (size_t)d->N * 4, hipMemcpyHostToDevice));
+    pamd::DecodeParams P = base_params(d, d->d_in, 1, d->d_out, d->d_ok, nullptr);
+    P.cycles = dcyc;
+    for (int rep = 0; rep < 2 && !rc; ++rep) rc = run_sc(d, P, false, nullptr);  // second run: warm caches
+    if (!rc) {
+        HIP_TRY(hipDeviceSynchronize());
+        std::vector<uint32_t> h(n);
+        HIP_TRY(hipMemcpy(h.data(), dcyc, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (unsigned i = 0; i < n && i < cap; ++i) {
+            cycles[i] = h[i];
+            if (ops) ops[i] = d->sc_prog.ins[i].op;
+            if (stages) stages[i] = d->sc_prog.ins[i].stage;
+        }
+    }
+    (void)hipFree(dcyc);
+    return rc;
+}
+
 const char* pcd_last_error(void) { return g_err.c_str(); }
 const char* pcd_version(void) { return "polar_amd 0.1 (gfx950)"; }
 

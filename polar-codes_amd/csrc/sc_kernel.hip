@@ -90,7 +90,7 @@ __device__ __forceinline__ float reduce_add8(const float a[8])
     return ((((((a[0] + a[1]) + a[2]) + a[3]) + a[4]) + a[5]) + a[6]) + a[7];
 }
 
-template <int LCL, bool I8>
+template <int LCL, bool I8, bool DIAG = false>
 __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
 {
     constexpr int LC = 1 << LCL;
@@ -129,6 +129,8 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
             if (op == OP_END) break;
             iw_next = prog64[pc + 1];  // scalar load, in flight while this instruction executes
             const uint32_t s = (uint32_t)((iw >> 8) & 0xFF), n = 1u << s, h = n >> 1, off = (uint32_t)(iw >> 32);
+            uint64_t t_start = 0;
+            if (DIAG && P.cycles && grp == 0) t_start = __builtin_amdgcn_s_memtime();
 
             // the op body, instantiated for the two kinds of input: an LDS stage buffer, or (root) the channel row
             auto run = [&](auto x) {
@@ -375,6 +377,10 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                 run([&](uint32_t i) { return xs[i]; });
             }
             WAVE_SYNC();
+            if (DIAG && P.cycles && grp == 0) {  // diagnostics: cycles this instruction took for the first group
+                const uint64_t t_end = __builtin_amdgcn_s_memtime();
+                if (lane == 0) P.cycles[pc] = (uint32_t)(t_end - t_start);
+            }
         }
 
         // ---- output: FastSscAvxFloat::decode :940-955 ------------------------------------------
@@ -451,6 +457,12 @@ hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, uns
     dim3 g(grid), b(64 * waves_per_block);
     if (lcl == 3)
         return i8 ? launch_sc_k<3, true>(P, g, b, lds, st, occupancy) : launch_sc_k<3, false>(P, g, b, lds, st, occupancy);
+    if (lcl == 4 && P.cycles && !i8) {  // per-instruction cycle stamps (diagnostics)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((sc_decode_kernel<4, false, true>), g, b, lds, st, P);
+        return hipGetLastError();
+    }
     if (lcl == 4)
         return i8 ? launch_sc_k<4, true>(P, g, b, lds, st, occupancy) : launch_sc_k<4, false>(P, g, b, lds, st, occupancy);
     return i8 ? launch_sc_k<6, true>(P, g, b, lds, st, occupancy) : launch_sc_k<6, false>(P, g, b, lds, st, occupancy);

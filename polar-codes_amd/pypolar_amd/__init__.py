@@ -32,7 +32,8 @@ C_SYMBOLS = [
     "pcd_create", "pcd_destroy", "pcd_set_error_detection", "pcd_set_systematic", "pcd_is_systematic",
     "pcd_block_length", "pcd_info_length", "pcd_list_size", "pcd_frozen_bits", "pcd_error_detection_mode",
     "pcd_out_bytes", "pcd_decode_f32", "pcd_decode_i8", "pcd_program_stats", "pcd_launch_info",
-    "pcd_set_timing", "pcd_kernel_times", "pcd_scl_trace", "pcd_scl_profile", "pcd_last_error", "pcd_version",
+    "pcd_set_timing", "pcd_kernel_times", "pcd_scl_trace", "pcd_scl_profile", "pcd_sc_profile", "pcd_last_error",
+    "pcd_version",
     "pce_create", "pce_destroy", "pce_set_error_detection", "pce_set_systematic", "pce_is_systematic",
     "pce_block_length", "pce_info_length", "pce_info_bytes", "pce_code_bytes", "pce_frozen_bits",
     "pce_error_detection_mode", "pce_encode",
@@ -95,6 +96,8 @@ def load_library():
     lib.pcd_scl_trace.argtypes = [vp, vp, vp, C.c_uint]
     lib.pcd_scl_profile.restype = C.c_int
     lib.pcd_scl_profile.argtypes = [vp, vp, vp, vp, vp, C.c_uint, C.POINTER(C.c_uint)]
+    lib.pcd_sc_profile.restype = C.c_int
+    lib.pcd_sc_profile.argtypes = [vp, vp, vp, vp, vp, C.c_uint, C.POINTER(C.c_uint)]
     lib.pcd_last_error.restype = C.c_char_p
     lib.pcd_version.restype = C.c_char_p
     lib.pce_create.restype = C.c_int
@@ -324,6 +327,18 @@ class PolarDecoder:
         n = C.c_uint()
         rc = self._lib.pcd_scl_profile(self._h, a.ctypes.data_as(C.c_void_p), ops.ctypes.data_as(C.c_void_p),
                                        st.ctypes.data_as(C.c_void_p), cyc.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+        if rc:
+            _raise(rc)
+        k = min(cap, n.value)
+        return ops[:k], st[:k], cyc[:k]
+
+    def sc_profile(self, llr_row, cap=8192):
+        """diagnostics: (ops, stages, cycles) per SC program instruction for one row"""
+        a = np.ascontiguousarray(llr_row, dtype=np.float32)
+        ops = np.zeros(cap, np.uint8); st = np.zeros(cap, np.uint8); cyc = np.zeros(cap, np.uint32)
+        n = C.c_uint()
+        rc = self._lib.pcd_sc_profile(self._h, a.ctypes.data_as(C.c_void_p), ops.ctypes.data_as(C.c_void_p),
+                                      st.ctypes.data_as(C.c_void_p), cyc.ctypes.data_as(C.c_void_p), cap, C.byref(n))
         if rc:
             _raise(rc)
         k = min(cap, n.value)
