@@ -62,6 +62,7 @@ def load_library():
     if not os.path.exists(_LIB_PATH):
         raise ImportError(f"{_LIB_PATH} is missing: build it with `make -C polar-codes_amd` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(_LIB_PATH)
     vp, u32p = C.c_void_p, C.POINTER(C.c_uint32)
     lib.pcd_create.restype = C.c_int
@@ -135,6 +136,26 @@ def load_library():
     lib.ppu_puncture_packed.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
     _lib = lib
     return lib
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as the system one).  If this library pulled in
+    the system runtime first and torch its own copy later, the process would hold two HIP runtimes and the second one
+    finds no GPU ("No HIP GPUs are available").  So when a torch wheel with a bundled runtime is installed and not yet
+    loaded, its copy is loaded first and libpolar_amd.so binds to it.  PYPOLAR_AMD_SYSTEM_HIP=1 skips this."""
+    import sys
+    if os.environ.get("PYPOLAR_AMD_SYSTEM_HIP") or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- best effort: without it the system runtime is used
+        pass
 
 
 def _raise(code):
