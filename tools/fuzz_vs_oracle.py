@@ -18,7 +18,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
 n_cfg = n_rows = n_bad = n_refused = 0
 while time.time() < t_end:
-    logN = int(rng.integers(3, 14))
+    logN = int(rng.integers(3, 16))
     N = 1 << logN
     L = int(rng.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 8, 11, 16, 24, 32]))
     kind = int(rng.integers(0, 3))
@@ -39,7 +39,7 @@ while time.time() < t_end:
     sysm = bool(rng.integers(0, 2))
     i8 = bool(rng.integers(0, 4) == 0)
     dectype = "mixed" if (L > 1 and rng.integers(0, 5) == 0) else "float"
-    B = int(rng.integers(1, 60 if N <= 2048 else 12))
+    B = int(rng.integers(1, 60 if N <= 2048 else (12 if N <= 8192 else 4)))
     mode = rng.integers(0, 3, B)
     llr = np.where(mode[:, None] == 0, rng.normal(0.5, 1.0, (B, N)) * 6.0,
                    np.where(mode[:, None] == 1, rng.choice([-2.0, -1.0, 1.0, 2.0], (B, N)), rng.normal(0, 4.0, (B, N))))
