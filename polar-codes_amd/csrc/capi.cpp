@@ -60,6 +60,7 @@ struct pcd_decoder {
     // launch geometry
     unsigned sc_wave_words = 0, sc_wpb = 4;  // LDS words per codeword, waves per workgroup
     unsigned sc_virtual_top = 0;
+    unsigned sc_s0 = 0, sc_arena_cw_words = 0;  // SC: first LLR stage in the arena (logN = none), arena floats per codeword
     int sc_lcl = 4;                           // log2(lanes per codeword): 4 -> four codewords per wave
     int lpl = 3;
     unsigned cwl = 0;  // log2 codewords per wave of the list kernel
@@ -135,6 +136,19 @@ void compute_geometry(pcd_decoder* d)
     if (const char* e = std::getenv("PCD_SC_LCL")) {  // experiments
         const int v = std::atoi(e);
         d->sc_lcl = (v == 3 || v == 6) ? v : 4;
+    }
+    d->sc_s0 = d->logN;
+    d->sc_arena_cw_words = 0;
+    if (N >= 2048 && d->sc_virtual_top && !std::getenv("PCD_SC_NO_ARENA") && !std::getenv("PCD_SC_LCL")) {
+        // long blocks: keep 16 lanes per codeword (four codewords per wave) and move the LLR stages from s0 up into a
+        // per-codeword arena slice, s0 chosen so that a wave stays within 10 KB of LDS (16 waves per CU)
+        unsigned s0 = d->logN - 1;
+        while (s0 > 6 && 4u * (((1u << s0) + bitw + 3) & ~3u) * 4u > 10240u) --s0;
+        if (const char* e = std::getenv("PCD_SC_S0")) s0 = (unsigned)std::atoi(e);
+        d->sc_lcl = 4;
+        d->sc_s0 = s0;
+        d->sc_wave_words = ((1u << s0) + bitw + 3) & ~3u;
+        d->sc_arena_cw_words = (N >> 1) - (1u << s0);  // stages s0 .. logN - 2 (stage logN - 1 is recomputed)
     }
     d->sc_wpb = 1;  // single-wave workgroups: LDS granularity of one wave, nothing is shared between waves anyway
     if (const char* e = std::getenv("PCD_SC_WPB")) d->sc_wpb = (unsigned)std::max(1, std::atoi(e));
@@ -350,6 +364,8 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     P.wave_lds_words = d->sc_wave_words;
     P.metrics = nullptr;
     P.sc_virtual_top = d->sc_virtual_top;
+    P.s0 = d->sc_s0;
+    P.arena_wave_words = d->sc_arena_cw_words;  // (per codeword for the SC kernel)
     P.prog_root_g0r = (!d->sc_prog.ins.empty() && d->sc_prog.ins[0].op == pamd::SC_G0R) ? 1u : 0u;
     const unsigned cw_per_wave = 64u >> d->sc_lcl;
     const size_t lds = (size_t)d->sc_wpb * cw_per_wave * d->sc_wave_words * 4;
@@ -363,6 +379,11 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     const unsigned cw_per_block = d->sc_wpb * cw_per_wave;
     const unsigned need = (unsigned)((P.rows + cw_per_block - 1) / cw_per_block);
     const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->sc_blocks_per_cu)));
+    if (d->sc_arena_cw_words) {
+        int rc = grow(d->d_arena, d->d_arena_cap, (size_t)grid * d->sc_wpb * cw_per_wave * d->sc_arena_cw_words * sizeof(float));
+        if (rc) return rc;
+    }
+    P.arena = d->d_arena;
     HIP_TRY(pamd::launch_sc(P, d->sc_lcl, i8, grid, d->sc_wpb, lds, st));
     return PCD_OK;
 }
@@ -769,7 +790,8 @@ int pcd_sc_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* 
 {
     if (!d || !llr_row || !cycles || !count) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
-    if (d->sc_lcl != 4) return fail(PCD_ERR_UNSUPPORTED, "the SC cycle profile exists for 16 lanes per codeword (N <= 2048) only");
+    if (d->sc_lcl != 4 || d->sc_arena_cw_words)
+        return fail(PCD_ERR_UNSUPPORTED, "the SC cycle profile exists for the all-LDS kernel (N <= 1024) only");
     int rc = ensure_device(d);
     if (rc) return rc;
     const unsigned n = (unsigned)d->sc_prog.ins.size();

@@ -90,7 +90,9 @@ __device__ __forceinline__ float reduce_add8(const float a[8])
     return ((((((a[0] + a[1]) + a[2]) + a[3]) + a[4]) + a[5]) + a[6]) + a[7];
 }
 
-template <int LCL, bool I8, bool DIAG = false>
+// ARENA: LLR stages s0 <= t < logN - 1 live in a per-codeword slice of global memory (cache resident) instead of LDS,
+// so that long blocks keep four codewords per wave and 16 waves per CU (the list kernels do the same, scl_kernel.h).
+template <int LCL, bool I8, bool DIAG = false, bool ARENA = false>
 __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
 {
     constexpr int LC = 1 << LCL;
@@ -110,7 +112,10 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
     uint32_t* wl = smem + ((size_t)wib * CW + slot) * P.wave_lds_words;
     float* llr = reinterpret_cast<float*>(wl);
     const bool virt = P.sc_virtual_top != 0;          // stage logN-1 recomputed from the channel, not stored
-    uint32_t* bits = wl + (virt ? (N >> 1) : N);
+    const uint32_t s0 = ARENA ? P.s0 : logN;          // first LLR stage kept in the arena
+    uint32_t* bits = wl + (ARENA ? (1u << s0) : (virt ? (N >> 1) : N));
+    // this codeword's arena slice: stage t at offset (1 << t) - (1 << s0)
+    float* ar = ARENA ? P.arena + ((size_t)(blockIdx.x * wpb + wib) * CW + slot) * P.arena_wave_words - (1u << s0) : nullptr;
     const uint32_t wave0 = blockIdx.x * wpb + wib, nwaves = gridDim.x * wpb;
     const const_u64_ptr prog64 = (const_u64_ptr)(uintptr_t)P.prog;
     const uint32_t ngroups = (P.rows + CW - 1) / CW;
@@ -136,16 +141,29 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
             auto run = [&](auto x) {
                 switch (op) {
                 case SC_F:
-                    for (uint32_t i = l; i < h; i += LC) llr[h + i] = polar_f(x(i), x(h + i));
+                    if (ARENA && s - 1 >= s0)
+                        for (uint32_t i = l; i < h; i += LC) ar[h + i] = polar_f(x(i), x(h + i));
+                    else
+                        for (uint32_t i = l; i < h; i += LC) llr[h + i] = polar_f(x(i), x(h + i));
                     break;
                 case SC_G:
-                    for (uint32_t i = l; i < h; i += LC) {
-                        const uint32_t b = off + i;
-                        llr[h + i] = polar_g(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
+                    if (ARENA && s - 1 >= s0) {
+                        for (uint32_t i = l; i < h; i += LC) {
+                            const uint32_t b = off + i;
+                            ar[h + i] = polar_g(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
+                        }
+                    } else {
+                        for (uint32_t i = l; i < h; i += LC) {
+                            const uint32_t b = off + i;
+                            llr[h + i] = polar_g(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
+                        }
                     }
                     break;
                 case SC_G0R:
-                    for (uint32_t i = l; i < h; i += LC) llr[h + i] = x(i) + x(h + i);
+                    if (ARENA && s - 1 >= s0)
+                        for (uint32_t i = l; i < h; i += LC) ar[h + i] = x(i) + x(h + i);
+                    else
+                        for (uint32_t i = l; i < h; i += LC) llr[h + i] = x(i) + x(h + i);
                     break;
                 case SC_COMBINE:
                 case SC_COMBINE0R: {
@@ -372,9 +390,17 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     run([&](uint32_t i) { return ch(i) + ch(hN + i); });
                 else
                     run([&](uint32_t i) { return polar_g(ch(i), ch(hN + i), (bits[i >> 5] >> (i & 31u)) & 1u); });
+            } else if (ARENA && s >= s0) {
+                const float* xs = ar + n;  // written earlier by this wave, waited for below
+                run([&](uint32_t i) { return xs[i]; });
             } else {
                 const float* xs = llr + n;
                 run([&](uint32_t i) { return xs[i]; });
+            }
+            if (ARENA && (op == SC_F || op == SC_G || op == SC_G0R) && s - 1 >= s0) {
+                // the op stored LLRs to the arena: wait for the stores before other lanes of the wave read them
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             WAVE_SYNC();
             if (DIAG && P.cycles && grp == 0) {  // diagnostics: cycles this instruction took for the first group
@@ -457,6 +483,20 @@ hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, uns
     dim3 g(grid), b(64 * waves_per_block);
     if (lcl == 3)
         return i8 ? launch_sc_k<3, true>(P, g, b, lds, st, occupancy) : launch_sc_k<3, false>(P, g, b, lds, st, occupancy);
+    if (lcl == 4 && P.s0 < P.logN && !P.cycles) {  // long blocks: upper LLR stages in the arena
+        if (i8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, true, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<4, true, false, true>, (int)b.x, lds);
+            hipLaunchKernelGGL((sc_decode_kernel<4, true, false, true>), g, b, lds, st, P);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<4, false, false, true>, (int)b.x, lds);
+            hipLaunchKernelGGL((sc_decode_kernel<4, false, false, true>), g, b, lds, st, P);
+        }
+        return hipGetLastError();
+    }
     if (lcl == 4 && P.cycles && !i8) {  // per-instruction cycle stamps (diagnostics)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
