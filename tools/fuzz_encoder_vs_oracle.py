@@ -15,7 +15,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
 n_cfg = n_rows = n_bad = 0
+t_print = time.time()
 while time.time() < t_end:
+    if time.time() - t_print > 30:
+        t_print = time.time()
+        print(f"... {n_cfg} configurations, {n_rows} rows, {n_bad} mismatching", flush=True)
     N = 1 << int(rng.integers(3, 16))
     K = int(rng.integers(1, N))
     frozen = np.sort(rng.choice(N, N - K, replace=False)).astype(np.uint32)

@@ -17,7 +17,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
 n_cfg = n_rows = n_bad = n_refused = 0
+t_print = time.time()
 while time.time() < t_end:
+    if time.time() - t_print > 30:
+        t_print = time.time()
+        print(f"... {n_cfg} configurations, {n_rows} rows, {n_bad} mismatching", flush=True)
     logN = int(rng.integers(3, 16))
     N = 1 << logN
     L = int(rng.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 8, 11, 16, 24, 32]))
