@@ -767,6 +767,82 @@ __device__ __forceinline__ bool select_ranked(const CTX& c, const float (&val)[(
     return true;
 }
 
+// ---- candidate selection by threshold for long lists (several candidates per lane, one codeword per wave) -----
+// Ranking every candidate against all others costs (candidates)^2 / 64 compare pairs per lane (2 048 VALU instructions
+// for 256 SPC candidates at L = 32).  Here the newP-th largest key T is found first by a bit-wise search (32 rounds of
+// one compare per candidate register + scalar popcounts), the candidates >= T -- exactly newP unless several tie at
+// T -- are compacted into the scratch by prefix count, and only those are ranked against each other (one survivor per
+// lane).  Returns false on any tie that matters; the caller then runs the literal emulation.
+template <typename CTX, int LPL, int CPP>
+__device__ __forceinline__ bool select_threshold(const CTX& c, const float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
+                                                 uint32_t newP, float& nval, uint32_t& nidx)
+{
+    static_assert(CTX::CW == 1, "wave-wide ballots: one codeword per wave");
+    constexpr int LP = CTX::LP;
+    constexpr int CPL = (CPP >> LPL) ? (CPP >> LPL) : 1;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 __attribute__((address_space(3))) lds_u32x4;
+    typedef uint32_t __attribute__((address_space(3))) lds_u32;
+    lds_u32* skey = (lds_u32*)(uintptr_t)c.scratch;  // [0, 40): keys of the survivors, zero padded
+    lds_u32* sid = skey + 40;                        // [40, 80): their candidate slot ids
+    lds_u32* rk = skey + 80;                         // [80, 112): rank -> survivor number
+    uint32_t key[CPL];
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) {
+        const uint32_t q = (uint32_t)c.j * CPL + r;
+        const bool valid = (q < (uint32_t)CPP) && ((uint32_t)c.pl < c.P);
+        key[r] = valid ? okey(val[r]) : 0u;  // 0 is below every real key
+    }
+    uint32_t T = 0;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = T | (1u << b);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) cnt += (uint32_t)__popcll(ballot64(key[r] >= cand));
+        T = cnt >= newP ? cand : T;
+    }
+    uint32_t base = 0, pos[CPL];
+    bool sel[CPL];
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) {
+        sel[r] = key[r] >= T;
+        const uint64_t m = ballot64(sel[r]);
+        pos[r] = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        base += (uint32_t)__popcll(m);
+    }
+    if (base != newP) return false;  // several candidates tie at the threshold
+    if (c.lane < 4) skey[newP + (uint32_t)c.lane] = 0u;
+#pragma unroll
+    for (int r = 0; r < CPL; ++r)
+        if (sel[r]) {
+            skey[pos[r]] = key[r];
+            sid[pos[r]] = (uint32_t)c.lane * CPL + r;
+        }
+    WAVE_SYNC();
+    const bool mine = (uint32_t)c.lane < newP;  // lane i ranks survivor i
+    const uint32_t myk = mine ? skey[c.lane] : 0xFFFFFFFFu;
+    uint32_t gt = 0;
+    for (uint32_t s4 = 0; s4 < newP; s4 += 4) {
+        const u32x4 k = *(const lds_u32x4*)(uintptr_t)(c.scratch + s4);
+        gt += (k.x > myk) ? 1u : 0u;
+        gt += (k.y > myk) ? 1u : 0u;
+        gt += (k.z > myk) ? 1u : 0u;
+        gt += (k.w > myk) ? 1u : 0u;
+    }
+    if (mine) rk[gt] = (uint32_t)c.lane;
+    WAVE_SYNC();
+    if (ballot64(mine && rk[gt] != (uint32_t)c.lane) != 0) return false;  // two survivors share a rank: exact tie
+    nval = 0.0f;
+    nidx = 0;
+    if ((uint32_t)c.pl < newP) {
+        const uint32_t si = rk[c.pl];
+        nval = unkey(skey[si]);
+        const uint32_t id = sid[si], sl = id / CPL, r = id % CPL;
+        nidx = (sl >> LPL) * CPP + (sl & (uint32_t)(LP - 1)) * CPL + r;
+    }
+    return true;
+}
+
 template <typename CTX, int LPL, int CPP>
 __device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
                                                 float pathbest, uint32_t newP, float& nval, uint32_t& nidx)
@@ -782,7 +858,12 @@ __device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP 
         if (select_ranked8<CTX, CPP>(c, val[0], newP, nval, nidx)) return;
     } else if (c.P * CPP > newP) {
         // (when every candidate survives, the reference leaves the last position unsorted: literal code below)
-        if (select_ranked<CTX, LPL, CPP>(c, val, newP, nval, nidx)) return;
+        constexpr int CPL = (CPP >> LPL) ? (CPP >> LPL) : 1;
+        if constexpr (CTX::CW == 1 && CPL >= 2) {
+            if (select_threshold<CTX, LPL, CPP>(c, val, newP, nval, nidx)) return;
+        } else {
+            if (select_ranked<CTX, LPL, CPP>(c, val, newP, nval, nidx)) return;
+        }
     }
     // literal emulation of the reference's swap order, one codeword of the wave at a time
 #pragma unroll
