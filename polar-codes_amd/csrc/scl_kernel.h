@@ -843,6 +843,75 @@ __device__ __forceinline__ bool select_threshold(const CTX& c, const float (&val
     return true;
 }
 
+// ---- literal selection for several codewords per wave ---------------------------------------------------------
+// The same emulation of simplePartialSortDescending as select_paths / select_paths_1, but for all codewords of the wave
+// at once: the wave-wide reductions become reductions over the lanes of a codeword (DPP inside the 16-lane rows), so
+// tie-heavy input (quantised LLRs) does not pay one pass per codeword.
+template <typename CTX, int LPL, int CPP>
+__device__ __forceinline__ void select_literal_cw(const CTX& c, const float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
+                                                  uint32_t newP, float& nval, uint32_t& nidx)
+{
+    constexpr int LP = CTX::LP;
+    constexpr int CPL = (CPP >> LPL) ? (CPP >> LPL) : 1;
+    constexpr int G = 64 / CTX::CW;  // lanes per codeword
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+    const uint32_t lane0 = (uint32_t)c.g0 << LPL;
+    const uint32_t size = c.P * CPP;
+    const uint32_t lim = (size - 1 < newP) ? size - 1 : newP;
+    uint32_t key[CPL], idx[CPL], pos[CPL];
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) {
+        const uint32_t q = (uint32_t)c.j * CPL + r;
+        const bool valid = (q < (uint32_t)CPP) && ((uint32_t)c.pl < c.P);
+        pos[r] = valid ? (uint32_t)c.pl * CPP + q : INF;  // (an invalid slot is never eligible and never position i)
+        idx[r] = pos[r];
+        key[r] = valid ? okey(val[r]) : 0u;
+    }
+    // lane / register that hold position x of this lane's codeword
+    auto lane_of = [&](uint32_t x) { return lane0 + (x / CPP) * LP + ((x % CPP) / CPL); };
+    auto pick = [&](const uint32_t (&a)[CPL], uint32_t rsel) {
+        uint32_t v = a[0];
+#pragma unroll
+        for (int r = 1; r < CPL; ++r) v = (rsel == (uint32_t)r) ? a[r] : v;
+        return v;
+    };
+    uint32_t rkey = 0, ridx = 0;
+    for (uint32_t i = 0; i < lim; ++i) {
+        uint32_t lk = 0, lp = INF;  // first maximum among this lane's eligible positions
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            const bool take = pos[r] != INF && pos[r] >= i && key[r] > lk;
+            lk = take ? key[r] : lk;
+            lp = take ? pos[r] : lp;
+        }
+        const uint32_t M = group_max_u32<G>(lk);
+        const uint32_t wp = group_min_u32<G>((lk == M) ? lp : INF);  // winner: lowest position holding the maximum
+        const uint32_t ri = (i % CPP) % CPL, rw = (wp % CPP) % CPL;
+        const uint32_t ki = shfl_u32(pick(key, ri), (int)lane_of(i)), xi = shfl_u32(pick(idx, ri), (int)lane_of(i));
+        const uint32_t xw = shfl_u32(pick(idx, rw), (int)lane_of(wp));
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            const bool at_w = pos[r] == wp, at_i = pos[r] == i;
+            key[r] = at_i ? M : (at_w ? ki : key[r]);
+            idx[r] = at_i ? xw : (at_w ? xi : idx[r]);
+        }
+        if ((uint32_t)c.pl == i) {
+            rkey = M;
+            ridx = xw;
+        }
+    }
+    if (lim < newP) {  // every candidate survives: the last position keeps what is left there
+        const uint32_t rl = (lim % CPP) % CPL;
+        const uint32_t kl = shfl_u32(pick(key, rl), (int)lane_of(lim)), xl = shfl_u32(pick(idx, rl), (int)lane_of(lim));
+        if ((uint32_t)c.pl == lim) {
+            rkey = kl;
+            ridx = xl;
+        }
+    }
+    nval = unkey(rkey);
+    nidx = ridx;
+}
+
 template <typename CTX, int LPL, int CPP>
 __device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
                                                 float pathbest, uint32_t newP, float& nval, uint32_t& nidx)
@@ -865,13 +934,13 @@ __device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP 
             if (select_ranked<CTX, LPL, CPP>(c, val, newP, nval, nidx)) return;
         }
     }
-    // literal emulation of the reference's swap order, one codeword of the wave at a time
-#pragma unroll
-    for (int t = 0; t < CTX::CW; ++t) {
-        if constexpr (CPP <= (1 << LPL))
-            select_paths_1<CTX, LPL, CPP>(c, val[0], newP, nval, nidx, t * CTX::LCW);
-        else
-            select_paths<CTX, LPL, CPP>(c, val, newP, nval, nidx, t * CTX::LCW);
+    // literal emulation of the reference's swap order
+    if constexpr (CTX::CW > 1) {
+        select_literal_cw<CTX, LPL, CPP>(c, val, newP, nval, nidx);
+    } else if constexpr (CPP <= (1 << LPL)) {
+        select_paths_1<CTX, LPL, CPP>(c, val[0], newP, nval, nidx, 0);
+    } else {
+        select_paths<CTX, LPL, CPP>(c, val, newP, nval, nidx, 0);
     }
 }
 
