@@ -3,14 +3,14 @@
 // every wave interprets the same flat decode program (program.h), so control flow is uniform
 // across the batch and there is no inter-wave synchronisation at all (no __syncthreads).
 //
-//   sc_decode_kernel   Fast-SSC  (reference: src/polarcode/decoding/fastssc_avx_float.cpp)
-//                      64 lanes work on one codeword; LLR stage buffers + packed partial sums in LDS.
-//   scl_decode_kernel  Fast-SSCL (reference: src/polarcode/decoding/scl_avx_float.cpp)
-//                      the wave is split into L' = 64/LP path groups of LP lanes (LP = 8 at L = 8,
-//                      the AVX width of the reference, so its summation order falls out naturally);
-//                      per-path LLR stage buffers in LDS, partial sums bit-packed, the reference's
-//                      DataPool lazy copy replaced by one 64-bit "slot word" per path that is moved
-//                      with a single cross-lane shuffle at every fork.
+//   sc_decode_kernel   Fast-SSC  (reference: src/polarcode/decoding/fastssc_avx_float.cpp), sc_kernel.hip
+//                      16 lanes work on one codeword (four codewords per wave); LLR stage buffers + packed
+//                      partial sums in LDS, the upper stages of long blocks in a global arena.
+//   scl_decode_kernel  Fast-SSCL (reference: src/polarcode/decoding/scl_avx_float.cpp), scl_kernel.h
+//                      the wave is split into 64/LP path groups of LP lanes, shared by 1, 2 or 4 codewords;
+//                      per-path LLR stage buffers in LDS (upper stages in a global arena), partial sums
+//                      bit-packed, the reference's DataPool lazy copy replaced by one "slot word" per path
+//                      that is moved with a single cross-lane shuffle at every fork.
 //
 // Bit-exactness notes: f is exact; g is one fp32 add; the metric sums follow the
 // reference's "8 strided accumulators, then x0+..+x7" order; every selection reproduces the

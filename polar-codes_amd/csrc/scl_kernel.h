@@ -9,14 +9,19 @@ namespace pamd {
 // =============================================================================================
 //  Fast-SSCL
 // =============================================================================================
-// LDS per wave (one codeword):
-//   llr   : L' path buffers of path_stride floats; stage t (block 2^t) at offset 1<<t, t < logN
-//           (the channel row, stage logN, is read straight from global memory / L2)
-//   bitsL : L' x wpp words -- outputs of LEFT children (and of the root), per stage
-//   bitsR : L' x wpp words -- outputs of RIGHT children
+// A wave holds 64 / LP path groups of LP lanes; they are split into 1 << CWL codewords of LCW groups each (SclCtx).
+// LDS per wave (all its codewords):
+//   llr   : one path buffer of path_stride floats per group; stage t (block 2^t) at offset 1<<t, t < s0
+//           (stages s0 .. logN-1 live in the per-wave arena in global memory, the channel row -- stage logN -- is
+//           read straight from global memory / L2, and stage logN-1 may be recomputed from it: "virtual top")
+//   bitsL : groups x wppL words -- outputs of LEFT children (and of the root), per stage
+//   bitsR : groups x wppR words -- outputs of RIGHT children
 //           stage t lives at word woff(t): t <= 5 -> word t (low 2^t bits), else (1 << (t-5)) + 4
-// Per lane: p = lane / LP (own path), metric (replicated over the path's lanes) and the slot word:
-//   field s-1 (FB bits) = which path buffer holds  LLR[s]  while the path is inside the left
+//           (stages >= sb may live in the arena instead, kernel flag HB)
+//   scratch: candidate keys / rank tables of the selection routines
+// Per lane: p = lane / LP (own group = path buffer), pl = its path index inside the codeword, the path metric
+// (replicated over the path's lanes) and the slot word:
+//   field s-1 (FB bits) = which path buffer of the codeword holds  LLR[s]  while the path is inside the left
 //   subtree of its stage-s ancestor, or the LEFT child's bits of that ancestor while inside the
 //   right subtree.  Writers always use their own index (all paths sit on the same tree node, so
 //   the previous contents are dead for everyone); forks copy the word (PathList::duplicatePath).
