@@ -1131,6 +1131,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 // n <= 8 with the block in LDS and 8 lanes per path: decided on the host (SCL_SPC_S / SCL_R1_S)
                 constexpr bool kSmallOp = decltype(SMALL_T)::value;
                 bool small = kSmallOp;
+                uint32_t signword = 0;  // (4 lanes per path, small leaf) the signs of the path's block, bit i = LLR i
                 if (DIAG && (P.ablate & 2u)) {  // perf experiment: no weak search
                     small = true;
                     wk.v[0] = wk.v[1] = wk.v[2] = wk.v[3] = 0x3F800000u;
@@ -1143,13 +1144,14 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         const bool in0 = (uint32_t)c.j < n, in1 = n == 8;
                         const float x0 = xb[in0 ? c.j : 0], x1 = xb[in1 ? c.j + 4 : 0];
                         const uint32_t a0 = in0 ? (fbits(x0) & 0x7FFFFFFFu) : INFB, a1 = in1 ? (fbits(x1) & 0x7FFFFFFFu) : INFB;
+                        const uint64_t sg0 = ballot64(in0 && sgn(x0)), sg1 = ballot64(in1 && sgn(x1));
+                        signword = ((uint32_t)(sg0 >> c.base) & 0xFu) | (((uint32_t)(sg1 >> c.base) & 0xFu) << 4);
                         if (spc) {
                             if (s == 2)
                                 weak_small4<Ctx, 2, 4>(c, a0, a1, wk);
                             else
                                 weak_small4<Ctx, 3, 4>(c, a0, a1, wk);
-                            const uint64_t sg = ballot64(in0 && sgn(x0)) ^ ballot64(in1 && sgn(x1));
-                            par = (uint32_t)__popc((uint32_t)(sg >> c.base) & 0xFu) & 1u;
+                            par = (uint32_t)__popc(signword) & 1u;
                         } else {
                             Weak<2> w2;
                             if (s == 1)
@@ -1253,9 +1255,12 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 const int sl = (int)(srcp << LPL);
                 const typename Ctx::SlotT nslot = c.slot_from_lane(sl);
                 // flip positions (< 2^15 each) and the parity travel packed in two registers
-                const uint32_t pk0 = shfl_u32(wk.ix[0] | (wk.ix[1] << 16), sl);
+                // (small leaves at 4 lanes per path: positions < 8, and the source path's sign word rides along in pk0)
+                constexpr bool kSignWord = kSmallOp && LPL == 2;
+                const uint32_t pk0 = shfl_u32(wk.ix[0] | (kSignWord ? (signword << 8) : 0u) | (wk.ix[1] << 16), sl);
                 const uint32_t pk1 = shfl_u32(wk.ix[2] | (wk.ix[3] << 16) | (par << 31), sl);
-                const uint32_t fpos[4] = { pk0 & 0xFFFFu, pk0 >> 16, pk1 & 0xFFFFu, (pk1 >> 16) & 0x7FFFu };
+                const uint32_t fpos[4] = { kSignWord ? (pk0 & 0xFFu) : (pk0 & 0xFFFFu), pk0 >> 16, pk1 & 0xFFFFu,
+                                           (pk1 >> 16) & 0x7FFFu };
                 const uint32_t spar = pk1 >> 31;
                 uint32_t fmask;
                 if (spc) {
@@ -1273,7 +1278,13 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 }
                 PAMD_STAMP(2)
                 // bits of the new path = signs of the SOURCE path's LLRs (identity buffer) with flips
-                if (small && LPL == 2) {  // n <= 8: LLRs j and j + 4 of the SOURCE path per lane, two ballot nibbles per path
+                if constexpr (kSignWord) {
+                    // bits of the new path = the source path's sign word with the flip positions toggled: no LLR reads
+                    uint32_t fw = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) fw |= ((fmask >> k) & 1u) << fpos[k];
+                    if (nact && c.j == 0) (c.area(side, c.p) + woff(s))[0] = (((pk0 >> 8) & 0xFFu) ^ fw) & ((1u << n) - 1u);
+                } else if (small && LPL == 2) {  // n <= 8: LLRs j and j + 4 of the SOURCE path per lane, two ballot nibbles per path
                     const float* xs = c.path_llr(srcp) + n;
                     const bool in0 = (uint32_t)c.j < n, in1 = n == 8;
                     uint32_t b0 = 0, b1 = 0;
