@@ -204,6 +204,26 @@ struct SclCtx {
     // sum over the path of v(i), i < n, in the reference's order: 8 strided accumulators
     // (acc[v] += x[8k+v], k ascending) then acc0+acc1+...+acc7 (avxconvenience.h:267).
     // acc[] holds this lane's accumulators: virtual AVX lane v = j + LP*a  (LP < 8) or v = j (LP >= 8)
+    // The same sum when only AVX lanes 0..3 can be non-zero (blocks of at most 4 LLRs, the REP leaves) and no term is
+    // -0.0: x + 0.0 == x then, so the four trailing additions of the reference's order are dropped.
+    __device__ __forceinline__ float lanesum_low4(const float acc[NACC]) const
+    {
+        if constexpr (LP == 4 || LP == 8) {
+            const uint32_t a = fbits(acc[0]);
+            uint32_t b0 = dpp_u32<0x00>(a), b1 = dpp_u32<0x55>(a), b2 = dpp_u32<0xAA>(a), b3 = dpp_u32<0xFF>(a);
+            if constexpr (LP == 8) {  // lanes 4..7 of the group take the first quad's values (row_half_mirror)
+                const bool hi = (j & 4) != 0;
+                const uint32_t o0 = dpp_u32<0x141>(b0), o1 = dpp_u32<0x141>(b1), o2 = dpp_u32<0x141>(b2), o3 = dpp_u32<0x141>(b3);
+                b0 = hi ? o0 : b0;
+                b1 = hi ? o1 : b1;
+                b2 = hi ? o2 : b2;
+                b3 = hi ? o3 : b3;
+            }
+            return ((bitsf(b0) + bitsf(b1)) + bitsf(b2)) + bitsf(b3);
+        } else {
+            return lanesum_finish(acc);
+        }
+    }
     __device__ __forceinline__ float lanesum_finish(const float acc[NACC]) const
     {
         if constexpr (LP == 8) {
@@ -718,27 +738,32 @@ __device__ __forceinline__ bool select_ranked(const CTX& c, const float (&val)[(
 {
     constexpr int LP = CTX::LP;
     constexpr int CPL = (CPP >> LPL) ? (CPP >> LPL) : 1;
+    // fewer candidates than lanes per path (REP: 2): the keys are stored densely, slot = group * CPP + q, so that the
+    // ranking does not wade through the empty slots of the idle lanes
+    constexpr bool COMPACT = CPL == 1 && CPP < LP;
+    constexpr uint32_t PER_GROUP = COMPACT ? (uint32_t)CPP : (uint32_t)(LP * CPL);  // key slots per path group
     constexpr uint32_t SLOTS = 64u * CPL;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef u32x4 __attribute__((address_space(3))) lds_u32x4;
     typedef uint32_t __attribute__((address_space(3))) lds_u32;
     lds_u32* keys = (lds_u32*)(uintptr_t)c.scratch;
     lds_u32* rk = keys + SLOTS + (uint32_t)c.g0;  // one rank table per codeword (CTX::LCW entries)
-    const uint32_t slot0 = ((uint32_t)c.g0 << LPL) * CPL;  // first key slot of this lane's codeword
-    uint32_t key[CPL];
+    const uint32_t slot0 = (uint32_t)c.g0 * PER_GROUP;  // first key slot of this lane's codeword
+    uint32_t key[CPL], id[CPL];
     bool valid[CPL];
 #pragma unroll
     for (int r = 0; r < CPL; ++r) {
         const uint32_t q = (uint32_t)c.j * CPL + r;
         valid[r] = (q < (uint32_t)CPP) && ((uint32_t)c.pl < c.P);
         key[r] = valid[r] ? okey(val[r]) : 0u;  // 0 is below every real key
-        keys[(uint32_t)c.lane * CPL + r] = key[r];
+        id[r] = COMPACT ? (uint32_t)c.p * CPP + q : (uint32_t)c.lane * CPL + r;
+        if (!COMPACT || q < (uint32_t)CPP) keys[id[r]] = key[r];
     }
     WAVE_SYNC();
     uint32_t gt[CPL];
 #pragma unroll
     for (int r = 0; r < CPL; ++r) gt[r] = 0;
-    const uint32_t nslots = (c.P * LP * CPL + 3u) & ~3u;  // slots of dead paths hold 0
+    const uint32_t nslots = (c.P * PER_GROUP + 3u) & ~3u;  // (the slots of dead paths hold 0)
     for (uint32_t s4 = 0; s4 < nslots; s4 += 4) {
         const u32x4 k = *(const lds_u32x4*)(uintptr_t)(c.scratch + slot0 + s4);
 #pragma unroll
@@ -753,21 +778,25 @@ __device__ __forceinline__ bool select_ranked(const CTX& c, const float (&val)[(
 #pragma unroll
     for (int r = 0; r < CPL; ++r) {
         sel[r] = valid[r] && gt[r] < newP;
-        if (sel[r]) rk[gt[r]] = (uint32_t)c.lane * CPL + r;
+        if (sel[r]) rk[gt[r]] = id[r];
     }
     WAVE_SYNC();
     bool lost = false;
 #pragma unroll
     for (int r = 0; r < CPL; ++r)
-        if (sel[r]) lost = lost || (rk[gt[r]] != (uint32_t)c.lane * CPL + r);
+        if (sel[r]) lost = lost || (rk[gt[r]] != id[r]);
     if (ballot64(lost) != 0) return false;
     nval = 0.0f;
     nidx = 0;
     if ((uint32_t)c.pl < newP) {
-        const uint32_t id = rk[c.pl];
-        nval = unkey(keys[id]);
-        const uint32_t sl = id / CPL, r = id % CPL;
-        nidx = ((sl >> LPL) - (uint32_t)c.g0) * CPP + (sl & (uint32_t)(LP - 1)) * CPL + r;
+        const uint32_t w = rk[c.pl];
+        nval = unkey(keys[w]);
+        if constexpr (COMPACT) {
+            nidx = w - slot0;  // (source path inside the codeword) * CPP + q
+        } else {
+            const uint32_t sl = w / CPL, r = w % CPL;
+            nidx = ((sl >> LPL) - (uint32_t)c.g0) * CPP + (sl & (uint32_t)(LP - 1)) * CPL + r;
+        }
     }
     return true;
 }
@@ -1560,7 +1589,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                     else
                         c.template with_src<I8>(s, c.p, body);
                 }
-                const float z = c.lanesum_finish(az), o = c.lanesum_finish(ao);
+                const float z = c.lanesum_low4(az), o = c.lanesum_low4(ao);  // (n <= 4; min0 / max0 never yield -0.0)
                 constexpr int CPL = (2 >> LPL) ? (2 >> LPL) : 1;
                 float val[CPL];
 #pragma unroll
