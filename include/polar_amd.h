@@ -76,8 +76,8 @@ size_t pcd_out_bytes(const pcd_decoder* d);                    /* (K + 7) / 8   
  *   metrics : rows x list_size float32 final path metrics, best first (SCL only)    (nullable)
  *   stream  : hipStream_t (NULL = default stream).  Device pointers: asynchronous on `stream`;
  *             host pointers: staged through device buffers and synchronised before returning.
- *             The "mixed" decoder synchronises the stream once per call (it reads the number of
- *             codewords the SC pass failed on before launching the list pass). */
+ *             (The "mixed" decoder is asynchronous as well: the list pass takes the number of codewords
+ *             the SC pass failed on from device memory.) */
 int pcd_decode_f32(pcd_decoder* d, const float* llr, size_t rows, uint8_t* out, uint8_t* ok,
                    float* metrics, int mem, void* stream);
 /* Batched Decoder::decode_vector(const char*, void*): int8 LLRs widened to float exactly as

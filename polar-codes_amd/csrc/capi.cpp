@@ -454,12 +454,12 @@ int decode_device(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t
         if ((rc = grow(d->d_list, d->d_list_cap, rows * 4))) return rc;
         HIP_TRY(hipMemsetAsync(d->d_count, 0, 4, st));
         HIP_TRY(pamd::launch_collect_failed(okbuf, (uint32_t)rows, d->d_list, d->d_count, st));
-        uint32_t nfail = 0;
-        HIP_TRY(hipMemcpyAsync(&nfail, d->d_count, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (nfail) {
-            pamd::DecodeParams P = base_params(d, llr, nfail, out, okbuf, metrics);
+        {
+            // the list pass reads its row count from the device (no host synchronisation): the grid is sized for the
+            // worst case, waves without work leave at once
+            pamd::DecodeParams P = base_params(d, llr, rows, out, okbuf, metrics);
             P.rowidx = d->d_list;
+            P.rows_dev = d->d_count;
             if ((rc = run_scl(d, P, i8, st))) return rc;
         }
     } else {

@@ -10,6 +10,7 @@ namespace pamd {
 struct DecodeParams {
     const void* llr;         // rows x N  float32 (or int8) channel LLRs, row-major, device memory
     const uint32_t* rowidx;  // nullable: decode rows rowidx[0..rows) of the batch ("mixed" second pass)
+    const uint32_t* rows_dev;  // nullable (list kernels): the row count lives in device memory (rows = upper bound, sizes the grid)
     uint32_t rows;
     uint32_t N, logN, K, nb, L;
     const Ins* prog;         // decode program (device)

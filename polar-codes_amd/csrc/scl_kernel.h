@@ -1068,7 +1068,9 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
     const uint32_t wave0 = blockIdx.x * wpb + wib, nwaves = gridDim.x * wpb;
     const const_u64_ptr prog64 = (const_u64_ptr)(uintptr_t)P.prog;
 
-    const uint32_t ngroups = (P.rows + CW - 1) / CW;
+    // ("mixed" decoder: the number of rows the SC pass failed on is only known on the device)
+    const uint32_t nrows = P.rows_dev ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*P.rows_dev) : P.rows;
+    const uint32_t ngroups = (nrows + CW - 1) / CW;
     const uint32_t mycw = (uint32_t)c.p >> (6 - LPL - CWL);  // which of the wave's codewords this lane works for
     for (uint32_t cw = wave0; cw < ngroups; cw += nwaves) {
         // channel rows of the wave's codewords (wave uniform); the last group may be ragged: idle slots decode the
@@ -1076,7 +1078,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
         const void* chanv[CW];
 #pragma unroll
         for (int t = 0; t < CW; ++t) {
-            const uint32_t ci = cw * CW + t, cl = ci < P.rows ? ci : cw * CW;
+            const uint32_t ci = cw * CW + t, cl = ci < nrows ? ci : cw * CW;
             const uint32_t r = P.rowidx ? P.rowidx[cl] : cl;
             chanv[t] = I8 ? (const void*)(reinterpret_cast<const int8_t*>(P.llr) + (size_t)r * N)
                           : (const void*)(reinterpret_cast<const float*>(P.llr) + (size_t)r * N);
@@ -1088,7 +1090,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
             return r;
         };
         const uint32_t cwi = cw * CW + mycw;
-        const bool live = cwi < P.rows;
+        const bool live = cwi < nrows;
         const uint32_t row = P.rowidx ? P.rowidx[live ? cwi : cw * CW] : (live ? cwi : cw * CW);
         const void* chan = chan_of(mycw);
         c.chan = chan;
@@ -1699,7 +1701,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
 #pragma unroll
         for (int t = 0; t < CW; ++t) {  // the information bits of each codeword's winner, 64 at a time with the whole wave
             const uint32_t ci = cw * CW + t;
-            const bool live_t = ci < P.rows;
+            const bool live_t = ci < nrows;
             const uint32_t row_t = P.rowidx ? P.rowidx[live_t ? ci : cw * CW] : ci;
             const uint32_t wg = CWL == 0 ? winner : readlane_u32(winner, t * LCWL);
             const uint32_t* wb = c.bits(0, wg, logN);
