@@ -283,6 +283,38 @@ void specialize_scl(pcd_decoder* d)
             in.off = aux;
         }
     }
+    // Fuse the neighbours of small leaves (4 lanes per path, blocks of at most 8 LLRs): `F_S leaf` and `G_S leaf
+    // [C_S]` become one instruction each -- the leaf computes its input from the parent's LLRs in registers (that
+    // stage is read by nobody else) and a right leaf combines its bits with the left sibling's on the way out.
+    // Flags in Ins::pad, see scl_kernel.h.  A third of the program's instructions at N = 1024 go away.
+    if (d->lpl == 2 && !std::getenv("PCD_NO_FUSE")) {
+        auto& v = d->scl_prog.ins;
+        std::vector<pamd::Ins> out;
+        out.reserve(v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            const pamd::Ins in = v[i];
+            const bool fg = (in.op == pamd::SCL_F_S || in.op == pamd::SCL_G_S) && in.stage <= 4 && (in.side & 0xEu) == 0;
+            if (fg && i + 1 < v.size()) {
+                pamd::Ins leaf = v[i + 1];
+                const bool small_leaf = leaf.stage + 1u == in.stage &&
+                                        (leaf.op == pamd::SCL_R0 || leaf.op == pamd::SCL_REP || leaf.op == pamd::SCL_SPC_S ||
+                                         leaf.op == pamd::SCL_R1_S);
+                if (small_leaf) {
+                    leaf.pad = in.op == pamd::SCL_F_S ? 1 : 2;
+                    size_t used = 2;
+                    if (in.op == pamd::SCL_G_S && i + 2 < v.size() && v[i + 2].op == pamd::SCL_C_S && v[i + 2].stage == in.stage) {
+                        leaf.pad |= (uint8_t)(4u | ((v[i + 2].side & 1u) << 3));
+                        used = 3;
+                    }
+                    out.push_back(leaf);
+                    i += used - 1;
+                    continue;
+                }
+            }
+            out.push_back(in);
+        }
+        v.swap(out);
+    }
 }
 
 int ensure_device(pcd_decoder* d)

@@ -77,8 +77,8 @@ __device__ __forceinline__ uint64_t shflx_u64(uint64_t v, int m)
 }
 
 // ---- cross-lane primitives that stay on the VALU (DPP / readlane) -------------------------------------
-// ds_bpermute (__shfl) takes an LDS round trip (~100+ cycles, and this kernel runs ~1 wave per SIMD, so
-// nothing hides it); DPP modifiers and v_readlane cost a VALU slot.
+// ds_bpermute (__shfl) takes an LDS round trip (~100+ cycles on a dependent chain, with 3-4 waves per SIMD
+// to hide it); DPP modifiers and v_readlane cost a VALU slot.
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
 {

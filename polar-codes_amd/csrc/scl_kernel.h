@@ -1138,6 +1138,45 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
             if (DIAG && ((P.ablate & 128u) || ((P.ablate & 64u) && is_leaf))) continue;
             // dispatch ordered by frequency (F / G / COMBINE are three quarters of the program); the two forking
             // leaves share one generic body instantiated separately, so each variant is straight-line code
+            // Host-fused neighbours of a small leaf (capi.cpp, fuse_small_leaves; 4 lanes per path, n <= 8): the F / G
+            // of the parent that produces the leaf's input runs as the leaf's prologue (its output is consumed in
+            // registers and never stored), the parent's COMBINE as the epilogue of a right leaf.
+            //   bits 0-1: 1 = input is F of the parent's LLRs, 2 = G;  bit 2: COMBINE follows;  bit 3: the parent's side
+            const uint32_t fuse = LPL == 2 ? ((uint32_t)(iw >> 24) & 0xFFu) : 0u;
+            auto leaf_input4 = [&](float& x0, float& x1) {  // LLRs j and j + 4 of this lane's path
+                const bool in0 = (uint32_t)c.j < n, in1 = n == 8;
+                const uint32_t i0 = in0 ? (uint32_t)c.j : 0u, i1 = in1 ? (uint32_t)c.j + 4u : 0u;
+                const uint32_t pro = fuse & 3u;
+                if (pro == 0) {
+                    const float* xb = c.path_llr(c.p) + n;
+                    x0 = xb[i0];
+                    x1 = xb[i1];
+                } else {
+                    constexpr typename Ctx::SlotT FM = (typename Ctx::SlotT)(LCW - 1);
+                    const uint32_t psh = s * (uint32_t)Ctx::FB;  // slot field of the parent stage s + 1
+                    if (pro == 1) {  // SCL_F_S
+                        const float* X = c.path_llr(c.p) + 2 * n;
+                        x0 = polar_f(X[i0], X[n + i0]);
+                        x1 = polar_f(X[i1], X[n + i1]);
+                    } else {  // SCL_G_S
+                        const uint32_t srcq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> psh) & (uint32_t)(LCW - 1));
+                        const float* X = c.path_llr(srcq) + 2 * n;
+                        const uint32_t lw = (c.area(0, c.p) + woff(s))[0];
+                        x0 = polar_g(X[i0], X[n + i0], (lw >> i0) & 1u);
+                        x1 = polar_g(X[i1], X[n + i1], (lw >> i1) & 1u);
+                    }
+                    c.slot = (c.slot & ~(FM << psh)) | ((typename Ctx::SlotT)c.pl << psh);
+                }
+            };
+            auto leaf_bits_out = [&](bool wr, uint32_t bw) {  // wr: lane 0 of a live path; bw: the leaf's n bits
+                if (!(fuse & 4u)) {
+                    if (wr) (c.area(side, c.p) + woff(s))[0] = bw;
+                } else if (wr) {  // SCL_C_S of the parent: [left ^ right | right]
+                    const uint32_t lq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> (s * (uint32_t)Ctx::FB)) & (uint32_t)(LCW - 1));
+                    const uint32_t mask = (1u << n) - 1u, r = bw & mask;
+                    (c.area((fuse >> 3) & 1u, c.p) + woff(s + 1))[0] = (((c.area(0, lq) + woff(s))[0] ^ r) & mask) | (r << n);
+                }
+            };
             auto fork_leaf = [&](auto SPC_T, auto SMALL_T) {  // SpcDecoder::decode     :498-621
                 constexpr bool spc = decltype(SPC_T)::value;
                 Weak<4> wk;
@@ -1171,9 +1210,9 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 if constexpr (LPL == 2) {
                     if (small && !(DIAG && (P.ablate & 2u))) {  // n <= 8: positions j and j + 4 of the block in lane j
                         constexpr uint32_t INFB = 0xFFFFFFFFu;
-                        const float* xb = c.path_llr(c.p) + n;
                         const bool in0 = (uint32_t)c.j < n, in1 = n == 8;
-                        const float x0 = xb[in0 ? c.j : 0], x1 = xb[in1 ? c.j + 4 : 0];
+                        float x0, x1;
+                        leaf_input4(x0, x1);
                         const uint32_t a0 = in0 ? (fbits(x0) & 0x7FFFFFFFu) : INFB, a1 = in1 ? (fbits(x1) & 0x7FFFFFFFu) : INFB;
                         const uint64_t sg0 = ballot64(in0 && sgn(x0)), sg1 = ballot64(in1 && sgn(x1));
                         signword = ((uint32_t)(sg0 >> c.base) & 0xFu) | (((uint32_t)(sg1 >> c.base) & 0xFu) << 4);
@@ -1314,7 +1353,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                     uint32_t fw = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) fw |= ((fmask >> k) & 1u) << fpos[k];
-                    if (nact && c.j == 0) (c.area(side, c.p) + woff(s))[0] = (((pk0 >> 8) & 0xFFu) ^ fw) & ((1u << n) - 1u);
+                    leaf_bits_out(nact && c.j == 0, (((pk0 >> 8) & 0xFFu) ^ fw) & ((1u << n) - 1u));
                 } else if (small && LPL == 2) {  // n <= 8: LLRs j and j + 4 of the SOURCE path per lane, two ballot nibbles per path
                     const float* xs = c.path_llr(srcp) + n;
                     const bool in0 = (uint32_t)c.j < n, in1 = n == 8;
@@ -1551,7 +1590,17 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 float acc[NACC];
 #pragma unroll
                 for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
-                if (active && (LP < 8 || c.j < 8)) {
+                if (LPL == 2 && fuse) {  // n <= 8, input straight from the fused F / G
+                    float x0, x1;
+                    leaf_input4(x0, x1);
+                    if (active) {
+#pragma unroll
+                        for (int a = 0; a < NACC; ++a) {
+                            const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
+                            acc[a] = acc[a] + (v < n ? min0(a == 0 ? x0 : x1) : 0.0f);
+                        }
+                    }
+                } else if (active && (LP < 8 || c.j < 8)) {
                     auto body = [&](auto x) {
 #pragma unroll
                         for (int a = 0; a < NACC; ++a) {
@@ -1568,15 +1617,32 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 const float sum = c.lanesum_finish(acc);
                 if (active) {
                     c.metric = c.metric + sum;
-                    uint32_t* ob = c.bits(side, c.p, s);
-                    const uint32_t nw = n >= 32 ? (n >> 5) : 1u;
-                    for (uint32_t w = c.j; w < nw; w += LP) ob[w] = 0u;
+                    if (LPL == 2 && fuse) {
+                        leaf_bits_out(c.j == 0, 0u);
+                    } else {
+                        uint32_t* ob = c.bits(side, c.p, s);
+                        const uint32_t nw = n >= 32 ? (n >> 5) : 1u;
+                        for (uint32_t w = c.j; w < nw; w += LP) ob[w] = 0u;
+                    }
                 }
             } else if (ins.op == SCL_REP) {  // RepetitionDecoder::decode :428-481 (n = 2 or 4)
                 float az[NACC], ao[NACC];
 #pragma unroll
                 for (int a = 0; a < NACC; ++a) az[a] = ao[a] = 0.0f;
-                if (active && (LP < 8 || c.j < 8)) {
+                if (LPL == 2 && fuse) {  // n <= 4 (lanesum_low4 below), input straight from the fused F / G
+                    float x0, x1;
+                    leaf_input4(x0, x1);
+                    if (active) {
+                        const float xv = (uint32_t)c.j < n ? x0 : 0.0f;
+                        az[0] = az[0] + min0(xv);
+                        ao[0] = ao[0] + max0(xv);
+#pragma unroll
+                        for (int a = 1; a < NACC; ++a) {
+                            az[a] = az[a] + min0(0.0f);
+                            ao[a] = ao[a] + max0(0.0f);
+                        }
+                    }
+                } else if (active && (LP < 8 || c.j < 8)) {
                     auto body = [&](auto x) {
 #pragma unroll
                         for (int a = 0; a < NACC; ++a) {
@@ -1609,7 +1675,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 if ((uint32_t)c.pl < c.P) {
                     c.metric = nval;
                     c.slot = nslot;
-                    if (c.j == 0) (c.area(side, c.p) + woff(s))[0] = q ? ((1u << n) - 1u) : 0u;
+                    leaf_bits_out(c.j == 0, q ? ((1u << n) - 1u) : 0u);
                 }
             } else if (ins.op == SCL_SPC) {
                 fork_leaf(std::true_type{}, std::false_type{});
