@@ -283,35 +283,62 @@ void specialize_scl(pcd_decoder* d)
             in.off = aux;
         }
     }
-    // Fuse the neighbours of small leaves (4 lanes per path, blocks of at most 8 LLRs): `F_S leaf` and `G_S leaf
-    // [C_S]` become one instruction each -- the leaf computes its input from the parent's LLRs in registers (that
-    // stage is read by nobody else) and a right leaf combines its bits with the left sibling's on the way out.
-    // Flags in Ins::pad, see scl_kernel.h.  A third of the program's instructions at N = 1024 go away.
+    // Fuse the neighbours of small leaves (4 lanes per path, blocks of at most 8 LLRs); flags in Ins::pad, see
+    // scl_kernel.h.  `F_S leaf` / `G_S leaf`: the leaf computes its input from the parent's LLRs in registers (that
+    // stage is read by nobody else).  `F_S R0 G_S leaf`: an all-frozen left sibling only adds to the metric, so it
+    // joins the right leaf's prologue.  A right leaf (or a COMBINE) also performs the single-word COMBINEs that
+    // follow it directly.  Roughly 40 % of the program's instructions at N = 1024 go away.
     if (d->lpl == 2 && !std::getenv("PCD_NO_FUSE")) {
         auto& v = d->scl_prog.ins;
+        auto small_leaf = [](const pamd::Ins& in) {
+            return in.stage <= 3 &&
+                   (in.op == pamd::SCL_R0 || in.op == pamd::SCL_REP || in.op == pamd::SCL_SPC_S || in.op == pamd::SCL_R1_S);
+        };
         std::vector<pamd::Ins> out;
         out.reserve(v.size());
-        for (size_t i = 0; i < v.size(); ++i) {
+        for (size_t i = 0; i < v.size(); ++i) {  // F_S / G_S into the leaf
             const pamd::Ins in = v[i];
             const bool fg = (in.op == pamd::SCL_F_S || in.op == pamd::SCL_G_S) && in.stage <= 4 && (in.side & 0xEu) == 0;
-            if (fg && i + 1 < v.size()) {
+            if (fg && i + 1 < v.size() && small_leaf(v[i + 1]) && v[i + 1].stage + 1u == in.stage) {
                 pamd::Ins leaf = v[i + 1];
-                const bool small_leaf = leaf.stage + 1u == in.stage &&
-                                        (leaf.op == pamd::SCL_R0 || leaf.op == pamd::SCL_REP || leaf.op == pamd::SCL_SPC_S ||
-                                         leaf.op == pamd::SCL_R1_S);
-                if (small_leaf) {
-                    leaf.pad = in.op == pamd::SCL_F_S ? 1 : 2;
-                    size_t used = 2;
-                    if (in.op == pamd::SCL_G_S && i + 2 < v.size() && v[i + 2].op == pamd::SCL_C_S && v[i + 2].stage == in.stage) {
-                        leaf.pad |= (uint8_t)(4u | ((v[i + 2].side & 1u) << 3));
-                        used = 3;
-                    }
-                    out.push_back(leaf);
-                    i += used - 1;
-                    continue;
-                }
+                leaf.pad = in.op == pamd::SCL_F_S ? 1 : 2;
+                out.push_back(leaf);
+                ++i;
+                continue;
             }
             out.push_back(in);
+        }
+        v.clear();
+        for (size_t i = 0; i < out.size(); ++i) {  // R0 left sibling into the right leaf
+            if (i + 1 < out.size() && out[i].op == pamd::SCL_R0 && out[i].pad == 1 && out[i + 1].pad == 2 &&
+                out[i + 1].stage == out[i].stage && i + 2 < out.size() && out[i + 2].op == pamd::SCL_C_S &&
+                out[i + 2].stage == out[i].stage + 1u && !std::getenv("PCD_NO_FUSE_R0") && !std::getenv("PCD_NO_FUSE_C")) {
+                // (the COMBINE right behind the pair is fused below, and knows that the left bits are all zero)
+                pamd::Ins leaf = out[i + 1];
+                leaf.pad = 3;
+                v.push_back(leaf);
+                ++i;
+                continue;
+            }
+            v.push_back(out[i]);
+        }
+        out.clear();
+        for (size_t i = 0; i < v.size(); ++i) {  // COMBINE chains
+            pamd::Ins head = v[i];
+            const bool leaf = small_leaf(head) && d->logN > head.stage;
+            if ((leaf || head.op == pamd::SCL_C_S) && !std::getenv("PCD_NO_FUSE_C")) {
+                unsigned top = head.stage, k = 0, fside = head.side & 1u;  // stage of the block held so far
+                if (head.op == pamd::SCL_C_S) k = 1;
+                while (i + 1 < v.size() && v[i + 1].op == pamd::SCL_C_S && v[i + 1].pad == 0 && v[i + 1].stage == top + 1u &&
+                       top + 1u <= 5u && k < 7u) {
+                    fside = v[i + 1].side & 1u;
+                    ++top;
+                    ++k;
+                    ++i;
+                }
+                if (k > (head.op == pamd::SCL_C_S ? 1u : 0u)) head.pad |= (uint8_t)((k << 2) | (fside << 5));
+            }
+            out.push_back(head);
         }
         v.swap(out);
     }

@@ -1140,8 +1140,9 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
             // leaves share one generic body instantiated separately, so each variant is straight-line code
             // Host-fused neighbours of a small leaf (capi.cpp, fuse_small_leaves; 4 lanes per path, n <= 8): the F / G
             // of the parent that produces the leaf's input runs as the leaf's prologue (its output is consumed in
-            // registers and never stored), the parent's COMBINE as the epilogue of a right leaf.
-            //   bits 0-1: 1 = input is F of the parent's LLRs, 2 = G;  bit 2: COMBINE follows;  bit 3: the parent's side
+            // registers and never stored), the COMBINEs that follow a right leaf (or a COMBINE) as its epilogue.
+            //   bits 0-1: input is 1 = F of the parent's LLRs, 2 = G, 3 = G after an all-frozen left sibling (whose
+            //             F + RateZero step runs here too);  bits 2-4: COMBINEs that follow;  bit 5: side of the last
             const uint32_t fuse = LPL == 2 ? ((uint32_t)(iw >> 24) & 0xFFu) : 0u;
             auto leaf_input4 = [&](float& x0, float& x1) {  // LLRs j and j + 4 of this lane's path
                 const bool in0 = (uint32_t)c.j < n, in1 = n == 8;
@@ -1158,23 +1159,45 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         const float* X = c.path_llr(c.p) + 2 * n;
                         x0 = polar_f(X[i0], X[n + i0]);
                         x1 = polar_f(X[i1], X[n + i1]);
-                    } else {  // SCL_G_S
+                    } else if (pro == 2) {  // SCL_G_S
                         const uint32_t srcq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> psh) & (uint32_t)(LCW - 1));
                         const float* X = c.path_llr(srcq) + 2 * n;
                         const uint32_t lw = (c.area(0, c.p) + woff(s))[0];
                         x0 = polar_g(X[i0], X[n + i0], (lw >> i0) & 1u);
                         x1 = polar_g(X[i1], X[n + i1], (lw >> i1) & 1u);
+                    } else {  // SCL_F_S, SCL_R0 on its output (:316-337, no fork), SCL_G_S with all-zero left bits
+                        const float* X = c.path_llr(c.p) + 2 * n;
+                        const float a0 = X[i0], b0 = X[n + i0], a1 = X[i1], b1 = X[n + i1];
+                        float acc[NACC];
+#pragma unroll
+                        for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+                        acc[0] = acc[0] + (in0 ? min0(polar_f(a0, b0)) : 0.0f);
+                        if constexpr (NACC > 1) acc[1] = acc[1] + (in1 ? min0(polar_f(a1, b1)) : 0.0f);
+                        const float sum = c.lanesum_finish(acc);
+                        if (active) c.metric = c.metric + sum;
+                        x0 = a0 + b0;
+                        x1 = a1 + b1;
                     }
                     c.slot = (c.slot & ~(FM << psh)) | ((typename Ctx::SlotT)c.pl << psh);
                 }
             };
+            // k COMBINEs on top of the block r of stage st (right child of its parent each time), h < 32 throughout
+            auto combine_chain = [&](uint32_t r, uint32_t st, uint32_t k, uint32_t fside, bool left0) {
+                for (uint32_t t = 0; t < k; ++t) {
+                    const uint32_t lq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> ((st + t) * (uint32_t)Ctx::FB)) & (uint32_t)(LCW - 1));
+                    const uint32_t nb = 1u << (st + t), mask = (1u << nb) - 1u;
+                    const uint32_t left = (left0 && t == 0) ? 0u : (c.area(0, lq) + woff(st + t))[0];
+                    r &= mask;
+                    r = ((left ^ r) & mask) | (r << nb);
+                }
+                (c.area(fside, c.p) + woff(st + k))[0] = r;
+            };
             auto leaf_bits_out = [&](bool wr, uint32_t bw) {  // wr: lane 0 of a live path; bw: the leaf's n bits
-                if (!(fuse & 4u)) {
+                const uint32_t k = (fuse >> 2) & 7u;
+                if (k == 0) {
                     if (wr) (c.area(side, c.p) + woff(s))[0] = bw;
-                } else if (wr) {  // SCL_C_S of the parent: [left ^ right | right]
-                    const uint32_t lq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> (s * (uint32_t)Ctx::FB)) & (uint32_t)(LCW - 1));
-                    const uint32_t mask = (1u << n) - 1u, r = bw & mask;
-                    (c.area((fuse >> 3) & 1u, c.p) + woff(s + 1))[0] = (((c.area(0, lq) + woff(s))[0] ^ r) & mask) | (r << n);
+                } else if (wr) {
+                    combine_chain(bw, s, k, (fuse >> 5) & 1u, (fuse & 3u) == 3u);
                 }
             };
             auto fork_leaf = [&](auto SPC_T, auto SMALL_T) {  // SpcDecoder::decode     :498-621
@@ -1416,6 +1439,9 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 }
                 c.slot = (c.slot & ~((typename Ctx::SlotT)(LCW - 1) << fsh)) | ((typename Ctx::SlotT)c.pl << fsh);
             } else if (ins.op == SCL_C_S) {  // COMBINE, h < 32
+                if (LPL == 2 && fuse) {  // ... and the COMBINEs right above it
+                    if (active && c.j == 0) combine_chain((c.area(1, c.p) + wo_c)[0], s - 1, (fuse >> 2) & 7u, (fuse >> 5) & 1u, false);
+                } else
                 if (active && c.j == 0 && !skip_small) {
                     const uint32_t lq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> fsh) & (uint32_t)(LCW - 1));
                     const uint32_t mask = (1u << h) - 1u;
