@@ -342,6 +342,32 @@ void specialize_scl(pcd_decoder* d)
         }
         v.swap(out);
     }
+    // All-frozen left child of a small inner node: `F_S R0 G_S` (or `R0 G_S` with the F_S already inside the R0) is
+    // one step -- the metric takes the sum over min(f, 0) and the right child's input is a + b.
+    if (!std::getenv("PCD_NO_FUSE") && !std::getenv("PCD_NO_FUSE_G0")) {
+        auto& v = d->scl_prog.ins;
+        std::vector<pamd::Ins> out;
+        out.reserve(v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            if (i + 2 < v.size() && v[i].op == pamd::SCL_F_S && (v[i].side & 0xEu) == 0 && v[i + 1].op == pamd::SCL_R0 &&
+                v[i + 1].pad == 0 && v[i + 1].stage + 1u == v[i].stage && v[i + 2].op == pamd::SCL_G_S &&
+                v[i + 2].stage == v[i].stage) {
+                pamd::Ins g = v[i + 2];
+                g.op = pamd::SCL_G0_S;
+                out.push_back(g);
+                i += 2;
+            } else if (i + 1 < v.size() && v[i].op == pamd::SCL_R0 && v[i].pad == 1 && v[i + 1].op == pamd::SCL_G_S &&
+                       v[i + 1].stage == v[i].stage + 1u) {
+                pamd::Ins g = v[i + 1];
+                g.op = pamd::SCL_G0_S;
+                out.push_back(g);
+                i += 1;
+            } else {
+                out.push_back(v[i]);
+            }
+        }
+        v.swap(out);
+    }
 }
 
 int ensure_device(pcd_decoder* d)

@@ -50,6 +50,7 @@ enum Op : uint8_t {
     SCL_C_W,       // COMBINE with h >= 32 (word-wise)
     SCL_SPC_S,     // SPC / R1 leaf of at most 8 LLRs held in LDS, 8 lanes per path (L <= 8 kernels only)
     SCL_R1_S,
+    SCL_G0_S,      // F_S, RateZero on its output, G_S with all-zero left bits in one step (all-frozen left child)
 };
 
 struct Ins {

@@ -1438,6 +1438,34 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                     for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
                 }
                 c.slot = (c.slot & ~((typename Ctx::SlotT)(LCW - 1) << fsh)) | ((typename Ctx::SlotT)c.pl << fsh);
+            } else if (ins.op == SCL_G0_S) {  // all-frozen left child: F_S + RateZeroDecoder::decode :316-337 + G_S (u = 0)
+                float acc[NACC];
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+                const float* x = c.path_llr(c.p) + n;
+                float* d = c.path_llr(c.p) + h;
+                if (active && (LP < 8 || c.j < 8)) {
+#pragma unroll
+                    for (int a = 0; a < NACC; ++a) {
+                        const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
+                        for (uint32_t i = v; i < h; i += 8) {
+                            const float xa = x[i], xb = x[h + i];
+                            acc[a] = acc[a] + min0(polar_f(xa, xb));
+                            if constexpr (LP <= 8) d[i] = xa + xb;
+                        }
+                        if (v >= h) acc[a] = acc[a] + 0.0f;
+                    }
+                }
+                if constexpr (LP > 8) {
+                    if (active)
+                        for (uint32_t i = c.j; i < h; i += LP) d[i] = x[i] + x[h + i];
+                }
+                const float sum = c.lanesum_finish(acc);
+                if (active) {
+                    c.metric = c.metric + sum;
+                    if (c.j == 0) (c.area(0, c.p) + wo_c)[0] = 0u;  // the left child's bits, for the COMBINE
+                }
+                c.slot = (c.slot & ~((typename Ctx::SlotT)(LCW - 1) << fsh)) | ((typename Ctx::SlotT)c.pl << fsh);
             } else if (ins.op == SCL_C_S) {  // COMBINE, h < 32
                 if (LPL == 2 && fuse) {  // ... and the COMBINEs right above it
                     if (active && c.j == 0) combine_chain((c.area(1, c.p) + wo_c)[0], s - 1, (fuse >> 2) & 7u, (fuse >> 5) & 1u, false);
