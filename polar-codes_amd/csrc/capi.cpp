@@ -336,7 +336,15 @@ void specialize_scl(pcd_decoder* d)
                     ++k;
                     ++i;
                 }
-                if (k > (head.op == pamd::SCL_C_S ? 1u : 0u)) head.pad |= (uint8_t)((k << 2) | (fside << 5));
+                unsigned wide = 0;  // ... and the two-word COMBINE of stage 6 on top of a chain that reached stage 5
+                if (top == 5 && k > 0 && i + 1 < v.size() && v[i + 1].op == pamd::SCL_C_W && v[i + 1].stage == 6 &&
+                    v[i + 1].pad == 0 && !std::getenv("PCD_NO_FUSE_CW")) {
+                    fside = v[i + 1].side & 1u;
+                    wide = 1;
+                    ++i;
+                }
+                if (wide || k > (head.op == pamd::SCL_C_S ? 1u : 0u))
+                    head.pad |= (uint8_t)((k << 2) | (fside << 5) | (wide << 6));
             }
             out.push_back(head);
         }

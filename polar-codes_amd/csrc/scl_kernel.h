@@ -1182,6 +1182,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 }
             };
             // k COMBINEs on top of the block r of stage st (right child of its parent each time), h < 32 throughout
+            // (fuse bit 6: the chain reaches the 32-bit block of stage 5 and the two-word COMBINE of stage 6 follows)
             auto combine_chain = [&](uint32_t r, uint32_t st, uint32_t k, uint32_t fside, bool left0) {
                 for (uint32_t t = 0; t < k; ++t) {
                     const uint32_t lq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> ((st + t) * (uint32_t)Ctx::FB)) & (uint32_t)(LCW - 1));
@@ -1190,7 +1191,14 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                     r &= mask;
                     r = ((left ^ r) & mask) | (r << nb);
                 }
-                (c.area(fside, c.p) + woff(st + k))[0] = r;
+                if (fuse & 64u) {
+                    const uint32_t lq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> (5u * (uint32_t)Ctx::FB)) & (uint32_t)(LCW - 1));
+                    uint32_t* ob = c.area(fside, c.p) + woff(6);
+                    ob[0] = (c.area(0, lq) + woff(5))[0] ^ r;
+                    ob[1] = r;
+                } else {
+                    (c.area(fside, c.p) + woff(st + k))[0] = r;
+                }
             };
             auto leaf_bits_out = [&](bool wr, uint32_t bw) {  // wr: lane 0 of a live path; bw: the leaf's n bits
                 const uint32_t k = (fuse >> 2) & 7u;
