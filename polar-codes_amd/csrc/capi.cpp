@@ -376,6 +376,27 @@ void specialize_scl(pcd_decoder* d)
         }
         v.swap(out);
     }
+    // `X_S(4) [F_S(3) leaf(2)]`: the leaf's lanes hold exactly the stage-3 pairs its F needs, so the op in front joins too
+    if (d->lpl == 2 && !std::getenv("PCD_NO_FUSE") && !std::getenv("PCD_NO_FUSE_GRAND")) {
+        auto& v = d->scl_prog.ins;
+        std::vector<pamd::Ins> out;
+        out.reserve(v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            const pamd::Ins& x = v[i];
+            const bool head = (x.op == pamd::SCL_F_S || x.op == pamd::SCL_G_S || x.op == pamd::SCL_G0_S) && x.stage == 4 && (x.side & 0xEu) == 0 && x.pad == 0;
+            if (head && i + 1 < v.size() && v[i + 1].stage == 2 && (v[i + 1].pad & 3u) == 1 &&
+                (v[i + 1].op == pamd::SCL_R0 || v[i + 1].op == pamd::SCL_REP || v[i + 1].op == pamd::SCL_SPC_S ||
+                 v[i + 1].op == pamd::SCL_R1_S)) {
+                pamd::Ins leaf = v[i + 1];
+                leaf.off = (x.op == pamd::SCL_F_S ? 1u : (x.op == pamd::SCL_G_S ? 2u : 3u)) << 24;
+                out.push_back(leaf);
+                ++i;
+            } else {
+                out.push_back(x);
+            }
+        }
+        v.swap(out);
+    }
 }
 
 int ensure_device(pcd_decoder* d)

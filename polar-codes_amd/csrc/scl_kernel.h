@@ -1155,6 +1155,46 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 } else {
                     constexpr typename Ctx::SlotT FM = (typename Ctx::SlotT)(LCW - 1);
                     const uint32_t psh = s * (uint32_t)Ctx::FB;  // slot field of the parent stage s + 1
+                    const uint32_t grand = ((uint32_t)(iw >> 56)) & 3u;
+                    if (grand) {
+                        // n = 4, pro = 1, and the stage-3 block the F reads is itself the output of the F_S / G_S / G0_S
+                        // (grand = 1 / 2 / 3) of stage 4 right before: that op runs here too -- lane j produces LLRs j
+                        // and j + 4 of stage 3 (stored: the parent's G needs them later), exactly the pair its F takes
+                        const uint32_t gsh = 3u * (uint32_t)Ctx::FB;  // slot field of stage 4
+                        const uint32_t srcq = grand == 2 ? (uint32_t)c.g0 + ((uint32_t)(c.slot >> gsh) & (uint32_t)(LCW - 1)) : (uint32_t)c.p;
+                        const float* X = c.path_llr(srcq) + 16;
+                        float* d = c.path_llr(c.p) + 8;
+                        const float a0 = X[c.j], b0 = X[8 + c.j], a1 = X[4 + c.j], b1 = X[12 + c.j];
+                        float v0, v1;
+                        if (grand == 1) {
+                            v0 = polar_f(a0, b0);
+                            v1 = polar_f(a1, b1);
+                        } else if (grand == 2) {
+                            const uint32_t lw = (c.area(0, c.p) + woff(3))[0];
+                            v0 = polar_g(a0, b0, (lw >> c.j) & 1u);
+                            v1 = polar_g(a1, b1, (lw >> (c.j + 4)) & 1u);
+                        } else {
+                            float acc[NACC];
+#pragma unroll
+                            for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
+                            acc[0] = acc[0] + min0(polar_f(a0, b0));
+                            if constexpr (NACC > 1) acc[1] = acc[1] + min0(polar_f(a1, b1));
+                            const float sum = c.lanesum_finish(acc);
+                            if (active) {
+                                c.metric = c.metric + sum;
+                                if (c.j == 0) (c.area(0, c.p) + woff(3))[0] = 0u;
+                            }
+                            v0 = a0 + b0;
+                            v1 = a1 + b1;
+                        }
+                        if (active) {
+                            d[c.j] = v0;
+                            d[c.j + 4] = v1;
+                        }
+                        c.slot = (c.slot & ~(FM << gsh)) | ((typename Ctx::SlotT)c.pl << gsh);
+                        x0 = polar_f(v0, v1);
+                        x1 = 0.0f;
+                    } else
                     if (pro == 1) {  // SCL_F_S
                         const float* X = c.path_llr(c.p) + 2 * n;
                         x0 = polar_f(X[i0], X[n + i0]);
