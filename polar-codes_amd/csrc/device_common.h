@@ -43,6 +43,18 @@ __device__ __forceinline__ uint32_t sgn(float x) { return __float_as_uint(x) >> 
 __device__ __forceinline__ float absf(float x) { return __uint_as_float(__float_as_uint(x) & 0x7FFFFFFFu); }
 
 // _mm256_polarf_ps avx_float.h:55-63 : sign = xor of signs, magnitude = min of magnitudes
+#ifdef PAMD_POLAR_F_MINF
+// Three VALU instructions: v_min_f32 with |.| source modifiers (exact on magnitudes: the kernels run with fp32
+// denormals preserved), v_xor_b32, v_and_or_b32.  Measured on one box: cfg 3 (4 lanes per path x 2 codewords)
+// +1.3 %, but SC -2.3 % and cfg 5 -3.8 % (the asm statement keeps the compiler from merging the |.| with its other
+// users there), so only the translation units that define the macro take this form.
+__device__ __forceinline__ float polar_f(float a, float b)
+{
+    float m;
+    asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(m) : "v"(a), "v"(b));
+    return bitsf(((fbits(a) ^ fbits(b)) & 0x80000000u) | fbits(m));
+}
+#else
 __device__ __forceinline__ float polar_f(float a, float b)
 {
     const uint32_t ua = fbits(a), ub = fbits(b);
@@ -50,6 +62,7 @@ __device__ __forceinline__ float polar_f(float a, float b)
     const uint32_t m = ma < mb ? ma : mb;  // magnitudes of non-NaN floats order like their bits
     return bitsf(((ua ^ ub) & 0x80000000u) | m);
 }
+#endif
 // _mm256_polarg_ps avx_float.h:71-81 : (a ^ sign(u)) + b
 __device__ __forceinline__ float polar_g(float a, float b, uint32_t u)
 {

@@ -1,4 +1,5 @@
 // List-decoder kernels with 4 lanes per path and 2 codeword(s) per wave (scl_kernel.h).
+#define PAMD_POLAR_F_MINF 1  // (device_common.h: the 3-instruction f pays off for this kernel)
 #include "scl_kernel.h"
 #include "scl_launch.h"
 
