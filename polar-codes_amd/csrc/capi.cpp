@@ -283,12 +283,12 @@ void specialize_scl(pcd_decoder* d)
             in.off = aux;
         }
     }
-    // Fuse the neighbours of small leaves (4 lanes per path, blocks of at most 8 LLRs); flags in Ins::pad, see
+    // Fuse the neighbours of small leaves (4 or 8 lanes per path, blocks of at most 8 LLRs); flags in Ins::pad, see
     // scl_kernel.h.  `F_S leaf` / `G_S leaf`: the leaf computes its input from the parent's LLRs in registers (that
     // stage is read by nobody else).  `F_S R0 G_S leaf`: an all-frozen left sibling only adds to the metric, so it
     // joins the right leaf's prologue.  A right leaf (or a COMBINE) also performs the single-word COMBINEs that
     // follow it directly.  Roughly 40 % of the program's instructions at N = 1024 go away.
-    if (d->lpl == 2 && !std::getenv("PCD_NO_FUSE")) {
+    if ((d->lpl == 2 || d->lpl == 3) && !std::getenv("PCD_NO_FUSE")) {
         auto& v = d->scl_prog.ins;
         auto small_leaf = [](const pamd::Ins& in) {
             return in.stage <= 3 &&

@@ -1143,9 +1143,10 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
             // registers and never stored), the COMBINEs that follow a right leaf (or a COMBINE) as its epilogue.
             //   bits 0-1: input is 1 = F of the parent's LLRs, 2 = G, 3 = G after an all-frozen left sibling (whose
             //             F + RateZero step runs here too);  bits 2-4: COMBINEs that follow;  bit 5: side of the last
-            const uint32_t fuse = LPL == 2 ? ((uint32_t)(iw >> 24) & 0xFFu) : 0u;
+            constexpr bool kFuse = LPL == 2 || LPL == 3;  // (8 lanes per path: lane j holds LLR j, x1 is unused)
+            const uint32_t fuse = kFuse ? ((uint32_t)(iw >> 24) & 0xFFu) : 0u;
             auto leaf_input4 = [&](float& x0, float& x1) {  // LLRs j and j + 4 of this lane's path
-                const bool in0 = (uint32_t)c.j < n, in1 = n == 8;
+                const bool in0 = (uint32_t)c.j < n, in1 = LP == 4 && n == 8;
                 const uint32_t i0 = in0 ? (uint32_t)c.j : 0u, i1 = in1 ? (uint32_t)c.j + 4u : 0u;
                 const uint32_t pro = fuse & 3u;
                 if (pro == 0) {
@@ -1155,7 +1156,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 } else {
                     constexpr typename Ctx::SlotT FM = (typename Ctx::SlotT)(LCW - 1);
                     const uint32_t psh = s * (uint32_t)Ctx::FB;  // slot field of the parent stage s + 1
-                    const uint32_t grand = ((uint32_t)(iw >> 56)) & 3u;
+                    const uint32_t grand = LPL == 2 ? (((uint32_t)(iw >> 56)) & 3u) : 0u;
                     if (grand) {
                         // n = 4, pro = 1, and the stage-3 block the F reads is itself the output of the F_S / G_S / G0_S
                         // (grand = 1 / 2 / 3) of stage 4 right before: that op runs here too -- lane j produces LLRs j
@@ -1314,15 +1315,17 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                     if (small && !(DIAG && (P.ablate & 2u))) {
                         constexpr uint32_t INFB = 0xFFFFFFFFu;
                         const bool in = (uint32_t)c.j < n;
-                        const float xj = (c.path_llr(c.p) + n)[in ? c.j : 0];
+                        float xj, xunused;
+                        leaf_input4(xj, xunused);
                         const uint32_t a = in ? (fbits(xj) & 0x7FFFFFFFu) : INFB;
+                        const uint64_t sg = ballot64(in && sgn(xj));
+                        signword = (uint32_t)(sg >> c.base) & 0xFFu;
                         if (spc) {
                             if (s == 2)
                                 find_weak_small<2, 4>(a, c.j, wk);
                             else
                                 find_weak_small<3, 4>(a, c.j, wk);
-                            const uint64_t sg = ballot64(in && sgn(xj));
-                            par = (uint32_t)__popc((uint32_t)(sg >> c.base) & 0xFFu) & 1u;
+                            par = (uint32_t)__popc(signword) & 1u;
                         } else {
                             Weak<2> w2;
                             if (s == 1)
@@ -1397,7 +1400,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 const typename Ctx::SlotT nslot = c.slot_from_lane(sl);
                 // flip positions (< 2^15 each) and the parity travel packed in two registers
                 // (small leaves at 4 lanes per path: positions < 8, and the source path's sign word rides along in pk0)
-                constexpr bool kSignWord = kSmallOp && LPL == 2;
+                constexpr bool kSignWord = kSmallOp && (LPL == 2 || LPL == 3);
                 const uint32_t pk0 = shfl_u32(wk.ix[0] | (kSignWord ? (signword << 8) : 0u) | (wk.ix[1] << 16), sl);
                 const uint32_t pk1 = shfl_u32(wk.ix[2] | (wk.ix[3] << 16) | (par << 31), sl);
                 const uint32_t fpos[4] = { kSignWord ? (pk0 & 0xFFu) : (pk0 & 0xFFFFu), pk0 >> 16, pk1 & 0xFFFFu,
@@ -1515,7 +1518,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 }
                 c.slot = (c.slot & ~((typename Ctx::SlotT)(LCW - 1) << fsh)) | ((typename Ctx::SlotT)c.pl << fsh);
             } else if (ins.op == SCL_C_S) {  // COMBINE, h < 32
-                if (LPL == 2 && fuse) {  // ... and the COMBINEs right above it
+                if (kFuse && fuse) {  // ... and the COMBINEs right above it
                     if (active && c.j == 0) combine_chain((c.area(1, c.p) + wo_c)[0], s - 1, (fuse >> 2) & 7u, (fuse >> 5) & 1u, false);
                 } else
                 if (active && c.j == 0 && !skip_small) {
@@ -1692,7 +1695,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 float acc[NACC];
 #pragma unroll
                 for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
-                if (LPL == 2 && fuse) {  // n <= 8, input straight from the fused F / G
+                if (kFuse && fuse) {  // n <= 8, input straight from the fused F / G
                     float x0, x1;
                     leaf_input4(x0, x1);
                     if (active) {
@@ -1719,7 +1722,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 const float sum = c.lanesum_finish(acc);
                 if (active) {
                     c.metric = c.metric + sum;
-                    if (LPL == 2 && fuse) {
+                    if (kFuse && fuse) {
                         leaf_bits_out(c.j == 0, 0u);
                     } else {
                         uint32_t* ob = c.bits(side, c.p, s);
@@ -1731,7 +1734,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 float az[NACC], ao[NACC];
 #pragma unroll
                 for (int a = 0; a < NACC; ++a) az[a] = ao[a] = 0.0f;
-                if (LPL == 2 && fuse) {  // n <= 4 (lanesum_low4 below), input straight from the fused F / G
+                if (kFuse && fuse) {  // n <= 4 (lanesum_low4 below), input straight from the fused F / G
                     float x0, x1;
                     leaf_input4(x0, x1);
                     if (active) {
