@@ -141,13 +141,12 @@ struct SclCtx {
     template <bool I8, typename F>
     __device__ __forceinline__ void with_src(uint32_t t, uint32_t q, F&& fn) const
     {
-        if (t == logN) {
-            if constexpr (I8)
-                fn(Rd<K_GI8>{ chan });
-            else
-                fn(Rd<K_GF32>{ chan });
+        // (fp32 channel rows and arena stages are both plain global floats: one instantiation of the caller's body
+        // serves both -- the code of this kernel has to stay well inside the instruction cache)
+        if (I8 && t == logN) {
+            fn(Rd<K_GI8>{ chan });
         } else if (t >= s0) {
-            fn(Rd<K_ARENA>{ arena_stage(q, t) });
+            fn(Rd<K_ARENA>{ t == logN ? chan : (const void*)arena_stage(q, t) });
         } else {
             fn(Rd<K_LDS>{ path_llr(q) + (1u << t) });
         }
@@ -156,11 +155,8 @@ struct SclCtx {
     template <bool I8, typename F>
     __device__ __forceinline__ void with_src_kind(uint32_t t, F&& fn) const
     {
-        if (t == logN) {
-            if constexpr (I8)
-                fn(std::integral_constant<int, K_GI8>{});
-            else
-                fn(std::integral_constant<int, K_GF32>{});
+        if (I8 && t == logN) {
+            fn(std::integral_constant<int, K_GI8>{});
         } else if (t >= s0) {
             fn(std::integral_constant<int, K_ARENA>{});
         } else {
@@ -1576,7 +1572,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         for (uint32_t e = lane; e < total; e += 64) {
                             uint32_t ct;
                             const uint32_t q = item_group(e >> ish, ct), i = (e & (ipp - 1)) << 2;
-                            const Rd<SK> x{ (SK == K_GF32 || SK == K_GI8) ? chan_of(ct) : c.template src_base<SK>(s, q) };
+                            const Rd<SK> x{ (SK == K_GI8 || s == logN) ? chan_of(ct) : c.template src_base<SK>(s, q) };
                             const float4 a = x.ld4(i), b = x.ld4(h + i);
                             const float4 r = make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z),
                                                          polar_f(a.w, b.w));
@@ -1642,7 +1638,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                             // LLR[s] of path q lives in the buffer its slot word names (all lanes take part in the move)
                             const uint32_t srcq = c.field(c.slot_from_lane((int)(q << LPL)), s, q);
                             if (in) {
-                                const Rd<SK> x{ (SK == K_GF32 || SK == K_GI8) ? chan_of(ct) : c.template src_base<SK>(s, srcq) };
+                                const Rd<SK> x{ (SK == K_GI8 || s == logN) ? chan_of(ct) : c.template src_base<SK>(s, srcq) };
                                 const float4 a = x.ld4(i), b = x.ld4(h + i);
                                 const uint32_t u = (c.bits(0, q, s - 1)[i >> 5] >> (i & 31u)) & 0xFu;
                                 const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
