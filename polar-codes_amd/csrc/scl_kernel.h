@@ -1582,13 +1582,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                                 Wr<K_LDS>{ c.path_llr(q) + h }.st4(i, r);
                         }
                     });
-                } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case)
-                    if (active) {
-                        const float* x = c.path_llr(c.p) + n;
-                        float* d = c.path_llr(c.p) + h;
-                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_f(x[i], x[h + i]);
-                    }
-                } else if (active) {
+                } else if (active) {  // (stages in LDS normally run as SCL_F_S)
                     c.template with_src<I8>(s, c.p, [&](auto x) {
                         c.with_dst(s - 1, c.p, [&](auto d) {
                             for (uint32_t i = c.j; i < h; i += LP) d.set(i, polar_f(x[i], x[h + i]));
@@ -1650,14 +1644,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                             }
                         }
                     });
-                } else if (s < c.s0 && s < logN) {  // both stages in LDS (the common case); h <= 32: one bit word
-                    if (active) {
-                        const float* x = c.path_llr(c.field(c.slot, s, (uint32_t)c.p)) + n;
-                        float* d = c.path_llr(c.p) + h;
-                        const uint32_t lw = (c.area(0, c.p) + wo)[0];
-                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
-                    }
-                } else if (active) {
+                } else if (active) {  // (stages in LDS normally run as SCL_G_S)
                     const uint32_t srcq = c.field(c.slot, s, (uint32_t)c.p);
                     const uint32_t* lb = c.area(0, c.p) + wo;
                     c.template with_src<I8>(s, srcq, [&](auto x) {
