@@ -122,6 +122,7 @@ int grow(T*& p, size_t& cap, size_t bytes)
 }
 
 void specialize_scl(pcd_decoder* d);
+void fuse_sc(pcd_decoder* d);
 
 void compute_geometry(pcd_decoder* d)
 {
@@ -150,6 +151,7 @@ void compute_geometry(pcd_decoder* d)
         d->sc_wave_words = ((1u << s0) + bitw + 3) & ~3u;
         d->sc_arena_cw_words = (N >> 1) - (1u << s0);  // stages s0 .. logN - 2 (stage logN - 1 is recomputed)
     }
+    if (d->has_sc) fuse_sc(d);
     d->sc_wpb = 1;  // single-wave workgroups: LDS granularity of one wave, nothing is shared between waves anyway
     if (const char* e = std::getenv("PCD_SC_WPB")) d->sc_wpb = (unsigned)std::max(1, std::atoi(e));
     if (d->L > 1) {
@@ -236,6 +238,75 @@ void compute_geometry(pcd_decoder* d)
         if (!std::getenv("PCD_NO_SPECIALIZE")) specialize_scl(d);
         d->scl_wpb = 1;
     }
+}
+
+// Fast-SSC program (flags in Ins::pad / Ins::side, see sc_kernel.hip): a leaf absorbs the F / G / G0R in front of it
+// and a right leaf the COMBINE behind it; COMBINEs of consecutive stages (a right spine) run in the instruction that
+// finishes the lowest block; the F ops of a left descent run in the instruction that starts it.  F / G inputs must be
+// plain LDS stages: not the channel row, not the recomputed stage below the root, not an arena stage.
+void fuse_sc(pcd_decoder* d)
+{
+    if (std::getenv("PCD_NO_FUSE")) return;
+    auto& v = d->sc_prog.ins;
+    auto is_leaf = [](const pamd::Ins& in) { return in.op >= pamd::SC_R0 && in.op <= pamd::SC_ZEROSPC; };
+    const unsigned top = d->logN - (d->sc_virtual_top ? 1u : 0u);  // first stage that is not a stored LDS / arena stage
+    auto lds_stage = [&](unsigned t) { return t < top && t < d->sc_s0; };
+    std::vector<pamd::Ins> out;
+    out.reserve(v.size());
+    for (size_t i = 0; i < v.size(); ++i) {
+        pamd::Ins in = v[i];
+        const bool fg = in.op == pamd::SC_F || in.op == pamd::SC_G || in.op == pamd::SC_G0R;
+        if (fg && in.pad == 0 && in.side == 0 && in.stage >= 1 && lds_stage(in.stage) && i + 1 < v.size() &&
+            is_leaf(v[i + 1]) && v[i + 1].stage + 1u == in.stage && v[i + 1].pad == 0) {
+            pamd::Ins leaf = v[i + 1];
+            if (leaf.op != pamd::SC_R0)  // (an all-frozen leaf reads nothing: its F / G simply disappears)
+                leaf.pad = in.op == pamd::SC_F ? 1 : (in.op == pamd::SC_G ? 2 : 3);
+            in = leaf;
+            ++i;
+        }
+        const bool no_c = std::getenv("PCD_NO_FUSE_C") != nullptr;
+        unsigned coff = 0, ch = 0;  // the block this instruction finishes: [coff, coff + 2 ch)
+        bool head = false;
+        if (is_leaf(in) && (in.pad & 0xFCu) == 0 && i + 1 < v.size() &&
+            (v[i + 1].op == pamd::SC_COMBINE || v[i + 1].op == pamd::SC_COMBINE0R) && v[i + 1].stage == in.stage + 1u &&
+            v[i + 1].off + (1u << in.stage) == in.off && !no_c) {
+            in.pad |= v[i + 1].op == pamd::SC_COMBINE ? 4 : 8;
+            coff = v[i + 1].off;
+            ch = 1u << in.stage;
+            head = true;
+            ++i;
+        } else if ((in.op == pamd::SC_COMBINE || in.op == pamd::SC_COMBINE0R || in.op == pamd::SC_RONE) && in.pad == 0 && !no_c) {
+            coff = in.off;
+            ch = 1u << (in.stage - 1);
+            head = true;
+        }
+        if (head) {
+            unsigned k = 0;
+            while (k < 7 && i + 1 < v.size() && v[i + 1].op == pamd::SC_COMBINE && v[i + 1].pad == 0 &&
+                   (1u << (v[i + 1].stage - 1)) == 2 * ch && v[i + 1].off + 2 * ch == coff) {
+                coff = v[i + 1].off;
+                ch *= 2;
+                ++k;
+                ++i;
+            }
+            in.pad |= (uint8_t)(k << 4);
+        }
+        const bool still_fg = in.op == pamd::SC_F || in.op == pamd::SC_G || in.op == pamd::SC_G0R;  // (not absorbed above)
+        if (still_fg && in.pad == 0 && in.side == 0 && !std::getenv("PCD_NO_FUSE_F")) {
+            unsigned k = 0, st = in.stage;
+            while (k < 7 && st >= 2 && i + 1 < v.size() && v[i + 1].op == pamd::SC_F && v[i + 1].pad == 0 && v[i + 1].side == 0 &&
+                   v[i + 1].stage + 1u == st && lds_stage(st - 1) &&
+                   // the follower must not be the F a leaf would absorb (that saves more: the leaf reads its output directly)
+                   !(i + 2 < v.size() && is_leaf(v[i + 2]) && v[i + 2].stage + 1u == v[i + 1].stage)) {
+                --st;
+                ++k;
+                ++i;
+            }
+            in.side = (uint8_t)k;
+        }
+        out.push_back(in);
+    }
+    v.swap(out);
 }
 
 // Replace generic inner-node ops by their specialised forms (program.h) for the chosen geometry.

@@ -137,6 +137,51 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
             uint64_t t_start = 0;
             if (DIAG && P.cycles && grp == 0) t_start = __builtin_amdgcn_s_memtime();
 
+            // Host-fused neighbours (capi.cpp, fuse_sc) -- the SC kernel is bound by the scalar unit (dispatch), so an
+            // instruction saved counts more than its body:
+            //   pad  bits 0-1: the F / G / G0R (1 / 2 / 3) of the parent stage s + 1 (an LDS stage) that produces this leaf's
+            //                  input runs as a prologue;  bits 2-3: the parent's COMBINE / COMBINE0R (1 / 2) runs as an
+            //                  epilogue of this (right) leaf;  bits 4-6: plain COMBINEs of the stages above that follow
+            //   side bits 0-2: F ops of the stages below that follow this F / G / G0R (left descent, LDS stages only)
+            const uint32_t fzz = (uint32_t)(iw >> 16) & 0xFFFFu;
+            const uint32_t fz = fzz >> 8;
+            if (__builtin_expect(fz != 0u, 0) && (fz & 3u)) {
+                const float* X = llr + 2 * n;
+                float* d = llr + n;
+                const uint32_t pro = fz & 3u, lo = off - n;  // (G: the left sibling's bits sit right below this block)
+                for (uint32_t i = l; i < n; i += LC) {
+                    const float a = X[i], b = X[n + i];
+                    float r;
+                    if (pro == 1u) {
+                        r = polar_f(a, b);
+                    } else if (pro == 3u) {
+                        r = a + b;
+                    } else {
+                        const uint32_t bi = lo + i;
+                        r = polar_g(a, b, (bits[bi >> 5] >> (bi & 31u)) & 1u);
+                    }
+                    d[i] = r;
+                }
+                WAVE_SYNC();
+            }
+            auto combine = [&](uint32_t coff, uint32_t ch_, bool copy) {  // Combine / Combine_0R avx_float.h:190-204
+                if (ch_ >= 32) {
+                    const uint32_t w0 = coff >> 5, hw = ch_ >> 5;
+                    for (uint32_t w = l; w < hw; w += LC) {
+                        const uint32_t r = bits[w0 + hw + w];
+                        bits[w0 + w] = copy ? r : (bits[w0 + w] ^ r);
+                    }
+                } else if (l == 0) {
+                    const uint32_t sh = coff & 31u, mask = (1u << ch_) - 1u;
+                    uint32_t w = bits[coff >> 5];
+                    const uint32_t r = (w >> (sh + ch_)) & mask;
+                    if (copy)
+                        w = (w & ~(mask << sh)) | (r << sh);
+                    else
+                        w ^= r << sh;
+                    bits[coff >> 5] = w;
+                }
+            };
             // the op body, instantiated for the two kinds of input: an LDS stage buffer, or (root) the channel row
             auto run = [&](auto x) {
                 switch (op) {
@@ -166,26 +211,9 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                         for (uint32_t i = l; i < h; i += LC) llr[h + i] = x(i) + x(h + i);
                     break;
                 case SC_COMBINE:
-                case SC_COMBINE0R: {
-                    const bool copy = op == SC_COMBINE0R;
-                    if (h >= 32) {
-                        const uint32_t w0 = off >> 5, hw = h >> 5;
-                        for (uint32_t w = l; w < hw; w += LC) {
-                            const uint32_t r = bits[w0 + hw + w];
-                            bits[w0 + w] = copy ? r : (bits[w0 + w] ^ r);
-                        }
-                    } else if (l == 0) {
-                        const uint32_t sh = off & 31u, mask = (1u << h) - 1u;
-                        uint32_t w = bits[off >> 5];
-                        const uint32_t r = (w >> (sh + h)) & mask;
-                        if (copy)
-                            w = (w & ~(mask << sh)) | (r << sh);
-                        else
-                            w ^= r << sh;
-                        bits[off >> 5] = w;
-                    }
+                case SC_COMBINE0R:
+                    combine(off, h, op == SC_COMBINE0R);
                     break;
-                }
                 case SC_RONE: {  // h >= 8
                     for (uint32_t i0 = 0; i0 < h; i0 += LC) {
                         const uint32_t i = i0 + l;
@@ -396,6 +424,28 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
             } else {
                 const float* xs = llr + n;
                 run([&](uint32_t i) { return xs[i]; });
+            }
+            if (__builtin_expect((fzz & 0xFC07u) != 0u, 0)) {  // (anything but a prologue)
+                uint32_t coff = off, ch_ = h;  // (head = COMBINE / COMBINE0R / RONE: the finished block is its own)
+                if (fz & 12u) {  // the parent's COMBINE: this leaf is its right child, the block starts n bits below
+                    WAVE_SYNC();
+                    coff = off - n;
+                    ch_ = n;
+                    combine(coff, ch_, (fz & 12u) == 8u);
+                }
+                for (uint32_t t = (fz >> 4) & 7u; t; --t) {  // ... and it is the right child of the next one up
+                    coff -= 2 * ch_;
+                    ch_ *= 2;
+                    WAVE_SYNC();
+                    combine(coff, ch_, false);
+                }
+                for (uint32_t t = 0; t < (fzz & 7u); ++t) {  // F of the stages below (RateRNode::decode :148-155, left descent)
+                    const uint32_t fn = 1u << (s - 1 - t), fh = fn >> 1;
+                    WAVE_SYNC();
+                    const float* X = llr + fn;
+                    float* d = llr + fh;
+                    for (uint32_t i = l; i < fh; i += LC) d[i] = polar_f(X[i], X[fh + i]);
+                }
             }
             if (ARENA && (op == SC_F || op == SC_G || op == SC_G0R) && s - 1 >= s0) {
                 // the op stored LLRs to the arena: wait for the stores before other lanes of the wave read them
