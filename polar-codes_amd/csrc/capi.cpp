@@ -242,7 +242,8 @@ void compute_geometry(pcd_decoder* d)
 
 // Fast-SSC program (flags in Ins::pad / Ins::side, see sc_kernel.hip): a leaf absorbs the F / G / G0R in front of it
 // and a right leaf the COMBINE behind it; COMBINEs of consecutive stages (a right spine) run in the instruction that
-// finishes the lowest block; the F ops of a left descent run in the instruction that starts it.  F / G inputs must be
+// finishes the lowest block; when the finished block is a left child, the parent's G runs there as well; the F ops of a
+// left descent run in the instruction that starts it.  F / G inputs must be
 // plain LDS stages: not the channel row, not the recomputed stage below the root, not an arena stage.
 void fuse_sc(pcd_decoder* d)
 {
@@ -265,22 +266,20 @@ void fuse_sc(pcd_decoder* d)
             ++i;
         }
         const bool no_c = std::getenv("PCD_NO_FUSE_C") != nullptr;
-        unsigned coff = 0, ch = 0;  // the block this instruction finishes: [coff, coff + 2 ch)
-        bool head = false;
+        // the block this instruction finishes: [coff, coff + 2 ch)
+        unsigned coff = in.off, ch = in.stage ? (1u << (in.stage - 1)) : 0u;
+        bool finishes = is_leaf(in) || in.op == pamd::SC_COMBINE || in.op == pamd::SC_COMBINE0R || in.op == pamd::SC_RONE;
+        bool chain_head = finishes && !is_leaf(in) && in.pad == 0 && !no_c;
         if (is_leaf(in) && (in.pad & 0xFCu) == 0 && i + 1 < v.size() &&
             (v[i + 1].op == pamd::SC_COMBINE || v[i + 1].op == pamd::SC_COMBINE0R) && v[i + 1].stage == in.stage + 1u &&
             v[i + 1].off + (1u << in.stage) == in.off && !no_c) {
             in.pad |= v[i + 1].op == pamd::SC_COMBINE ? 4 : 8;
             coff = v[i + 1].off;
             ch = 1u << in.stage;
-            head = true;
+            chain_head = true;
             ++i;
-        } else if ((in.op == pamd::SC_COMBINE || in.op == pamd::SC_COMBINE0R || in.op == pamd::SC_RONE) && in.pad == 0 && !no_c) {
-            coff = in.off;
-            ch = 1u << (in.stage - 1);
-            head = true;
         }
-        if (head) {
+        if (chain_head) {
             unsigned k = 0;
             while (k < 7 && i + 1 < v.size() && v[i + 1].op == pamd::SC_COMBINE && v[i + 1].pad == 0 &&
                    (1u << (v[i + 1].stage - 1)) == 2 * ch && v[i + 1].off + 2 * ch == coff) {
@@ -291,9 +290,22 @@ void fuse_sc(pcd_decoder* d)
             }
             in.pad |= (uint8_t)(k << 4);
         }
+        // The finished block is a left child: the parent's G comes next and can run right here (unless a leaf is about to
+        // absorb it, which also spares the LDS round trip of its output).
+        unsigned fstage = 0;  // stage of the F / G / G0R whose left descent may follow inside this instruction
+        const bool no_f = std::getenv("PCD_NO_FUSE_F") != nullptr;
+        if (finishes && ch && !no_f && !std::getenv("PCD_NO_FUSE_G") && i + 1 < v.size() && v[i + 1].op == pamd::SC_G &&
+            v[i + 1].pad == 0 && v[i + 1].side == 0 && (1u << v[i + 1].stage) == 4 * ch && v[i + 1].off == coff &&
+            lds_stage(v[i + 1].stage) &&
+            !(i + 2 < v.size() && is_leaf(v[i + 2]) && v[i + 2].stage + 1u == v[i + 1].stage)) {
+            in.side |= 8;
+            fstage = v[i + 1].stage;
+            ++i;
+        }
         const bool still_fg = in.op == pamd::SC_F || in.op == pamd::SC_G || in.op == pamd::SC_G0R;  // (not absorbed above)
-        if (still_fg && in.pad == 0 && in.side == 0 && !std::getenv("PCD_NO_FUSE_F")) {
-            unsigned k = 0, st = in.stage;
+        if (still_fg && in.pad == 0 && in.side == 0 && !no_f) fstage = in.stage;
+        if (fstage) {
+            unsigned k = 0, st = fstage;
             while (k < 7 && st >= 2 && i + 1 < v.size() && v[i + 1].op == pamd::SC_F && v[i + 1].pad == 0 && v[i + 1].side == 0 &&
                    v[i + 1].stage + 1u == st && lds_stage(st - 1) &&
                    // the follower must not be the F a leaf would absorb (that saves more: the leaf reads its output directly)
@@ -302,7 +314,7 @@ void fuse_sc(pcd_decoder* d)
                 ++k;
                 ++i;
             }
-            in.side = (uint8_t)k;
+            in.side |= (uint8_t)k;
         }
         out.push_back(in);
     }

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
             //   pad  bits 0-1: the F / G / G0R (1 / 2 / 3) of the parent stage s + 1 (an LDS stage) that produces this leaf's
             //                  input runs as a prologue;  bits 2-3: the parent's COMBINE / COMBINE0R (1 / 2) runs as an
             //                  epilogue of this (right) leaf;  bits 4-6: plain COMBINEs of the stages above that follow
-            //   side bits 0-2: F ops of the stages below that follow this F / G / G0R (left descent, LDS stages only)
+            //   side bit 3:    the block this instruction finishes is a left child -- the parent's G runs here too
+            //   side bits 0-2: F ops of the stages below that follow this F / G / G0R or that tail G (left descent)
             const uint32_t fzz = (uint32_t)(iw >> 16) & 0xFFFFu;
             const uint32_t fz = fzz >> 8;
             if (__builtin_expect(fz != 0u, 0) && (fz & 3u)) {
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                 const float* xs = llr + n;
                 run([&](uint32_t i) { return xs[i]; });
             }
-            if (__builtin_expect((fzz & 0xFC07u) != 0u, 0)) {  // (anything but a prologue)
+            if (__builtin_expect((fzz & 0xFC0Fu) != 0u, 0)) {  // (anything but a prologue)
                 uint32_t coff = off, ch_ = h;  // (head = COMBINE / COMBINE0R / RONE: the finished block is its own)
                 if (fz & 12u) {  // the parent's COMBINE: this leaf is its right child, the block starts n bits below
                     WAVE_SYNC();
@@ -439,8 +440,20 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     WAVE_SYNC();
                     combine(coff, ch_, false);
                 }
-                for (uint32_t t = 0; t < (fzz & 7u); ++t) {  // F of the stages below (RateRNode::decode :148-155, left descent)
-                    const uint32_t fn = 1u << (s - 1 - t), fh = fn >> 1;
+                uint32_t fbase = h;  // length of the stage the first follower F reads
+                if (fzz & 8u) {  // G of the parent of the finished block [coff, coff + 2 ch_) (RateRNode::decode :148-155)
+                    const uint32_t gh = 2 * ch_;
+                    WAVE_SYNC();
+                    const float* X = llr + 2 * gh;
+                    float* d = llr + gh;
+                    for (uint32_t i = l; i < gh; i += LC) {
+                        const uint32_t bi = coff + i;
+                        d[i] = polar_g(X[i], X[gh + i], (bits[bi >> 5] >> (bi & 31u)) & 1u);
+                    }
+                    fbase = gh;
+                }
+                for (uint32_t t = 0; t < (fzz & 7u); ++t) {  // F of the stages below (left descent)
+                    const uint32_t fn = fbase >> t, fh = fn >> 1;
                     WAVE_SYNC();
                     const float* X = llr + fn;
                     float* d = llr + fh;
