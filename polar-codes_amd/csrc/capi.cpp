@@ -151,6 +151,14 @@ void compute_geometry(pcd_decoder* d)
         d->sc_wave_words = ((1u << s0) + bitw + 3) & ~3u;
         d->sc_arena_cw_words = (N >> 1) - (1u << s0);  // stages s0 .. logN - 2 (stage logN - 1 is recomputed)
     }
+    // LDS bank skew: the codewords of a wave make the same accesses at the same offsets of their slices, and a slice
+    // stride that is a multiple of 32 words puts them all on the same banks (measured at N = 1024, stride 544: 40 % of
+    // the LDS cycles were bank conflicts).  With 16 (8) lanes per codeword a stride of 16 (8) mod 32 words spreads the two
+    // (four) codewords of a 32-lane LDS pass over all banks.
+    if (d->sc_lcl <= 4 && !std::getenv("PCD_SC_NO_SKEW")) {
+        const unsigned want = 1u << d->sc_lcl;
+        d->sc_wave_words += (want + 32u - d->sc_wave_words % 32u) % 32u;
+    }
     if (d->has_sc) fuse_sc(d);
     d->sc_wpb = 1;  // single-wave workgroups: LDS granularity of one wave, nothing is shared between waves anyway
     if (const char* e = std::getenv("PCD_SC_WPB")) d->sc_wpb = (unsigned)std::max(1, std::atoi(e));

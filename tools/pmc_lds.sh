@@ -1,0 +1,13 @@
+#!/bin/bash
+export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}; CFG=${1:-cfg3}; KER=${2:-scl_decode_kernel}; LB=${3:-18}
+cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/pmclds_$CFG -- python3 $R/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --log2-batch $LB > /dev/null 2>&1
+cd $R && python3 - "$CFG" "$KER" "$LB" <<'PY'
+import csv, glob, collections, sys
+cfg, ker, lb = sys.argv[1], sys.argv[2], int(sys.argv[3])
+agg = collections.defaultdict(float)
+for f in glob.glob(f"gpurun_out/pmclds_{cfg}/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if ker in r["Kernel_Name"]: agg[r["Counter_Name"]] += float(r["Counter_Value"])
+n = 1 << lb
+for k, v in sorted(agg.items()): print(f"{cfg} {k:24s} total={v:.6g} per_cw={v / n:.1f}")
+PY
