@@ -130,6 +130,7 @@ __device__ __forceinline__ uint32_t partner_u32(uint32_t v)
         return v;                                                          \
     }
 PAMD_GROUP_REDUCE(uint32_t, group_xor_u32, partner_u32, v ^ o)
+PAMD_GROUP_REDUCE(uint32_t, group_or_u32, partner_u32, v | o)
 PAMD_GROUP_REDUCE(uint32_t, group_max_u32, partner_u32, o > v ? o : v)
 PAMD_GROUP_REDUCE(uint32_t, group_min_u32, partner_u32, o < v ? o : v)
 

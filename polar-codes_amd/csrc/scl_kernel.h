@@ -984,6 +984,28 @@ __device__ __forceinline__ void write_leaf_bits(const CTX& c, const SRC& x, uint
     const uint32_t n = 1u << s;
     uint32_t* dst = c.bits(side, c.p, s);
     uint32_t acc = 0;
+    constexpr uint32_t E = 4u * LP;  // LLRs per path and trip with 16-byte loads
+    if (LP <= 8 && n >= E) {
+        // every lane takes four consecutive LLRs, the sign nibbles of the path's lanes are OR-ed together (DPP), and
+        // the flips are applied to the finished words
+        for (uint32_t i0 = 0; i0 < n; i0 += E) {
+            uint32_t nib = 0;
+            if (active) {
+                const float4 a = x.ld4(i0 + 4u * (uint32_t)c.j);
+                nib = sgn(a.x) | (sgn(a.y) << 1) | (sgn(a.z) << 2) | (sgn(a.w) << 3);
+            }
+            acc |= group_or_u32<LP>(nib << (4u * (uint32_t)c.j)) << (i0 & 31u);
+            if (((i0 + E) & 31u) == 0 || i0 + E >= n) {
+                const uint32_t wi = i0 >> 5;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    acc ^= (((fmask >> k) & 1u) && (fpos[k] >> 5) == wi) ? (1u << (fpos[k] & 31u)) : 0u;
+                if (active && c.j == 0) dst[wi] = acc;
+                acc = 0;
+            }
+        }
+        return;
+    }
     for (uint32_t i0 = 0; i0 < n; i0 += LP) {
         const uint32_t i = i0 + c.j;
         uint32_t b = 0;
