@@ -268,8 +268,10 @@ struct Weak {
     uint32_t ix[CNT];  // original indices
 };
 
+// signs (optional): receives the XOR of the sign bits of this lane's share of the block (bit 0), so that the SPC parity
+// comes out of the same scan.
 template <typename CTX, int CNT, typename SRC>
-__device__ __forceinline__ void find_weak(const CTX& c, const SRC& x, uint32_t n, Weak<CNT>& out)
+__device__ __forceinline__ void find_weak(const CTX& c, const SRC& x, uint32_t n, Weak<CNT>& out, uint32_t* signs = nullptr)
 {
     constexpr int LP = CTX::LP;
     constexpr uint32_t INFB = 0xFFFFFFFFu;  // larger than any |x| bit pattern / any position
@@ -286,23 +288,40 @@ __device__ __forceinline__ void find_weak(const CTX& c, const SRC& x, uint32_t n
         tv[k] = INFB;
         tp[k] = INFB;
     }
-    const bool has_tail = n > (uint32_t)CNT;  // wave uniform
+    const bool has_tail = n > (uint32_t)CNT;  // wave uniform (then n >= 4)
+    uint32_t sx = 0;
     if (has_tail) {
-        for (uint32_t i = (uint32_t)CNT + (uint32_t)c.j; i < n; i += LP) {
-            uint32_t a = fbits(x[i]) & 0x7FFFFFFFu, ap = i;
-            bool placed = false;
+        // 16-byte loads: lane j takes the chunks j, j + LP, ... of four consecutive LLRs (one load latency per four
+        // elements: the scan of a large leaf is bound by it); the head positions in chunk 0 stay out of the tail lists
+        const uint32_t nch = n >> 2;
+        for (uint32_t ch = (uint32_t)c.j; ch < nch; ch += LP) {
+            const float4 q = x.ld4(ch << 2);
+            const float e4[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
-            for (int k = 0; k < CNT; ++k) {  // positions arrive ascending: strict '<' keeps earlier ones first
-                const bool lt = placed || (a < tv[k]);
-                const uint32_t sv = lt ? tv[k] : a, sp = lt ? tp[k] : ap;
-                tv[k] = lt ? a : tv[k];
-                tp[k] = lt ? ap : tp[k];
-                a = sv;
-                ap = sp;
-                placed = lt;
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t fb = fbits(e4[e]);
+                sx ^= fb;
+                uint32_t ap = (ch << 2) + (uint32_t)e;
+                uint32_t a = ap >= (uint32_t)CNT ? (fb & 0x7FFFFFFFu) : INFB;
+                bool placed = false;
+#pragma unroll
+                for (int k = 0; k < CNT; ++k) {  // positions arrive ascending: strict '<' keeps earlier ones first
+                    const bool lt = placed || (a < tv[k]);
+                    const uint32_t sv = lt ? tv[k] : a, sp = lt ? tp[k] : ap;
+                    tv[k] = lt ? a : tv[k];
+                    tp[k] = lt ? ap : tp[k];
+                    a = sv;
+                    ap = sp;
+                    placed = lt;
+                }
             }
         }
+    } else if (c.j == 0) {
+#pragma unroll
+        for (int e = 0; e < CNT; ++e)
+            if ((uint32_t)e < n) sx ^= fbits(x[e]);
     }
+    if (signs) *signs = sx >> 31;
     const uint32_t lim = (n - 1 < (uint32_t)CNT) ? n - 1 : (uint32_t)CNT;
 #pragma unroll
     for (int i = 0; i < CNT; ++i) {
@@ -1273,9 +1292,8 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 uint32_t par = 0;
                 auto search = [&](auto x) {
                     if (spc) {
-                        find_weak<Ctx, 4>(c, x, n, wk);
                         uint32_t pb = 0;
-                        for (uint32_t i = c.j; i < n; i += LP) pb ^= sgn(x[i]);
+                        find_weak<Ctx, 4>(c, x, n, wk, &pb);
                         par = group_xor_u32<LP>(pb) & 1u;
                     } else {
                         Weak<2> w2;
