@@ -1513,7 +1513,16 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 if (active && !skip_small) {
                     const float* x = c.path_llr(c.p) + n;
                     float* d = c.path_llr(c.p) + h;
-                    for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_f(x[i], x[h + i]);
+                    if (h >= 4) {  // 16-byte LDS accesses: a lane takes four consecutive outputs per trip
+                        const Rd<K_LDS> xr{ x };
+                        const Wr<K_LDS> dw{ d };
+                        for (uint32_t i = 4u * (uint32_t)c.j; i < h; i += 4u * LP) {
+                            const float4 a = xr.ld4(i), b = xr.ld4(h + i);
+                            dw.st4(i, make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z), polar_f(a.w, b.w)));
+                        }
+                    } else {
+                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_f(x[i], x[h + i]);
+                    }
                 }
                 c.slot = (c.slot & ~((typename Ctx::SlotT)(LCW - 1) << fsh)) | ((typename Ctx::SlotT)c.pl << fsh);
             } else if (ins.op == SCL_G_S) {  // G, both stages in LDS, h <= 32: one left-bit word
@@ -1522,7 +1531,18 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                     const float* x = c.path_llr(srcq) + n;
                     float* d = c.path_llr(c.p) + h;
                     const uint32_t lw = (c.area(0, c.p) + wo_c)[0];
-                    for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
+                    if (h >= 4) {
+                        const Rd<K_LDS> xr{ x };
+                        const Wr<K_LDS> dw{ d };
+                        for (uint32_t i = 4u * (uint32_t)c.j; i < h; i += 4u * LP) {
+                            const float4 a = xr.ld4(i), b = xr.ld4(h + i);
+                            const uint32_t u = lw >> i;
+                            dw.st4(i, make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
+                                                  polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, (u >> 3) & 1u)));
+                        }
+                    } else {
+                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
+                    }
                 }
                 c.slot = (c.slot & ~((typename Ctx::SlotT)(LCW - 1) << fsh)) | ((typename Ctx::SlotT)c.pl << fsh);
             } else if (ins.op == SCL_G0_S) {  // all-frozen left child: F_S + RateZeroDecoder::decode :316-337 + G_S (u = 0)
