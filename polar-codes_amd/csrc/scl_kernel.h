@@ -1886,9 +1886,10 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
             // the best path passes for almost every codeword: check it alone with all lanes of the codeword first
             const uint32_t* b0 = c.bits(0, (uint32_t)c.g0, logN);
             uint32_t syn0 = 0;
-            for (uint32_t t = (uint32_t)lane - lane0; t < P.K; t += LCWL) {
-                const uint32_t pos = P.lut[t];
-                if ((b0[pos >> 5] >> (pos & 31u)) & 1u) syn0 ^= P.syn[t];
+#pragma unroll 4
+            for (uint32_t t = (uint32_t)lane - lane0; t < P.K; t += LCWL) {  // (branch-free: the table loads of several trips overlap)
+                const uint32_t pos = P.lut[t], sy = P.syn[t];
+                syn0 ^= ((b0[pos >> 5] >> (pos & 31u)) & 1u) ? sy : 0u;
             }
             syn0 = group_xor_u32<LCWL>(syn0);
             best_passes = ballot64(syn0 != 0) == 0;  // ... of every codeword of the wave
@@ -1920,6 +1921,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
             const uint32_t wg = CWL == 0 ? winner : readlane_u32(winner, t * LCWL);
             const uint32_t* wb = c.bits(0, wg, logN);
             uint8_t* orow = P.out + (size_t)row_t * P.nb;
+#pragma unroll 2
             for (uint32_t t0 = 0; t0 < P.K; t0 += 64) {
                 const uint32_t tt = t0 + lane;
                 uint32_t bit = 0;
