@@ -60,11 +60,20 @@ struct ScLanes {
     __device__ __forceinline__ uint32_t min_index(uint32_t best, uint32_t bidx, bool any) const
     {
         uint64_t key = any ? (((uint64_t)best << 32) | bidx) : (((uint64_t)0x7F800000u << 32) | 0xFFFFFFFFu);
-#pragma unroll
-        for (int m = 1; m < LC; m <<= 1) {
-            const uint64_t o = shflx_u64(key, m);
-            key = o < key ? o : key;
-        }
+        // all-reduce inside the group: DPP partners inside a 16-lane row (no LDS round trips), ds_bpermute beyond
+        auto step = [&](auto M) {
+            constexpr int m = decltype(M)::value;
+            if constexpr (m < LC) {
+                const uint64_t o = ((uint64_t)partner_u32<m>((uint32_t)(key >> 32)) << 32) | partner_u32<m>((uint32_t)key);
+                key = o < key ? o : key;
+            }
+        };
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 8>{});
+        step(std::integral_constant<int, 16>{});
+        step(std::integral_constant<int, 32>{});
         const uint32_t idx = (uint32_t)key;
         return idx == 0xFFFFFFFFu ? 0u : idx;
     }
