@@ -426,27 +426,31 @@ def test_mixed_decoder_grid(built_library, N, L):
     assert 0 < int(sc_ok.sum()) < B      # the batch exercises both the SC-only and the SC + list branch
 
 
-FUSE_SWITCHES = ["PCD_NO_FUSE", "PCD_NO_FUSE_C", "PCD_NO_FUSE_R0", "PCD_NO_FUSE_G0", "PCD_NO_FUSE_GRAND", "PCD_NO_FUSE_CW"]
+FUSE_SWITCHES = ["PCD_NO_FUSE", "PCD_NO_FUSE_C", "PCD_NO_FUSE_R0", "PCD_NO_FUSE_G0", "PCD_NO_FUSE_GRAND", "PCD_NO_FUSE_CW",
+                 "PCD_NO_FUSE_F", "PCD_NO_FUSE_G", "PCD_SC_NO_SKEW"]
 
 
 @pytest.mark.parametrize("switch", FUSE_SWITCHES)
-def test_fused_and_unfused_list_programs_agree(built_library, switch, monkeypatch):
-    """The host rewrites the list decoder's instruction list (capi.cpp, specialize_scl: leaf prologues, COMBINE chains,
-    G0_S); every stage of that rewrite can be switched off when the decoder is created.  All variants must reproduce
-    the reference's vectors -- 4 lanes per path (L = 8), 8 lanes per path (L = 2, 4) and a random frozen set."""
+def test_fused_and_unfused_programs_agree(built_library, switch, monkeypatch):
+    """The host rewrites the decoders' instruction lists (capi.cpp: specialize_scl -- leaf prologues, COMBINE chains,
+    G0_S; fuse_sc -- leaf prologues / epilogues, COMBINE chains, tail G, left-descent F runs); every stage of that
+    rewrite can be switched off when the decoder is created.  All variants must reproduce the reference's vectors --
+    SC, 4 lanes per path (L = 8), 8 lanes per path (L = 2, 4) and random frozen sets."""
     names = ["cfg3_n1024_k512_l8_crc24_awgn.bin", "cfg3_n1024_k512_l8_crc24_ties.bin", "cfg4_n1024_k176_l8_crc11_awgn.bin",
-             "mix_n256_k128_l4_crc8_awgn.bin", "sweep_n512.bin"]
+             "mix_n256_k128_l4_crc8_awgn.bin", "sweep_n512.bin", "cfg2_n1024_k512_sc_awgn.bin", "cfg2_n1024_k512_sc_ties.bin",
+             "sweep_n2048.bin", "cfg1_n64_k40_sc_awgn.bin"]
     monkeypatch.setenv(switch, "1")
     for name in names:
         for fx in gio.load(os.path.join(gio.GOLDEN_DIR, name)):
-            if fx.L < 2 or fx.dectype != "float":
+            if fx.dectype != "float":
                 continue
-            out, ok, met = _decoder(fx).decode_batch(fx.llr, return_metrics=True)
-            assert np.array_equal(out, fx.out), (switch, fx.name)
-            assert np.array_equal(ok.astype(np.uint8), fx.ok), (switch, fx.name)
-            _check_metrics(met, fx.metrics, fx.npaths, fx.name)
+            res = _decoder(fx).decode_batch(fx.llr, return_metrics=fx.L > 1)
+            assert np.array_equal(res[0], fx.out), (switch, fx.name)
+            assert np.array_equal(res[1].astype(np.uint8), fx.ok), (switch, fx.name)
+            if fx.L > 1:
+                _check_metrics(res[2], fx.metrics, fx.npaths, fx.name)
     rng = np.random.default_rng(5)
-    for N, L in [(256, 2), (256, 4), (512, 8), (128, 8)]:
+    for N, L in [(256, 2), (256, 4), (512, 8), (128, 8), (256, 1), (2048, 1)]:
         K = N // 2
         frozen = np.sort(rng.choice(N, N - K, replace=False)).astype(np.uint32)
         llr = (rng.standard_normal((48, N)) * 2.0 + 1.0).astype(np.float32)
@@ -457,6 +461,7 @@ def test_fused_and_unfused_list_programs_agree(built_library, switch, monkeypatc
         import pypolar_amd
         d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
         d.setErrorDetection(8, "crc")
-        out, ok, met = d.decode_batch(llr, return_metrics=True)
-        assert np.array_equal(out, e_out) and np.array_equal(ok.astype(np.uint8), e_ok), (switch, N, L)
-        assert np.allclose(met, e_met, rtol=METRIC_RTOL, atol=0), (switch, N, L)
+        res = d.decode_batch(llr, return_metrics=L > 1)
+        assert np.array_equal(res[0], e_out) and np.array_equal(res[1].astype(np.uint8), e_ok), (switch, N, L)
+        if L > 1:
+            assert np.allclose(res[2], e_met, rtol=METRIC_RTOL, atol=0), (switch, N, L)
