@@ -56,6 +56,25 @@ struct ScLanes {
 #pragma unroll
         for (int v = 0; v < 8; ++v) a[v] = shfl_f32(acc, lbase + v);
     }
+    // sign of the reference's lanesum (fold8 + x0+..+x7 in that order), uniform in the group: lane 0 of the group pulls
+    // the accumulators of lanes 1..7 with DPP row shifts (a group never straddles a 16-lane row), one ballot spreads it
+    template <typename X>
+    __device__ __forceinline__ bool lanesum_negative(const X& x, uint32_t n) const
+    {
+        float acc = 0.0f;
+        if (l < 8)
+            for (uint32_t i = l; i < n; i += 8) acc = acc + x(i);
+        const uint32_t a = fbits(acc);
+        float s = acc;
+        s = s + bitsf(dpp_u32<0x101>(a));
+        s = s + bitsf(dpp_u32<0x102>(a));
+        s = s + bitsf(dpp_u32<0x103>(a));
+        s = s + bitsf(dpp_u32<0x104>(a));
+        s = s + bitsf(dpp_u32<0x105>(a));
+        s = s + bitsf(dpp_u32<0x106>(a));
+        s = s + bitsf(dpp_u32<0x107>(a));
+        return (slice(ballot64(l == 0 && sgn(s))) & 1ull) != 0;
+    }
     // lexicographic (value, index) minimum over the group; key of a lane without candidates = (inf, ~0)
     __device__ __forceinline__ uint32_t min_index(uint32_t best, uint32_t bidx, bool any) const
     {
@@ -253,12 +272,9 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                         g.put_bits(bits, off + i0, n < (uint32_t)LC ? n : (uint32_t)LC, m);
                     }
                     break;
-                case SC_REP: {
-                    float a[8];
-                    g.fold8(x, n, a);
-                    g.fill_pattern(bits, off, n, sgn(reduce_add8(a)) ? 0xFFFFFFFFu : 0u);
+                case SC_REP:
+                    g.fill_pattern(bits, off, n, g.lanesum_negative(x, n) ? 0xFFFFFFFFu : 0u);
                     break;
-                }
                 case SC_SPC: {
                     uint32_t par = 0;
                     for (uint32_t i0 = 0; i0 < n; i0 += LC) {
