@@ -46,15 +46,40 @@ struct ScLanes {
             put_bits(bits, off, n, pat & ((1u << n) - 1u));
         }
     }
-    // the reference's fold8 (8 strided AVX accumulators, acc = 0; acc += x[8k+v]); result broadcast in the group
+    // the reference's fold8 (8 strided AVX accumulators, acc = 0; acc += x[8k+v]).  The eight sums arrive in LANE 0 of
+    // the group (DPP row shifts; a group never straddles a 16-lane row) -- the other lanes hold don't-care values.
     template <typename X>
     __device__ __forceinline__ void fold8(const X& x, uint32_t n, float a[8]) const
     {
         float acc = 0.0f;
         if (l < 8)
             for (uint32_t i = l; i < n; i += 8) acc = acc + x(i);
-#pragma unroll
-        for (int v = 0; v < 8; ++v) a[v] = shfl_f32(acc, lbase + v);
+        const uint32_t u = fbits(acc);
+        a[0] = acc;
+        a[1] = bitsf(dpp_u32<0x101>(u));
+        a[2] = bitsf(dpp_u32<0x102>(u));
+        a[3] = bitsf(dpp_u32<0x103>(u));
+        a[4] = bitsf(dpp_u32<0x104>(u));
+        a[5] = bitsf(dpp_u32<0x105>(u));
+        a[6] = bitsf(dpp_u32<0x106>(u));
+        a[7] = bitsf(dpp_u32<0x107>(u));
+    }
+    // the value lane 0 of the group holds, in every lane of the group (LC <= 16: quad broadcast + row shifts)
+    __device__ __forceinline__ uint32_t from_lane0(uint32_t v) const
+    {
+        if constexpr (LC > 16) {
+            return shfl_u32(v, lbase);
+        } else {
+            const uint32_t q0 = dpp_u32<0x00>(v);  // lane 0 of every quad
+            if constexpr (LC <= 4) return q0;
+            const uint32_t q1 = dpp_u32<0x114>(q0);  // row_shr:4
+            uint32_t r = (l & 4) ? q1 : q0;
+            if constexpr (LC > 8) {
+                const uint32_t q2 = dpp_u32<0x118>(q0), q3 = dpp_u32<0x11C>(q0);  // row_shr:8, :12
+                r = (l & 8) ? ((l & 4) ? q3 : q2) : r;
+            }
+            return r;
+        }
     }
     // sign of the reference's lanesum (fold8 + x0+..+x7 in that order), uniform in the group: lane 0 of the group pulls
     // the accumulators of lanes 1..7 with DPP row shifts (a group never straddles a 16-lane row), one ballot spreads it
@@ -298,7 +323,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                         e = ((a[0] + a[2]) + a[4]) + a[6];
                         o = ((a[1] + a[3]) + a[5]) + a[7];
                     }
-                    g.fill_pattern(bits, off, n, (sgn(e) ? 0x55555555u : 0u) | (sgn(o) ? 0xAAAAAAAAu : 0u));
+                    g.fill_pattern(bits, off, n, g.from_lane0((sgn(e) ? 0x55555555u : 0u) | (sgn(o) ? 0xAAAAAAAAu : 0u)));
                     break;
                 }
                 case SC_DSPC8: {  // flip EVERY class member tied for the class minimum
@@ -355,7 +380,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     g.fold8(x, n, a);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) t[j] = a[j] + a[j + 4];
-                    g.fill_pattern(bits, off, n, spc4_signs(t) * 0x11111111u);
+                    g.fill_pattern(bits, off, n, g.from_lane0(spc4_signs(t) * 0x11111111u));
                     break;
                 }
                 case SC_TYPE5:
@@ -379,7 +404,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     else
                         ss = sgn(gg[0]) | (sgn(gg[1]) << 1) | (sgn(gg[2]) << 2) | (sgn(gg[3]) << 3);
                     const uint32_t byte = ((sr ? (ss ^ 0xFu) : ss) & 0xFu) | (ss << 4);
-                    g.fill_pattern(bits, off, n, byte * 0x01010101u);
+                    g.fill_pattern(bits, off, n, g.from_lane0(byte * 0x01010101u));
                     break;
                 }
                 case SC_ZSPC8: {
