@@ -155,9 +155,12 @@ void compute_geometry(pcd_decoder* d)
     // stride that is a multiple of 32 words puts them all on the same banks (measured at N = 1024, stride 544: 40 % of
     // the LDS cycles were bank conflicts).  With 16 (8) lanes per codeword a stride of 16 (8) mod 32 words spreads the two
     // (four) codewords of a 32-lane LDS pass over all banks.
+    // (Not when the extra words cost a resident wave: N = 4096 sits exactly at 10 KB per wave.)
     if (d->sc_lcl <= 4 && !std::getenv("PCD_SC_NO_SKEW")) {
-        const unsigned want = 1u << d->sc_lcl;
-        d->sc_wave_words += (want + 32u - d->sc_wave_words % 32u) % 32u;
+        const unsigned want = 1u << d->sc_lcl, cws = 64u >> d->sc_lcl;
+        const unsigned skewed = d->sc_wave_words + (want + 32u - d->sc_wave_words % 32u) % 32u;
+        if (lds_blocks_per_cu((size_t)skewed * 4 * cws) >= lds_blocks_per_cu((size_t)d->sc_wave_words * 4 * cws))
+            d->sc_wave_words = skewed;
     }
     if (d->has_sc) fuse_sc(d);
     d->sc_wpb = 1;  // single-wave workgroups: LDS granularity of one wave, nothing is shared between waves anyway
