@@ -64,6 +64,13 @@ struct ScLanes {
         a[6] = bitsf(dpp_u32<0x106>(u));
         a[7] = bitsf(dpp_u32<0x107>(u));
     }
+    // value of lane l ^ 4 (same parity class; row_half_mirror would cross the classes).  Both moves run in all lanes
+    // BEFORE the select: a DPP read from a lane that is masked out returns 0, so they must not sit in the arms of a branch.
+    __device__ __forceinline__ uint32_t xor4_u32(uint32_t v) const
+    {
+        const uint32_t dn = dpp_u32<0x114>(v), up = dpp_u32<0x104>(v);  // row_shr:4 (lane l - 4), row_shl:4 (lane l + 4)
+        return (l & 4) ? dn : up;
+    }
     // the value lane 0 of the group holds, in every lane of the group (LC <= 16: quad broadcast + row shifts)
     __device__ __forceinline__ uint32_t from_lane0(uint32_t v) const
     {
@@ -331,11 +338,13 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     const float v = x(l8);
                     float m = absf(v);
                     uint32_t p = sgn(v);
-#pragma unroll
-                    for (int k = 2; k < 8; k <<= 1) {
-                        const float om = shflx_f32(m, k);
+                    {  // (lanes l ^ 2 and l ^ 4 by DPP: both keep the parity class of l)
+                        float om = bitsf(partner_u32<2>(fbits(m)));
                         m = om < m ? om : m;
-                        p ^= shflx_u32(p, k);
+                        p ^= partner_u32<2>(p);
+                        om = bitsf(g.xor4_u32(fbits(m)));
+                        m = om < m ? om : m;
+                        p ^= g.xor4_u32(p);
                     }
                     const uint32_t bit = sgn(v) ^ ((p && absf(v) == m) ? 1u : 0u);
                     g.put_bits(bits, off, 8, g.slice(ballot64(l < 8 && bit)));
@@ -354,9 +363,10 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                         }
                     }
                     float cm = minv;  // class minimum over lanes of equal parity (within lanes 0..7 of the group)
-#pragma unroll
-                    for (int k = 2; k < 8; k <<= 1) {
-                        const float om = shflx_f32(cm, k);
+                    {
+                        float om = bitsf(partner_u32<2>(fbits(cm)));
+                        cm = om < cm ? om : cm;
+                        om = bitsf(g.xor4_u32(fbits(cm)));
                         cm = om < cm ? om : cm;
                     }
                     const uint64_t tie = g.slice(ballot64(l < 8 && minv == cm));
