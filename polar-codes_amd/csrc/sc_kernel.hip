@@ -307,15 +307,24 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                 case SC_REP:
                     g.fill_pattern(bits, off, n, g.lanesum_negative(x, n) ? 0xFFFFFFFFu : 0u);
                     break;
-                case SC_SPC: {
-                    uint32_t par = 0;
+                case SC_SPC: {  // one pass: hard decisions, parity and the first minimum of |x| (SpcDecoder::decode :342-373)
+                    uint32_t par = 0, best = 0x7F800000u, bidx = 0;
+                    bool any = false;
                     for (uint32_t i0 = 0; i0 < n; i0 += LC) {
                         const uint32_t i = i0 + l;
-                        const uint64_t m = g.slice(ballot64(i < n && sgn(x(i < n ? i : 0))));
+                        const bool in = i < n;
+                        const uint32_t xb = fbits(x(in ? i : 0));
+                        const uint64_t m = g.slice(ballot64(in && (xb >> 31)));
                         par ^= (uint32_t)__popcll(m) & 1u;
                         g.put_bits(bits, off + i0, n < (uint32_t)LC ? n : (uint32_t)LC, m);
+                        const uint32_t a = xb & 0x7FFFFFFFu;
+                        if (in && a < best) {
+                            best = a;
+                            bidx = i;
+                            any = true;
+                        }
                     }
-                    const uint32_t im = g.firstmin_abs(x, n);
+                    const uint32_t im = g.min_index(best, bidx, any);
                     if (par) g.flip_bit(bits, off + im);
                     break;
                 }
