@@ -152,7 +152,10 @@ __device__ __forceinline__ float reduce_add8(const float a[8])
 
 // ARENA: LLR stages s0 <= t < logN - 1 live in a per-codeword slice of global memory (cache resident) instead of LDS,
 // so that long blocks keep four codewords per wave and 16 waves per CU (the list kernels do the same, scl_kernel.h).
-template <int LCL, bool I8, bool DIAG = false, bool ARENA = false>
+// B2: the wide F / G loops take two elements per lane and trip (their loads are in flight together).  Worth 2-3 % from
+// N = 1024 on; it costs registers (86 -> 115 VGPRs, 4 instead of 5 waves per SIMD), which shorter blocks -- whose LDS
+// footprint would allow the fifth wave -- pay with 15 %, so the host picks by block length.
+template <int LCL, bool I8, bool DIAG = false, bool ARENA = false, bool B2 = false>
 __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
 {
     constexpr int LC = 1 << LCL;
@@ -249,7 +252,13 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                 case SC_F:
                     if (ARENA && s - 1 >= s0)
                         for (uint32_t i = l; i < h; i += LC) ar[h + i] = polar_f(x(i), x(h + i));
-                    else
+                    else if (B2 && h >= 2u * LC) {  // two elements per lane and trip: their loads are in flight together
+                        for (uint32_t i0 = l; i0 < h; i0 += 2u * LC) {
+                            const float a0 = x(i0), b0 = x(h + i0), a1 = x(i0 + LC), b1 = x(h + i0 + LC);
+                            llr[h + i0] = polar_f(a0, b0);
+                            llr[h + i0 + LC] = polar_f(a1, b1);
+                        }
+                    } else
                         for (uint32_t i = l; i < h; i += LC) llr[h + i] = polar_f(x(i), x(h + i));
                     break;
                 case SC_G:
@@ -257,6 +266,14 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                         for (uint32_t i = l; i < h; i += LC) {
                             const uint32_t b = off + i;
                             ar[h + i] = polar_g(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
+                        }
+                    } else if (B2 && h >= 2u * LC) {
+                        for (uint32_t i0 = l; i0 < h; i0 += 2u * LC) {
+                            const uint32_t bi0 = off + i0, bi1 = bi0 + LC;
+                            const float a0 = x(i0), b0 = x(h + i0), a1 = x(i0 + LC), b1 = x(h + i0 + LC);
+                            const uint32_t u0 = (bits[bi0 >> 5] >> (bi0 & 31u)) & 1u, u1 = (bits[bi1 >> 5] >> (bi1 & 31u)) & 1u;
+                            llr[h + i0] = polar_g(a0, b0, u0);
+                            llr[h + i0 + LC] = polar_g(a1, b1, u1);
                         }
                     } else {
                         for (uint32_t i = l; i < h; i += LC) {
@@ -617,15 +634,15 @@ hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, uns
         return i8 ? launch_sc_k<3, true>(P, g, b, lds, st, occupancy) : launch_sc_k<3, false>(P, g, b, lds, st, occupancy);
     if (lcl == 4 && P.s0 < P.logN && !P.cycles) {  // long blocks: upper LLR stages in the arena
         if (i8) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, true, false, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, true, false, true, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<4, true, false, true>, (int)b.x, lds);
-            hipLaunchKernelGGL((sc_decode_kernel<4, true, false, true>), g, b, lds, st, P);
+            if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<4, true, false, true, true>, (int)b.x, lds);
+            hipLaunchKernelGGL((sc_decode_kernel<4, true, false, true, true>), g, b, lds, st, P);
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, false, false, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, false, false, true, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<4, false, false, true>, (int)b.x, lds);
-            hipLaunchKernelGGL((sc_decode_kernel<4, false, false, true>), g, b, lds, st, P);
+            if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<4, false, false, true, true>, (int)b.x, lds);
+            hipLaunchKernelGGL((sc_decode_kernel<4, false, false, true, true>), g, b, lds, st, P);
         }
         return hipGetLastError();
     }
@@ -633,6 +650,20 @@ hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, uns
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((sc_decode_kernel<4, false, true>), g, b, lds, st, P);
+        return hipGetLastError();
+    }
+    if (lcl == 4 && P.logN >= 10) {  // (N = 1024 without arena: the two-deep variant)
+        if (i8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, true, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<4, true, false, false, true>, (int)b.x, lds);
+            hipLaunchKernelGGL((sc_decode_kernel<4, true, false, false, true>), g, b, lds, st, P);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, false, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<4, false, false, false, true>, (int)b.x, lds);
+            hipLaunchKernelGGL((sc_decode_kernel<4, false, false, false, true>), g, b, lds, st, P);
+        }
         return hipGetLastError();
     }
     if (lcl == 4)
