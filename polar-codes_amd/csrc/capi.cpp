@@ -358,6 +358,31 @@ void specialize_scl(pcd_decoder* d)
     }
     auto woff = [](unsigned t) { return t <= 5 ? t : ((1u << (t - 5)) + 4u); };
     const unsigned fb = 6u - (unsigned)d->lpl - d->cwl;  // bits per slot field: a path buffer of the same codeword
+    // The children of the root (virtual input) for all paths of a codeword from one set of channel loads, with the F
+    // steps of the left descent below them in the same instruction (SCL_VTOP, scl_kernel.h): N = 1024 with 4 lanes per
+    // path x 2 codewords per wave, i.e. one 16-byte chunk of the 256 outputs per lane.
+    // (it stores stages logN-2 / logN-3 to the arena and stage logN-4 to LDS, and reads its bit blocks from the arena)
+    if (d->virtual_top && d->lpl == 2 && d->cwl == 1 && d->logN == 10 && d->logN * fb <= 32 && d->s0 == d->logN - 3 &&
+        d->sb <= d->logN - 2 && !std::getenv("PCD_NO_VTOP")) {
+        auto& v = d->scl_prog.ins;
+        std::vector<pamd::Ins> out;
+        out.reserve(v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            pamd::Ins in = v[i];
+            if ((in.op == pamd::SCL_F || in.op == pamd::SCL_G) && in.stage == d->logN - 1 && (in.side & 4u)) {
+                unsigned k = 0;
+                while (k < 2 && i + 1 < v.size() && v[i + 1].op == pamd::SCL_F && v[i + 1].stage + 1u + k == in.stage &&
+                       (v[i + 1].side & 0xEu) == 0 && v[i + 1].pad == 0) {
+                    ++k;
+                    ++i;
+                }
+                in.off = (in.op == pamd::SCL_G ? 1u : 0u) | (k << 1);
+                in.op = pamd::SCL_VTOP;
+            }
+            out.push_back(in);
+        }
+        v.swap(out);
+    }
     for (auto& in : d->scl_prog.ins) {
         const unsigned s = in.stage;
         if ((in.op == pamd::SCL_SPC || in.op == pamd::SCL_R1) && (d->lpl == 3 || d->lpl == 2) && s <= 3 && s < d->s0 && s < d->logN) {

@@ -51,6 +51,11 @@ enum Op : uint8_t {
     SCL_SPC_S,     // SPC / R1 leaf of at most 8 LLRs held in LDS, 8 lanes per path (L <= 8 kernels only)
     SCL_R1_S,
     SCL_G0_S,      // F_S, RateZero on its output, G_S with all-zero left bits in one step (all-frozen left child)
+    // F / G of stage logN-1 with a virtual input (recomputed from the channel row) for ALL live paths of a codeword from
+    // one set of channel loads (every path reads the same row), with the F of the next one or two stages of the left
+    // descent applied to the values while they are still in registers (4 lanes per path x 2 codewords, N = 1024).
+    // `off`: bit 0 = the op is a G, bits 1-2 = number of fused F levels below (0..2)
+    SCL_VTOP,
 };
 
 struct Ins {

@@ -961,6 +961,127 @@ __device__ __forceinline__ void select_literal_cw(const CTX& c, const float (&va
     nidx = ridx;
 }
 
+// ---- candidate selection by merging sorted lists (4 lanes per path x 8 path groups x 2 codewords per wave) ----------
+// The candidates of ONE path come out of the leaf formulas already ordered (R1: m >= m-v0 >= m-v1 >= (m-v0)-v1 because
+// v0 <= v1 and fp32 subtraction is monotone; SPC: all but one pair, fixed by the caller; REP: one compare), so the
+// reference's partial selection sort over the L x CPP candidates is a merge of 8 sorted lists that keeps the best 8.
+// Path metrics are never positive, so the raw fp32 bit pattern read as an unsigned integer orders them the other way
+// round: the BEST candidate has the SMALLEST key, and 0xFFFFFFFF (no metric) marks an empty slot.
+// Layout: list element i of a path sits in register i / 4, lane i % 4 of the path's quad.  Three merge levels (quad
+// pairs inside 8 lanes, 8-lane groups inside a DPP row, the two rows of the codeword), each = one "keep the smaller of
+// a_i and b_(7-i)" step followed by a 3-stage bitonic clean-up over 8 lanes; the sort direction alternates between
+// sibling groups so that the partner of the next level is a plain lane ^ 8 / lane ^ 16 exchange.  Inside an 8-lane
+// group, rank r ends up at lane phi(r) = r < 4 ? r : 11 - r (all four groups of a codeword hold the same result).
+// Everything stays on the VALU (DPP moves, v_permlane16_swap); exact ties that matter are detected afterwards and
+// handed to the literal emulation by the caller (return value false).
+constexpr uint64_t merge_keepmin_mask(int dist, int dbit)
+{
+    uint64_t m = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int b2 = (l >> 2) & 1;
+        const bool base = dist == 4 ? (b2 == 0) : (dist == 2 ? (((l >> 1) & 1) == b2) : ((l & 1) == b2));
+        const bool d = dbit >= 0 ? ((l >> dbit) & 1) != 0 : false;
+        if (base != d) m |= 1ull << l;
+    }
+    return m;
+}
+// One compare-exchange stage on (key, payload) pairs with the partner lane named by a DPP control; KEEPMIN marks the
+// lanes that keep the smaller key (32-bit pattern, the same for both halves of the wave).  Written in assembly: the
+// compiler's form keeps nine 64-bit lane masks in SGPRs, which this kernel does not have (they were spilled to VGPR
+// lanes and reloaded in every stage); here the mask is a literal of two s_xor_b32.  DPP reads need two wait states
+// after the VALU write of their source (s_nop 1; the compiler does not see inside the statement).
+//   vcc = (partner >= own) ^ KEEPMIN... : "keep own" = !(partner < own) on KEEPMIN lanes, (partner < own) on the others
+#define PAMD_MERGE_STAGE(DPPSTR)                                                                          \
+    asm volatile("s_nop 1\n\t"                                                                            \
+                 "v_mov_b32_dpp %2, %0 " DPPSTR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                 "v_cmp_lt_u32_e32 vcc, %2, %0\n\t"                                                        \
+                 "s_xor_b32 vcc_lo, vcc_lo, %3\n\t"                                                        \
+                 "s_xor_b32 vcc_hi, vcc_hi, %3\n\t"                                                        \
+                 "v_cndmask_b32_e32 %0, %2, %0, vcc\n\t"                                                   \
+                 "v_cndmask_b32_dpp %1, %1, %1, vcc " DPPSTR " row_mask:0xf bank_mask:0xf bound_ctrl:1"    \
+                 : "+v"(k), "+v"(x), "=&v"(pk)                                                            \
+                 : "i"(KEEPMIN)                                                                           \
+                 : "vcc")
+template <int DIST, uint32_t KEEPMIN>
+__device__ __forceinline__ void merge_cmpex(uint32_t& k, uint32_t& x)
+{
+    uint32_t pk;
+    if constexpr (DIST == 4)
+        PAMD_MERGE_STAGE("row_half_mirror");
+    else if constexpr (DIST == 2)
+        PAMD_MERGE_STAGE("quad_perm:[2,3,0,1]");
+    else
+        PAMD_MERGE_STAGE("quad_perm:[1,0,3,2]");
+}
+#undef PAMD_MERGE_STAGE
+template <int DBIT>
+__device__ __forceinline__ void merge_sort8(uint32_t& k, uint32_t& x)
+{
+    merge_cmpex<4, (uint32_t)merge_keepmin_mask(4, DBIT)>(k, x);  // sequence distance 4: lane <-> 7 - lane
+    merge_cmpex<2, (uint32_t)merge_keepmin_mask(2, DBIT)>(k, x);
+    merge_cmpex<1, (uint32_t)merge_keepmin_mask(1, DBIT)>(k, x);
+}
+template <typename CTX, int CPP>
+__device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t x0, uint32_t k1, uint32_t x1,
+                                             uint32_t newP, float& nval, uint32_t& nidx)
+{
+    static_assert(CTX::LP == 4 && CTX::CW == 2 && CTX::LCW == 8, "8 path groups of 4 lanes per codeword");
+    constexpr uint32_t INFK = 0xFFFFFFFFu;
+    uint32_t k = k0, x = x0, pk;
+    if constexpr (CPP == 8) {  // a_i against b_(7-i): the other quad's second register, mirrored; keep the smaller
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b32_dpp %2, %3 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_cmp_ge_u32_e32 vcc, %2, %0\n\t"
+                     "v_cndmask_b32_e32 %0, %2, %0, vcc\n\t"
+                     "v_cndmask_b32_dpp %1, %4, %1, vcc row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                     : "+v"(k), "+v"(x), "=&v"(pk)
+                     : "v"(k1), "v"(x1)
+                     : "vcc");
+    }
+    merge_sort8<3>(k, x);
+    // the 8-lane neighbour group of the row (lane ^ 8) holds its list the other way round
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %2, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_cmp_ge_u32_e32 vcc, %2, %0\n\t"
+                 "v_cndmask_b32_e32 %0, %2, %0, vcc\n\t"
+                 "v_cndmask_b32_dpp %1, %1, %1, vcc row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "+v"(k), "+v"(x), "=&v"(pk)
+                 :
+                 : "vcc");
+    merge_sort8<4>(k, x);
+    {
+        // lane ^ 16: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the second.
+        // With both operands = k the results are {row 0, row 0, row 2, row 2} and {row 1, row 1, row 3, row 3}: in every
+        // lane one of them is the partner's key and the other the lane's own, so no lane predicate is needed
+        const auto sk = __builtin_amdgcn_permlane16_swap(k, k, false, false);
+        const auto sx = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        const bool ta = sk[0] < k, tb = sk[1] < k;
+        x = ta ? sx[0] : (tb ? sx[1] : x);
+        k = ta ? sk[0] : (tb ? sk[1] : k);
+    }
+    merge_sort8<-1>(k, x);
+    // exact ties among the winners: ranks r | r + 1 are quad neighbours (rotation by one lane; its wrap-around pair and
+    // the pairs of the second comparison that are not neighbours compare two ranks of the same list, so an equality
+    // there is a tie as well), ranks 3 | 4 sit in lanes 3 | 7 (rotation of the row by four lanes) ...
+    const uint32_t nx = dpp_u32<0x39>(k), n4 = dpp_u32<0x124>(k);
+    const bool tie = k != INFK && (k == nx || k == n4);
+    // ... and at the cut: exactly newP candidates of each codeword may be at or below the key of rank newP - 1
+    const uint32_t rl = newP - 1u, tl = rl < 4u ? rl : 11u - rl;
+    const uint32_t t0 = readlane_u32(k, (int)tl), t1 = readlane_u32(k, (int)(32u + tl));
+    uint32_t n0 = (uint32_t)__popc((uint32_t)ballot64(k0 <= t0)), n1 = (uint32_t)__popc((uint32_t)(ballot64(k0 <= t1) >> 32));
+    if constexpr (CPP == 8) {
+        n0 += (uint32_t)__popc((uint32_t)ballot64(k1 <= t0));
+        n1 += (uint32_t)__popc((uint32_t)(ballot64(k1 <= t1) >> 32));
+    }
+    if (ballot64(tie) != 0 || n0 != newP || n1 != newP) return false;
+    // new path pl inherits the candidate of rank pl
+    const uint32_t pl = (uint32_t)c.pl;
+    const uint32_t src = ((uint32_t)c.lane & ~7u) | (pl < 4u ? pl : 11u - pl);
+    nval = bitsf((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)k));
+    nidx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)x);
+    return true;
+}
+
 template <typename CTX, int LPL, int CPP>
 __device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
                                                 float pathbest, uint32_t newP, float& nval, uint32_t& nidx)
@@ -1138,7 +1259,19 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
         uint32_t trace_n = 0;
 
         uint64_t iw_next = prog64[0];
+        int lane_v = threadIdx.x & 63;
         for (uint32_t pc = 0;; ++pc) {
+            // The lane number is made opaque once per instruction so that nothing derived from it (addresses, lane
+            // predicates as 64-bit SGPR masks) is hoisted out of the interpreter loop: the kernel is at its register
+            // limits (128 VGPRs, 102 SGPRs) and hoisted values were spilled; re-deriving them costs a few VALU ops.
+            asm volatile("" : "+v"(lane_v));
+            const int lane = lane_v;
+            c.lane = lane;
+            c.p = lane >> LPL;
+            c.pl = c.p & (LCW - 1);
+            c.g0 = c.p & ~(LCW - 1);
+            c.j = lane & (LP - 1);
+            c.base = lane & ~(LP - 1);
             const uint64_t iw = iw_next;
             Ins ins;
             ins.op = (uint8_t)(iw & 0xFF);
@@ -1181,6 +1314,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
             //   bits 0-1: input is 1 = F of the parent's LLRs, 2 = G, 3 = G after an all-frozen left sibling (whose
             //             F + RateZero step runs here too);  bits 2-4: COMBINEs that follow;  bit 5: side of the last
             constexpr bool kFuse = LPL == 2 || LPL == 3;  // (8 lanes per path: lane j holds LLR j, x1 is unused)
+            constexpr bool kMerge = LPL == 2 && CWL == 1;  // candidate selection by select_merge
             const uint32_t fuse = kFuse ? ((uint32_t)(iw >> 24) & 0xFFu) : 0u;
             auto leaf_input4 = [&](float& x0, float& x1) {  // LLRs j and j + 4 of this lane's path
                 const bool in0 = (uint32_t)c.j < n, in1 = LP == 4 && n == 8;
@@ -1384,50 +1518,98 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 }
                 PAMD_STAMP(0)
                 const float v0 = bitsf(wk.v[0]), v1 = bitsf(wk.v[1]), v2 = bitsf(wk.v[2]), v3 = bitsf(wk.v[3]);
-                uint32_t nidx;
-                float nval;
+                uint32_t nidx = 0;
+                float nval = 0.0f;
                 uint32_t newP;
                 if (spc) {
                     constexpr int CPL = (8 >> LPL) ? (8 >> LPL) : 1;
-                    float val[CPL];
                     const float m = par ? c.metric - v0 : c.metric;
                     const float beta = par ? m - 0.0f : m - v0;
-#pragma unroll
-                    for (int r = 0; r < CPL; ++r) {
-                        const uint32_t q = (uint32_t)c.j * CPL + r;
-                        float t;
-                        switch (q) {
-                        case 0: t = m; break;
-                        case 1: t = beta - v1; break;
-                        case 2: t = beta - v2; break;
-                        case 3: t = beta - v3; break;
-                        case 4: t = (m - v1) - v2; break;
-                        case 5: t = (m - v1) - v3; break;
-                        case 6: t = (m - v2) - v3; break;
-                        default: t = ((beta - v1) - v2) - v3; break;
-                        }
-                        val[r] = t;
-                    }
                     newP = (c.P * 8 < c.L) ? c.P * 8 : c.L;
-                    select_dispatch<Ctx, LPL, 8>(c, val, m, newP, nval, nidx);
+                    auto literal = [&]() {  // candidates in the reference's order: position q of path pl in lane q / CPL
+                        float val[CPL];
+#pragma unroll
+                        for (int r = 0; r < CPL; ++r) {
+                            const uint32_t q = (uint32_t)c.j * CPL + r;
+                            float t;
+                            switch (q) {
+                            case 0: t = m; break;
+                            case 1: t = beta - v1; break;
+                            case 2: t = beta - v2; break;
+                            case 3: t = beta - v3; break;
+                            case 4: t = (m - v1) - v2; break;
+                            case 5: t = (m - v1) - v3; break;
+                            case 6: t = (m - v2) - v3; break;
+                            default: t = ((beta - v1) - v2) - v3; break;
+                            }
+                            val[r] = t;
+                        }
+                        if constexpr (kMerge)
+                            select_literal_cw<Ctx, LPL, 8>(c, val, newP, nval, nidx);
+                        else
+                            select_dispatch<Ctx, LPL, 8>(c, val, m, newP, nval, nidx);
+                    };
+                    if constexpr (kMerge) {
+                        bool done = false;
+                        if (c.P * 8 > newP && !(c.ablate & 1u)) {
+                            // the path's candidates best first: c0 c1 c2 {c3, c4} c5 c6 c7 -- element i in register
+                            // i / 4 of lane i % 4 (select_merge); branch-free per-lane selects
+                            const uint32_t j = (uint32_t)c.j;
+                            const float t1 = m - v1, t2 = m - v2;
+                            const float c3 = beta - v3, c4 = t1 - v2;
+                            const bool sw = fbits(c4) < fbits(c3);  // (keys: smaller = better)
+                            const float vs = j == 1 ? v1 : (j == 2 ? v2 : v3);
+                            float e0 = j == 0 ? m : beta - vs;
+                            e0 = (j == 3 && sw) ? c4 : e0;
+                            const float a3 = (beta - v1) - v2;
+                            const float A = j == 3 ? a3 : (j == 2 ? t2 : t1);
+                            float e1 = A - (j == 0 ? v2 : v3);
+                            e1 = (j == 0 && sw) ? c3 : e1;
+                            const uint32_t q0 = (j == 3 && sw) ? 4u : j, q1 = (j == 0 && sw) ? 3u : 4u + j;
+                            const uint32_t pb = (uint32_t)c.pl << 3;
+                            done = select_merge<Ctx, 8>(c, active ? fbits(e0) : 0xFFFFFFFFu, pb | q0,
+                                                        active ? fbits(e1) : 0xFFFFFFFFu, pb | q1, newP, nval, nidx);
+                        }
+                        if (!done) literal();
+                    } else {
+                        literal();
+                    }
                 } else {
                     constexpr int CPL = (4 >> LPL) ? (4 >> LPL) : 1;
-                    float val[CPL];
                     const float m = c.metric;
-#pragma unroll
-                    for (int r = 0; r < CPL; ++r) {
-                        const uint32_t q = (uint32_t)c.j * CPL + r;
-                        float t;
-                        switch (q) {
-                        case 0: t = m; break;
-                        case 1: t = m - v0; break;
-                        case 2: t = m - v1; break;
-                        default: t = (m - v0) - v1; break;
-                        }
-                        val[r] = t;
-                    }
                     newP = (c.P * 4 < c.L) ? c.P * 4 : c.L;
-                    select_dispatch<Ctx, LPL, 4>(c, val, m, newP, nval, nidx);
+                    auto literal = [&]() {
+                        float val[CPL];
+#pragma unroll
+                        for (int r = 0; r < CPL; ++r) {
+                            const uint32_t q = (uint32_t)c.j * CPL + r;
+                            float t;
+                            switch (q) {
+                            case 0: t = m; break;
+                            case 1: t = m - v0; break;
+                            case 2: t = m - v1; break;
+                            default: t = (m - v0) - v1; break;
+                            }
+                            val[r] = t;
+                        }
+                        if constexpr (kMerge)
+                            select_literal_cw<Ctx, LPL, 4>(c, val, newP, nval, nidx);
+                        else
+                            select_dispatch<Ctx, LPL, 4>(c, val, m, newP, nval, nidx);
+                    };
+                    if constexpr (kMerge) {
+                        bool done = false;
+                        if (c.P * 4 > newP && !(c.ablate & 1u)) {  // m >= m - v0 >= m - v1 >= (m - v0) - v1: lane j holds candidate j
+                            const uint32_t j = (uint32_t)c.j;
+                            const float d0 = m - v0;
+                            const float e0 = j == 0 ? m : (j == 1 ? d0 : (j == 2 ? m - v1 : d0 - v1));
+                            done = select_merge<Ctx, 4>(c, active ? fbits(e0) : 0xFFFFFFFFu, ((uint32_t)c.pl << 2) | j,
+                                                        0xFFFFFFFFu, 0u, newP, nval, nidx);
+                        }
+                        if (!done) literal();
+                    } else {
+                        literal();
+                    }
                 }
                 PAMD_STAMP(1)
                 const uint32_t srcp = (uint32_t)c.g0 + (spc ? (nidx >> 3) : (nidx >> 2));  // the source path's group
@@ -1816,6 +1998,19 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 const uint32_t newP = (c.P * 2 < c.L) ? c.P * 2 : c.L;
                 float nval;
                 uint32_t nidx;
+                bool done = false;
+                if constexpr (kMerge) {
+                    if (c.P * 2 > newP && !(c.ablate & 1u)) {  // the better of the two in lane 0, the other in lane 1
+                        const float ca = c.metric + z, cb = c.metric - o;
+                        const bool sw = fbits(cb) < fbits(ca);
+                        const bool first = c.j == 0;
+                        const float e0 = (first != sw) ? ca : cb;
+                        const uint32_t q0 = (first != sw) ? 0u : 1u;
+                        done = select_merge<Ctx, 2>(c, (active && c.j < 2) ? fbits(e0) : 0xFFFFFFFFu, ((uint32_t)c.pl << 1) | q0,
+                                                    0xFFFFFFFFu, 0u, newP, nval, nidx);
+                    }
+                    if (!done) select_literal_cw<Ctx, LPL, 2>(c, val, newP, nval, nidx);
+                } else
                 select_dispatch<Ctx, LPL, 2>(c, val, (c.metric + z > c.metric - o) ? c.metric + z : c.metric - o, newP, nval, nidx);
                 const uint32_t srcp = (uint32_t)c.g0 + (nidx >> 1), q = nidx & 1u;
                 const typename Ctx::SlotT nslot = c.slot_from_lane((int)(srcp << LPL));
@@ -1829,9 +2024,83 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 fork_leaf(std::true_type{}, std::false_type{});
             } else if (ins.op == SCL_R1) {
                 fork_leaf(std::false_type{}, std::false_type{});
+            } else if (ins.op == SCL_VTOP) {
+                if constexpr (kMerge && !S64 && HB) {
+                    // Stage s = logN - 1 block of every live path from the channel row: h = 256 outputs per path = one
+                    // 16-byte chunk per lane, so the four channel chunks a lane needs are loaded ONCE per codeword and
+                    // serve all its paths (they differ only in the bits that steer the g's).  The F of the next stages
+                    // pairs chunk l with l + 32 (the other half of the wave: v_permlane32_swap), then l with l + 16
+                    // (the other DPP row: v_permlane16_swap): the left descent continues in registers, every level
+                    // is still stored for the G that comes back to it later.  The bit words of path ql + 1 are fetched
+                    // before path ql is computed and stored (plain global loads -- the host only emits the op when
+                    // these bit blocks live in the arena -- so that the waits can be counted: a flat load would have to
+                    // wait for the stores issued behind it as well).
+                    const bool right = (vflags & 8u) != 0, isg = (aux & 1u) != 0;
+                    const uint32_t kf = (aux >> 1) & 3u;
+                    const uint32_t ci = 4u * (uint32_t)lane;
+                    const uint32_t wi = ci >> 5, wsh = ci & 31u;  // (h = 256 is a multiple of 32: chunk ci + h has the same shift)
+                    const uint32_t wo_root = woff(logN - 1) - c.wsb + wi, wo_u = woff(s - 1) - c.wsb + wi;
+                    auto f4 = [](float4 a, float4 b) {
+                        return make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z), polar_f(a.w, b.w));
+                    };
+                    auto g4 = [](float4 a, float4 b, uint32_t u) {
+                        return make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
+                                           polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, (u >> 3) & 1u));
+                    };
+                    for (uint32_t t = 0; t < (uint32_t)CW; ++t) {
+                        const void* chp = chanv[0];
+#pragma unroll
+                        for (int k = 1; k < CW; ++k) chp = (t == (uint32_t)k) ? chanv[k] : chp;
+                        const Rd<I8 ? K_GI8 : K_GF32> x{ chp };
+                        const float4 c0 = x.ld4(ci), c1 = x.ld4(ci + h), c2 = x.ld4(ci + 2u * h), c3 = x.ld4(ci + 3u * h);
+                        auto fetch = [&](uint32_t ql, uint32_t& wa, uint32_t& wb, uint32_t& wu) {
+                            const uint32_t q = t * (uint32_t)LCW + ql;
+                            wa = wb = wu = 0;
+                            if (right) {  // the root's left-child bits of path q sit in the buffer its slot word names
+                                const uint32_t sq = readlane_u32((uint32_t)c.slot, (int)(q << LPL));
+                                const uint32_t holder = t * (uint32_t)LCW + ((sq >> ((logN - 1u) * (uint32_t)Ctx::FB)) & (uint32_t)(LCW - 1));
+                                const uint32_t* rl = c.gbits + __umul24(holder, c.gwpp) + wo_root;
+                                wa = rl[0];
+                                wb = rl[h >> 5];
+                            }
+                            if (isg) wu = (c.gbits + __umul24(q, c.gwpp) + wo_u)[0];
+                        };
+                        uint32_t na, nb, nu;
+                        fetch(0, na, nb, nu);
+                        for (uint32_t ql = 0; ql < c.P; ++ql) {
+                            const uint32_t q = t * (uint32_t)LCW + ql;
+                            const uint32_t ua = (na >> wsh) & 0xFu, ub = (nb >> wsh) & 0xFu, u = (nu >> wsh) & 0xFu;
+                            if (ql + 1u < c.P) fetch(ql + 1u, na, nb, nu);
+                            const float4 a = right ? g4(c0, c2, ua) : f4(c0, c2), b = right ? g4(c1, c3, ub) : f4(c1, c3);
+                            const float4 r = isg ? g4(a, b, u) : f4(a, b);
+                            Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(ci, r);
+                            if (kf >= 1u) {
+                                // lanes 0..31: chunk l of stage s - 2 = f(chunk l, chunk l + 32)
+                                const auto sx = __builtin_amdgcn_permlane32_swap(fbits(r.x), fbits(r.x), false, false);
+                                const auto sy = __builtin_amdgcn_permlane32_swap(fbits(r.y), fbits(r.y), false, false);
+                                const auto sz = __builtin_amdgcn_permlane32_swap(fbits(r.z), fbits(r.z), false, false);
+                                const auto sw = __builtin_amdgcn_permlane32_swap(fbits(r.w), fbits(r.w), false, false);
+                                const float4 r2 = f4(r, make_float4(bitsf(sx[1]), bitsf(sy[1]), bitsf(sz[1]), bitsf(sw[1])));
+                                if (lane < 32) Wr<K_GF32>{ c.arena_stage(q, s - 2) }.st4(ci, r2);
+                                if (kf >= 2u) {
+                                    // lanes 0..15: chunk l of stage s - 3 = f(chunk l, chunk l + 16)
+                                    const auto tx = __builtin_amdgcn_permlane16_swap(fbits(r2.x), fbits(r2.x), false, false);
+                                    const auto ty = __builtin_amdgcn_permlane16_swap(fbits(r2.y), fbits(r2.y), false, false);
+                                    const auto tz = __builtin_amdgcn_permlane16_swap(fbits(r2.z), fbits(r2.z), false, false);
+                                    const auto tw = __builtin_amdgcn_permlane16_swap(fbits(r2.w), fbits(r2.w), false, false);
+                                    const float4 r3 = f4(r2, make_float4(bitsf(tx[1]), bitsf(ty[1]), bitsf(tz[1]), bitsf(tw[1])));
+                                    if (lane < 16) Wr<K_LDS>{ c.path_llr(q) + (1u << (s - 3)) }.st4(ci, r3);
+                                }
+                            }
+                        }
+                    }
+                    c.set_field(s);
+                    if (kf >= 1u) c.set_field(s - 1);
+                    if (kf >= 2u) c.set_field(s - 2);
+                }
             }
         op_done:
-            if (ins.op <= SCL_G && s - 1 >= c.s0 && !(vflags & 2u)) {
+            if ((ins.op <= SCL_G || ins.op == SCL_VTOP) && s - 1 >= c.s0 && !(vflags & 2u)) {
                 // this op stored LLRs to the global arena: wait for the stores (L2 is the meeting point; the
                 // arena is read back with sc1 loads)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1985,7 +2254,11 @@ static hipError_t launch_scl_t(const DecodeParams& P, bool i8, bool diag, dim3 g
     constexpr unsigned fb = 6u - LPL - CWL;    // bits per slot field
     const bool slot64 = P.logN * fb > 32u;
     const bool hb = P.sb <= P.logN;            // high-stage bit blocks in the arena
-    if (diag && !i8) return launch_scl_k<LPL, false, true, true, true, CWL>(P, grid, block, lds, st, occ);
+    if (diag && !i8) {  // (diagnostic variant: the slot word of the production kernel where it exists)
+        constexpr bool DS64 = fb > 3;
+        if (slot64 && !DS64) return hipErrorInvalidValue;
+        return launch_scl_k<LPL, false, DS64, true, true, CWL>(P, grid, block, lds, st, occ);
+    }
     if constexpr (fb <= 3) {
         if (!slot64 && !hb)
             return i8 ? launch_scl_k<LPL, true, false, false, false, CWL>(P, grid, block, lds, st, occ)
