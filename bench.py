@@ -3,7 +3,11 @@
 codewords/s (+ info-Gbit/s) of Fast-SSCL decoding, N=1024 K=512 L=8 + CRC-24C, batch 2^20 per GPU,
 synthetic AWGN LLRs (Eb/N0 = 2 dB, systematic codewords with valid checksums), inputs resident in HBM.
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) the
+script is one rank; started plainly it launches its N ranks itself as fresh child processes -- before anything in the
+parent has touched the GPU -- relays rank 0's JSON line and exits non-zero if any rank does.
 
 A step = one pass of the hot path over the whole resident batch: pcd_decode_f32 on device pointers
 (+ for N > 1 the all-gather of the decoded bytes and verdicts over RCCL).  Prints ONE JSON line (rank 0).
@@ -11,22 +15,78 @@ A step = one pass of the hot path over the whole resident batch: pcd_decode_f32 
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "polar-codes_amd"))
 
-import pypolar_amd  # noqa: E402
-from pypolar_amd import detector as pdet  # noqa: E402
-from pypolar_amd import sharding  # noqa: E402
-from pypolar_amd.construction import frozen_bits  # noqa: E402
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--log2-batch", type=int, default=None, help="codewords per GPU = 2^this (default: BASELINE's 20)")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-traffic", dest="pmc_traffic", action="store_true", default=None,
+                    help="fill roofline.traffic from two rocprofv3 --pmc child passes (default at N = 1 when rocprofv3 "
+                         "is on PATH; adds about a minute)")
+    ap.add_argument("--no-pmc-traffic", dest="pmc_traffic", action="store_false")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="every rank reports its RANK / WORLD_SIZE / LOCAL_RANK and exits before touching the GPU "
+                         "(test of the N > 1 launcher)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks as fresh child processes (this process has not imported
+    torch nor loaded the HIP library yet), wait for them, exit with the first non-zero status."""
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            st = p.poll()
+            if st is None:
+                continue
+            alive.remove(p)
+            if st != 0 and rc == 0:
+                rc = st
+                for q in alive:          # a rank failed: the others would wait in a collective for ever
+                    q.terminate()
+    return rc
+
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+np = torch = pypolar_amd = pdet = sharding = frozen_bits = None
+
+
+def heavy_imports():
+    """numpy / torch / the product's ctypes module: only in a process that is going to be a rank"""
+    global np, torch, pypolar_amd, pdet, sharding, frozen_bits
+    import numpy
+    import torch as _torch
+    sys.path.insert(0, os.path.join(ROOT, "polar-codes_amd"))
+    import pypolar_amd as _pp
+    from pypolar_amd import detector as _pdet
+    from pypolar_amd import sharding as _sh
+    from pypolar_amd.construction import frozen_bits as _fb
+    np, torch, pypolar_amd, pdet, sharding, frozen_bits = numpy, _torch, _pp, _pdet, _sh, _fb
 
 CONFIGS = {
     # SURVEY section 8(d)
@@ -246,11 +306,11 @@ def pmc_traffic(config, log2b, kernel_substr):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         tmp = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
         try:
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", BENCH_PMC_CHILD="1")
             subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable,
                             os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "2", "--warmup", "0",
-                            "--no-cpu-baseline", "--log2-batch", str(log2b)],
-                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=900, check=True)
+                            "--no-cpu-baseline", "--no-pmc-traffic", "--log2-batch", str(log2b)],
+                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=300, check=True)
             vals = []
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
@@ -309,17 +369,24 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(obj) + "\n").encode())
 
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--log2-batch", type=int, default=None, help="codewords per GPU = 2^this (default: BASELINE's 20)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pmc-traffic", action="store_true",
-                    help="also fill roofline.traffic from two rocprofv3 --pmc child passes (N = 1 only; adds about a minute)")
-    args = ap.parse_args()
+    args = parse_args()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        os.dup2(real_stdout, 1)          # the ranks inherit the real stdout: rank 0 writes the JSON line to it
+        sys.exit(self_launch(args))
+    if args.launch_check:
+        info = {"launch_check": True, "rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")),
+                "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "master": os.environ.get("MASTER_ADDR", ""),
+                "gpus": args.gpus}
+        if os.environ.get("BENCH_LAUNCH_CHECK_FAIL_RANK") == str(info["rank"]):
+            sys.exit(3)
+        if info["rank"] == 0:
+            emit(info)
+        return
+    heavy_imports()
+    if args.pmc_traffic is None:  # default: on for the single-GPU run when the profiler is there (and not inside its own child pass)
+        import shutil
+        args.pmc_traffic = args.gpus == 1 and shutil.which("rocprofv3") is not None and not os.environ.get("BENCH_PMC_CHILD")
 
     cfg = dict(CONFIGS[args.config])
     rank = int(os.environ.get("RANK", "0"))
