@@ -386,7 +386,9 @@ def main():
     heavy_imports()
     if args.pmc_traffic is None:  # default: on for the single-GPU run when the profiler is there (and not inside its own child pass)
         import shutil
-        args.pmc_traffic = args.gpus == 1 and shutil.which("rocprofv3") is not None and not os.environ.get("BENCH_PMC_CHILD")
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        args.pmc_traffic = (args.gpus == 1 and shutil.which("rocprofv3") is not None and not profiled
+                            and not os.environ.get("BENCH_PMC_CHILD"))
 
     cfg = dict(CONFIGS[args.config])
     rank = int(os.environ.get("RANK", "0"))

@@ -11,8 +11,11 @@
 // and peeks the final path metrics of SclAvxFloat (scl_avx_float.h: PathList::mMetric).
 //
 // Sub-commands
-//   gen   N K L ctor dsnr crcsize crctype ebn0_db count seed mode dectype out.bin
+//   gen   N K L ctor dsnr crcsize crctype ebn0_db count seed mode dectype out.bin [systematic=1] [input=f32]
 //         (ctor = BB | BE | 5G, or @file with one frozen index per line: hand-made sets, K is then derived)
+//         systematic = 0: setSystematic(false) on encoder and decoder (fastssc_avx_float.cpp:944-948,
+//         scl_avx_float.cpp:731-746); input = i8: the row (rounded to int8 values) goes through the
+//         decode_vector(const char*) overload (decoder.cpp:169-181, bitcontainer.cpp:202-207)
 //         writes a golden fixture (format below).  A FRESH decoder object is used for every
 //         codeword (the reference carries mMetric[0] over between calls).
 //   time  N K L ctor dsnr crcsize crctype ebn0_db rows threads seconds
@@ -40,7 +43,8 @@
 //   u32 hdr[10] = {0x31584650 'PFX1', N, K, L, nF, count, nb=(K+7)/8, crcsize, crcnr, dectype}
 //   u32 F[nF]
 //   count x { f32 llr[N] | u8 info[nb] | u8 out[nb] | u8 ok | u8 npaths | f32 metrics[L] }
-// mode: awgn | noise | ties | quant      dectype: 0 float, 2 mixed
+// mode: awgn | noise | ties | quant      dectype (low byte): 0 float, 2 mixed; bit 8: non-systematic,
+// bit 9: the row was fed as int8 through decode_vector(const char*)
 
 #include <algorithm>
 #include <atomic>
@@ -154,6 +158,8 @@ static int cmd_gen(int argc, char** argv)
     const std::string mode = argv[12];
     c.dectype = (std::string(argv[13]) == "mixed") ? 2 : 0;
     const char* out = argv[14];
+    const bool systematic = argc > 15 ? atoi(argv[15]) != 0 : true;
+    const bool in_i8 = argc > 16 && std::string(argv[16]) == "i8";
     if (!c.ctor.empty() && c.ctor[0] == '@') {  // explicit frozen set: one index per line in the named file
         FILE* ff = fopen(c.ctor.c_str() + 1, "r");
         if (!ff) { perror(c.ctor.c_str() + 1); return 1; }
@@ -168,13 +174,15 @@ static int cmd_gen(int argc, char** argv)
 
     Encoding::ButterflyFipPacked enc(c.N, c.F);
     enc.setErrorDetection(ErrorDetection::create(c.crcsize, c.crctype));
+    enc.setSystematic(systematic);
     Gauss rng(seed);
 
     FILE* f = fopen(out, "wb");
     if (!f) { perror(out); return 1; }
     const bool nr = c.crctype.find("nr") != std::string::npos;
     uint32_t hdr[10] = { 0x31584650u, c.N, c.K, c.L, (uint32_t)c.F.size(), count, nb,
-                         c.crcsize, (uint32_t)nr, (uint32_t)c.dectype };
+                         c.crcsize, (uint32_t)nr,
+                         (uint32_t)c.dectype | (systematic ? 0u : 0x100u) | (in_i8 ? 0x200u : 0u) };
     fwrite(hdr, 4, 10, f);
     fwrite(c.F.data(), 4, c.F.size(), f);
 
@@ -184,8 +192,20 @@ static int cmd_gen(int argc, char** argv)
     for (unsigned r = 0; r < count; ++r) {
         make_row(c, enc, rng, mode, ebn0_db, info, llr);
         std::unique_ptr<Decoding::Decoder> dec(make_decoder(c)); // fresh: metric starts at 0
+        dec->setSystematic(systematic);
         std::vector<uint8_t> outb(nb + 16, 0);
-        const bool ok = dec->decode_vector(llr.data(), outb.data());
+        bool ok;
+        if (in_i8) {  // the fixture keeps the row as (int8-valued) floats
+            std::vector<char> row8(c.N);
+            for (unsigned i = 0; i < c.N; ++i) {
+                const float v = std::max(-127.0f, std::min(127.0f, std::nearbyint(llr[i])));
+                row8[i] = (char)(int)v;
+                llr[i] = (float)(int)v;
+            }
+            ok = dec->decode_vector(row8.data(), outb.data());
+        } else {
+            ok = dec->decode_vector(llr.data(), outb.data());
+        }
         std::vector<float> metrics(c.L, 0.0f);
         uint8_t npaths = 1;
         Decoding::SclAvxFloat* scl = nullptr;

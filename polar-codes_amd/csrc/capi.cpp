@@ -15,6 +15,14 @@
 #include "kernels.h"
 #include "program.h"
 
+// Experiment switches (geometry overrides, fusion stages, ablation, verbose launch geometry) exist only in the
+// diagnostic build (`make diag`, -DPAMD_DIAG): the release library reads no environment variable at all.
+#ifdef PAMD_DIAG
+#define PAMD_ENV(name) std::getenv(name)
+#else
+#define PAMD_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -90,7 +98,12 @@ struct pcd_decoder {
     uint32_t* d_list = nullptr;
     size_t d_list_cap = 0;
     uint32_t* d_count = nullptr;
-    int sc_blocks_per_cu = 0, scl_blocks_per_cu = 0;
+    int sc_blocks_per_cu[2] = { 0, 0 }, scl_blocks_per_cu[2] = { 0, 0 };  // resident workgroups per CU, per kernel variant (fp32 / int8 input)
+    // One stream at a time per handle: the scratch (arena, failed-row list, staging) belongs to the handle, so a call on
+    // another stream first waits for the event recorded behind the previous call's launches.
+    hipEvent_t last_ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
 
     // kernel timing: a ring of HIP event pairs recorded on the launch stream around the kernel(s) of
     // each decode call; resolved lazily by pcd_kernel_times so the timed calls never synchronise
@@ -131,21 +144,21 @@ void compute_geometry(pcd_decoder* d)
     // SC: LLR stages below the root + packed bits per codeword; 64/LC codewords per wave.  The stage right below
     // the root (N/2 floats, half of the LLR memory) is not stored but recomputed from the channel row whenever the
     // root's children are inner nodes or leaves reading through the same accessor (always possible; N >= 16).
-    d->sc_virtual_top = (N >= 16 && !std::getenv("PCD_SC_NO_VIRTUAL")) ? 1u : 0u;
+    d->sc_virtual_top = (N >= 16 && !PAMD_ENV("PCD_SC_NO_VIRTUAL")) ? 1u : 0u;
     d->sc_wave_words = ((d->sc_virtual_top ? N / 2 : N) + bitw + 3) & ~3u;
     d->sc_lcl = N <= 2048 ? 4 : 6;  // 16 lanes per codeword while four codewords still leave >= 9 waves per CU
-    if (const char* e = std::getenv("PCD_SC_LCL")) {  // experiments
+    if (const char* e = PAMD_ENV("PCD_SC_LCL")) {  // experiments
         const int v = std::atoi(e);
         d->sc_lcl = (v == 3 || v == 6) ? v : 4;
     }
     d->sc_s0 = d->logN;
     d->sc_arena_cw_words = 0;
-    if (N >= 2048 && d->sc_virtual_top && !std::getenv("PCD_SC_NO_ARENA") && !std::getenv("PCD_SC_LCL")) {
+    if (N >= 2048 && d->sc_virtual_top && !PAMD_ENV("PCD_SC_NO_ARENA") && !PAMD_ENV("PCD_SC_LCL")) {
         // long blocks: keep 16 lanes per codeword (four codewords per wave) and move the LLR stages from s0 up into a
         // per-codeword arena slice, s0 chosen so that a wave stays within 10 KB of LDS (16 waves per CU)
         unsigned s0 = d->logN - 1;
         while (s0 > 6 && 4u * (((1u << s0) + bitw + 3) & ~3u) * 4u > 10240u) --s0;
-        if (const char* e = std::getenv("PCD_SC_S0")) s0 = (unsigned)std::atoi(e);
+        if (const char* e = PAMD_ENV("PCD_SC_S0")) s0 = std::min(d->logN - 1, std::max(6u, (unsigned)std::atoi(e)));
         d->sc_lcl = 4;
         d->sc_s0 = s0;
         d->sc_wave_words = ((1u << s0) + bitw + 3) & ~3u;
@@ -156,7 +169,7 @@ void compute_geometry(pcd_decoder* d)
     // the LDS cycles were bank conflicts).  With 16 (8) lanes per codeword a stride of 16 (8) mod 32 words spreads the two
     // (four) codewords of a 32-lane LDS pass over all banks.
     // (Not when the extra words cost a resident wave: N = 4096 sits exactly at 10 KB per wave.)
-    if (d->sc_lcl <= 4 && !std::getenv("PCD_SC_NO_SKEW")) {
+    if (d->sc_lcl <= 4 && !PAMD_ENV("PCD_SC_NO_SKEW")) {
         const unsigned want = 1u << d->sc_lcl, cws = 64u >> d->sc_lcl;
         const unsigned skewed = d->sc_wave_words + (want + 32u - d->sc_wave_words % 32u) % 32u;
         if (lds_blocks_per_cu((size_t)skewed * 4 * cws) >= lds_blocks_per_cu((size_t)d->sc_wave_words * 4 * cws))
@@ -164,7 +177,7 @@ void compute_geometry(pcd_decoder* d)
     }
     if (d->has_sc) fuse_sc(d);
     d->sc_wpb = 1;  // single-wave workgroups: LDS granularity of one wave, nothing is shared between waves anyway
-    if (const char* e = std::getenv("PCD_SC_WPB")) d->sc_wpb = (unsigned)std::max(1, std::atoi(e));
+    if (const char* e = PAMD_ENV("PCD_SC_WPB")) d->sc_wpb = (unsigned)std::max(1, std::atoi(e));
     if (d->L > 1) {
         unsigned lprime = 2;  // path groups one codeword needs
         while (lprime < d->L) lprime <<= 1;
@@ -173,7 +186,7 @@ void compute_geometry(pcd_decoder* d)
         // L <= 8: 4 lanes per path x 2 codewords up to N = 2048 (measured at cfg 3: 12.0 -> 15.4 M cw/s against 8 lanes
         // x 1; from N = 4096 on the wide F / G passes dominate and 8 lanes x 1 codeword is 5-10 % faster).
         d->cwl = lprime == 2 ? 2u : (lprime == 4 ? 1u : (lprime == 8 && d->logN <= 11 ? 1u : 0u));
-        if (const char* e = std::getenv("PCD_CWL")) {  // experiments: 0 = one codeword per wave; 1 at L <= 8: 4 lanes per path
+        if (const char* e = PAMD_ENV("PCD_CWL")) {  // experiments: 0 = one codeword per wave; 1 at L <= 8: 4 lanes per path
             const unsigned v = (unsigned)std::atoi(e);
             d->cwl = (lprime == 2 && v <= 2) || (lprime <= 8 && v <= 1) ? v : 0u;
             if (lprime == 2 && v == 1) d->cwl = 0;  // (8 lanes x 2 paths x 2 codewords has no kernel)
@@ -232,8 +245,8 @@ void compute_geometry(pcd_decoder* d)
             best_s0 = hb_s0;
             best_sb = hb_sb;
         }
-        if (const char* dbg = std::getenv("PCD_S0")) best_s0 = (unsigned)std::atoi(dbg);  // experiments
-        if (const char* dbg = std::getenv("PCD_SB")) best_sb = std::max(sb_lo, (unsigned)std::atoi(dbg));
+        if (const char* dbg = PAMD_ENV("PCD_S0")) best_s0 = std::min(d->logN, std::max(lo, (unsigned)std::atoi(dbg)));  // experiments
+        if (const char* dbg = PAMD_ENV("PCD_SB")) best_sb = std::max(sb_lo, (unsigned)std::atoi(dbg));
         if (best_sb > d->logN) best_sb = d->logN + 1;
         d->s0 = best_s0;
         d->sb = best_sb;
@@ -246,7 +259,7 @@ void compute_geometry(pcd_decoder* d)
         d->gbit_left_words = d->sb <= d->logN ? woff(d->logN) + bitw - woff(d->sb) : 0;
         d->gbit_path_words = d->gbit_left_words + (d->sb < d->logN ? woff(d->logN) - woff(d->sb) : 0);
         d->arena_wave_words = (d->arena_bits_off + lmax * d->gbit_path_words + 3u) & ~3u;
-        if (!std::getenv("PCD_NO_SPECIALIZE")) specialize_scl(d);
+        if (!PAMD_ENV("PCD_NO_SPECIALIZE")) specialize_scl(d);
         d->scl_wpb = 1;
     }
 }
@@ -258,7 +271,7 @@ void compute_geometry(pcd_decoder* d)
 // plain LDS stages: not the channel row, not the recomputed stage below the root, not an arena stage.
 void fuse_sc(pcd_decoder* d)
 {
-    if (std::getenv("PCD_NO_FUSE")) return;
+    if (PAMD_ENV("PCD_NO_FUSE")) return;
     auto& v = d->sc_prog.ins;
     auto is_leaf = [](const pamd::Ins& in) { return in.op >= pamd::SC_R0 && in.op <= pamd::SC_ZEROSPC; };
     const unsigned top = d->logN - (d->sc_virtual_top ? 1u : 0u);  // first stage that is not a stored LDS / arena stage
@@ -276,7 +289,7 @@ void fuse_sc(pcd_decoder* d)
             in = leaf;
             ++i;
         }
-        const bool no_c = std::getenv("PCD_NO_FUSE_C") != nullptr;
+        const bool no_c = PAMD_ENV("PCD_NO_FUSE_C") != nullptr;
         // the block this instruction finishes: [coff, coff + 2 ch)
         unsigned coff = in.off, ch = in.stage ? (1u << (in.stage - 1)) : 0u;
         bool finishes = is_leaf(in) || in.op == pamd::SC_COMBINE || in.op == pamd::SC_COMBINE0R || in.op == pamd::SC_RONE;
@@ -304,8 +317,8 @@ void fuse_sc(pcd_decoder* d)
         // The finished block is a left child: the parent's G comes next and can run right here (unless a leaf is about to
         // absorb it, which also spares the LDS round trip of its output).
         unsigned fstage = 0;  // stage of the F / G / G0R whose left descent may follow inside this instruction
-        const bool no_f = std::getenv("PCD_NO_FUSE_F") != nullptr;
-        if (finishes && ch && !no_f && !std::getenv("PCD_NO_FUSE_G") && i + 1 < v.size() && v[i + 1].op == pamd::SC_G &&
+        const bool no_f = PAMD_ENV("PCD_NO_FUSE_F") != nullptr;
+        if (finishes && ch && !no_f && !PAMD_ENV("PCD_NO_FUSE_G") && i + 1 < v.size() && v[i + 1].op == pamd::SC_G &&
             v[i + 1].pad == 0 && v[i + 1].side == 0 && (1u << v[i + 1].stage) == 4 * ch && v[i + 1].off == coff &&
             lds_stage(v[i + 1].stage) &&
             !(i + 2 < v.size() && is_leaf(v[i + 2]) && v[i + 2].stage + 1u == v[i + 1].stage)) {
@@ -339,7 +352,7 @@ void specialize_scl(pcd_decoder* d)
     // inner nodes with at least 64 outputs per path, it is never stored -- the root's F / G only keep their
     // slot-word bookkeeping (flag 2) and the children's F / G recompute their inputs from the channel row
     // (flag 4, +8 for the right child).  Removes the largest arena stage and its HBM-side traffic.
-    if (d->s0 < d->logN && d->logN >= 8 && !std::getenv("PCD_NO_VIRTUAL")) {
+    if (d->s0 < d->logN && d->logN >= 8 && !PAMD_ENV("PCD_NO_VIRTUAL")) {
         bool ok = !d->scl_prog.ins.empty() && d->scl_prog.ins[0].op == pamd::SCL_F && d->scl_prog.ins[0].stage == d->logN;
         for (const auto& in : d->scl_prog.ins)
             if (in.stage == d->logN - 1 && in.op >= pamd::SCL_R0 && in.op <= pamd::SCL_SPC) ok = false;  // leaf child
@@ -363,7 +376,7 @@ void specialize_scl(pcd_decoder* d)
     // path x 2 codewords per wave, i.e. one 16-byte chunk of the 256 outputs per lane.
     // (it stores stages logN-2 / logN-3 to the arena and stage logN-4 to LDS, and reads its bit blocks from the arena)
     if (d->virtual_top && d->lpl == 2 && d->cwl == 1 && d->logN == 10 && d->logN * fb <= 32 && d->s0 == d->logN - 3 &&
-        d->sb <= d->logN - 2 && !std::getenv("PCD_NO_VTOP")) {
+        d->sb <= d->logN - 2 && !PAMD_ENV("PCD_NO_VTOP")) {
         auto& v = d->scl_prog.ins;
         std::vector<pamd::Ins> out;
         out.reserve(v.size());
@@ -407,7 +420,7 @@ void specialize_scl(pcd_decoder* d)
     // stage is read by nobody else).  `F_S R0 G_S leaf`: an all-frozen left sibling only adds to the metric, so it
     // joins the right leaf's prologue.  A right leaf (or a COMBINE) also performs the single-word COMBINEs that
     // follow it directly.  Roughly 40 % of the program's instructions at N = 1024 go away.
-    if ((d->lpl == 2 || d->lpl == 3) && !std::getenv("PCD_NO_FUSE")) {
+    if ((d->lpl == 2 || d->lpl == 3) && !PAMD_ENV("PCD_NO_FUSE")) {
         auto& v = d->scl_prog.ins;
         auto small_leaf = [](const pamd::Ins& in) {
             return in.stage <= 3 &&
@@ -431,7 +444,7 @@ void specialize_scl(pcd_decoder* d)
         for (size_t i = 0; i < out.size(); ++i) {  // R0 left sibling into the right leaf
             if (i + 1 < out.size() && out[i].op == pamd::SCL_R0 && out[i].pad == 1 && out[i + 1].pad == 2 &&
                 out[i + 1].stage == out[i].stage && i + 2 < out.size() && out[i + 2].op == pamd::SCL_C_S &&
-                out[i + 2].stage == out[i].stage + 1u && !std::getenv("PCD_NO_FUSE_R0") && !std::getenv("PCD_NO_FUSE_C")) {
+                out[i + 2].stage == out[i].stage + 1u && !PAMD_ENV("PCD_NO_FUSE_R0") && !PAMD_ENV("PCD_NO_FUSE_C")) {
                 // (the COMBINE right behind the pair is fused below, and knows that the left bits are all zero)
                 pamd::Ins leaf = out[i + 1];
                 leaf.pad = 3;
@@ -445,7 +458,7 @@ void specialize_scl(pcd_decoder* d)
         for (size_t i = 0; i < v.size(); ++i) {  // COMBINE chains
             pamd::Ins head = v[i];
             const bool leaf = small_leaf(head) && d->logN > head.stage;
-            if ((leaf || head.op == pamd::SCL_C_S) && !std::getenv("PCD_NO_FUSE_C")) {
+            if ((leaf || head.op == pamd::SCL_C_S) && !PAMD_ENV("PCD_NO_FUSE_C")) {
                 unsigned top = head.stage, k = 0, fside = head.side & 1u;  // stage of the block held so far
                 if (head.op == pamd::SCL_C_S) k = 1;
                 while (i + 1 < v.size() && v[i + 1].op == pamd::SCL_C_S && v[i + 1].pad == 0 && v[i + 1].stage == top + 1u &&
@@ -457,7 +470,7 @@ void specialize_scl(pcd_decoder* d)
                 }
                 unsigned wide = 0;  // ... and the two-word COMBINE of stage 6 on top of a chain that reached stage 5
                 if (top == 5 && k > 0 && i + 1 < v.size() && v[i + 1].op == pamd::SCL_C_W && v[i + 1].stage == 6 &&
-                    v[i + 1].pad == 0 && !std::getenv("PCD_NO_FUSE_CW")) {
+                    v[i + 1].pad == 0 && !PAMD_ENV("PCD_NO_FUSE_CW")) {
                     fside = v[i + 1].side & 1u;
                     wide = 1;
                     ++i;
@@ -471,7 +484,7 @@ void specialize_scl(pcd_decoder* d)
     }
     // All-frozen left child of a small inner node: `F_S R0 G_S` (or `R0 G_S` with the F_S already inside the R0) is
     // one step -- the metric takes the sum over min(f, 0) and the right child's input is a + b.
-    if (!std::getenv("PCD_NO_FUSE") && !std::getenv("PCD_NO_FUSE_G0")) {
+    if (!PAMD_ENV("PCD_NO_FUSE") && !PAMD_ENV("PCD_NO_FUSE_G0")) {
         auto& v = d->scl_prog.ins;
         std::vector<pamd::Ins> out;
         out.reserve(v.size());
@@ -496,7 +509,7 @@ void specialize_scl(pcd_decoder* d)
         v.swap(out);
     }
     // `X_S(4) [F_S(3) leaf(2)]`: the leaf's lanes hold exactly the stage-3 pairs its F needs, so the op in front joins too
-    if (d->lpl == 2 && !std::getenv("PCD_NO_FUSE") && !std::getenv("PCD_NO_FUSE_GRAND")) {
+    if (d->lpl == 2 && !PAMD_ENV("PCD_NO_FUSE") && !PAMD_ENV("PCD_NO_FUSE_GRAND")) {
         auto& v = d->scl_prog.ins;
         std::vector<pamd::Ins> out;
         out.reserve(v.size());
@@ -518,7 +531,7 @@ void specialize_scl(pcd_decoder* d)
     }
 }
 
-int ensure_device(pcd_decoder* d)
+int ensure_device(pcd_decoder* d, pamd::DeviceScope& scope)
 {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -526,7 +539,7 @@ int ensure_device(pcd_decoder* d)
         return fail(PCD_ERR_NO_DEVICE,
                     "no HIP device available: the decoder runs on the GPU only (there is no CPU fallback)");
     if (d->device < 0 || d->device >= count) return fail(PCD_ERR_NO_DEVICE, "invalid HIP device ordinal");
-    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(scope.enter(d->device));
     if (!d->dev_ready) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, d->device));
@@ -587,7 +600,7 @@ pamd::DecodeParams base_params(const pcd_decoder* d, const void* llr, size_t row
     P.metrics = metrics;
     P.det_on = d->det.size != 0;
     P.systematic = d->systematic ? 1u : 0u;
-    if (const char* ab = std::getenv("PCD_ABLATE")) P.ablate = (uint32_t)std::atoi(ab);
+    if (const char* ab = PAMD_ENV("PCD_ABLATE")) P.ablate = (uint32_t)std::atoi(ab);
     return P;
 }
 
@@ -602,16 +615,19 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     P.prog_root_g0r = (!d->sc_prog.ins.empty() && d->sc_prog.ins[0].op == pamd::SC_G0R) ? 1u : 0u;
     const unsigned cw_per_wave = 64u >> d->sc_lcl;
     const size_t lds = (size_t)d->sc_wpb * cw_per_wave * d->sc_wave_words * 4;
-    if (d->sc_blocks_per_cu == 0) {  // resident workgroups per CU: the grid is sized to exactly fill the chip
+    int& sc_bpc = d->sc_blocks_per_cu[i8 ? 1 : 0];
+    if (sc_bpc == 0) {  // resident workgroups per CU: the grid is sized to exactly fill the chip
         int occ = 0;
-        HIP_TRY(pamd::launch_sc(P, d->sc_lcl, i8, 1, d->sc_wpb, lds, st, &occ));
-        d->sc_blocks_per_cu = std::max(1, std::min(occ, (int)lds_blocks_per_cu(lds)));
-        if (std::getenv("PCD_VERBOSE"))
+        pamd::DecodeParams Q = P;
+        Q.cycles = nullptr;  // (the query is about the production kernel, whatever this call is)
+        HIP_TRY(pamd::launch_sc(Q, d->sc_lcl, i8, 1, d->sc_wpb, lds, st, &occ));
+        sc_bpc = std::max(1, std::min(occ, (int)lds_blocks_per_cu(lds)));
+        if (PAMD_ENV("PCD_VERBOSE"))
             std::fprintf(stderr, "[pcd] sc: %u codewords/wave, lds=%zu B/workgroup, occupancy=%d blocks/CU\n", cw_per_wave, lds, occ);
     }
     const unsigned cw_per_block = d->sc_wpb * cw_per_wave;
     const unsigned need = (unsigned)((P.rows + cw_per_block - 1) / cw_per_block);
-    const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->sc_blocks_per_cu)));
+    const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * sc_bpc)));
     if (d->sc_arena_cw_words) {
         int rc = grow(d->d_arena, d->d_arena_cap, (size_t)grid * d->sc_wpb * cw_per_wave * d->sc_arena_cw_words * sizeof(float));
         if (rc) return rc;
@@ -637,16 +653,21 @@ int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     P.gbit_left_words = d->gbit_left_words;
     P.gbit_path_words = d->gbit_path_words;
     const size_t lds = (size_t)d->scl_wpb * d->scl_wave_words * 4;
-    if (d->scl_blocks_per_cu == 0) {  // resident workgroups per CU (LDS and VGPR limited)
+    int& scl_bpc = d->scl_blocks_per_cu[i8 ? 1 : 0];
+    if (scl_bpc == 0) {  // resident workgroups per CU (LDS and VGPR limited)
         int occ = 0;
-        HIP_TRY(pamd::launch_scl(P, d->lpl, i8, 1, d->scl_wpb, lds, st, &occ));
-        d->scl_blocks_per_cu = std::max(1, std::min(occ, (int)lds_blocks_per_cu(lds)));
-        if (const char* e = std::getenv("PCD_BLOCKS_PER_CU")) d->scl_blocks_per_cu = std::max(1, std::atoi(e));  // experiments
-        if (std::getenv("PCD_VERBOSE")) std::fprintf(stderr, "[pcd] scl: %u lanes/path x %u codewords/wave, s0=%u sb=%u lds=%zu B occupancy=%d -> %d blocks/CU\n", 64u / d->lmax, 1u << d->cwl, d->s0, d->sb, lds, occ, d->scl_blocks_per_cu);
+        pamd::DecodeParams Q = P;
+        Q.trace = nullptr;
+        Q.cycles = nullptr;
+        Q.ablate = 0;
+        HIP_TRY(pamd::launch_scl(Q, d->lpl, i8, 1, d->scl_wpb, lds, st, &occ));
+        scl_bpc = std::max(1, std::min(occ, (int)lds_blocks_per_cu(lds)));
+        if (const char* e = PAMD_ENV("PCD_BLOCKS_PER_CU")) scl_bpc = std::max(1, std::min(64, std::atoi(e)));  // experiments
+        if (PAMD_ENV("PCD_VERBOSE")) std::fprintf(stderr, "[pcd] scl: %u lanes/path x %u codewords/wave, s0=%u sb=%u lds=%zu B occupancy=%d -> %d blocks/CU\n", 64u / d->lmax, 1u << d->cwl, d->s0, d->sb, lds, occ, scl_bpc);
     }
     const unsigned cw_per_block = d->scl_wpb << d->cwl;
     const unsigned need = (unsigned)((P.rows + cw_per_block - 1) / cw_per_block);
-    const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * d->scl_blocks_per_cu)));
+    const unsigned grid = std::max(1u, std::min(need, (unsigned)(d->num_cu * scl_bpc)));
     if (d->arena_wave_words) {
         int rc = grow(d->d_arena, d->d_arena_cap, (size_t)grid * d->scl_wpb * d->arena_wave_words * sizeof(float));
         if (rc) return rc;
@@ -663,6 +684,7 @@ int decode_device(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t
     if (rows == 0) return PCD_OK;
     if (rows > 0xFFFFFFFFull) return fail(PCD_ERR_INVALID_ARG, "rows must fit in 32 bits");
     int rc;
+    if (d->has_last && d->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, d->last_ev, 0));
     const bool timed = d->timing && d->ev_count < kTimingSlots;
     if (timed) {
         if (d->ev.empty()) {
@@ -702,6 +724,10 @@ int decode_device(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t
         HIP_TRY(hipEventRecord(d->ev[2 * d->ev_count + 1], st));
         d->ev_count++;
     }
+    if (!d->last_ev) HIP_TRY(hipEventCreateWithFlags(&d->last_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(d->last_ev, st));
+    d->last_stream = st;
+    d->has_last = true;
     return PCD_OK;
 }
 
@@ -713,11 +739,12 @@ int decode_any(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t* o
     if (d->det.size != 0 && d->nb < d->det.check_bytes())
         return fail(PCD_ERR_INVALID_ARG, "information word shorter than the detector's checksum field");
     if (d->det.size == 32 && d->nb < 4) return fail(PCD_ERR_INVALID_ARG, "CRC-32 needs at least 4 output bytes");
-    int rc = ensure_device(d);
+    pamd::DeviceScope scope;
+    int rc = ensure_device(d, scope);
     if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (mem == PCD_MEM_DEVICE) return decode_device(d, llr, i8, rows, out, ok, metrics, st);
-    if (mem != PCD_MEM_HOST) return fail(PCD_ERR_INVALID_ARG, "mem must be PCD_MEM_HOST or PCD_MEM_DEVICE");
+    if (mem != PCD_MEM_HOST) return fail(PCD_ERR_INVALID_ARG, "mem must be 0 (host pointers) or 1 (device pointers)");
     // host pointers: stage through device buffers, synchronous
     const size_t esz = i8 ? 1 : 4;
     const size_t in_bytes = rows * d->N * esz, out_bytes = rows * d->nb;
@@ -834,7 +861,8 @@ void pcd_destroy(pcd_decoder* d)
 {
     if (!d) return;
     if (d->dev_ready) {
-        (void)hipSetDevice(d->device);
+        pamd::DeviceScope scope;
+        (void)scope.enter(d->device);
         (void)hipFree(d->d_sc_prog);
         (void)hipFree(d->d_scl_prog);
         (void)hipFree(d->d_lut);
@@ -842,6 +870,7 @@ void pcd_destroy(pcd_decoder* d)
         (void)hipFree(d->d_count);
         for (auto e : d->ev)
             if (e) (void)hipEventDestroy(e);
+        if (d->last_ev) (void)hipEventDestroy(d->last_ev);
     }
     if (d->d_in) (void)hipFree(d->d_in);
     if (d->d_out) (void)hipFree(d->d_out);
@@ -954,9 +983,13 @@ int pcd_kernel_times(pcd_decoder* d, float* ms, size_t cap, size_t* count)
 
 int pcd_scl_trace(pcd_decoder* d, const float* llr_row, float* trace, unsigned cap)
 {
+#ifndef PAMD_DIAG
+    return fail(PCD_ERR_UNSUPPORTED, "diagnostics (trace / cycle profile) exist in the diagnostic build only: make -C polar-codes_amd diag");
+#else
     if (!d || !llr_row || !trace) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "not a list decoder");
-    int rc = ensure_device(d);
+    pamd::DeviceScope scope;
+    int rc = ensure_device(d, scope);
     if (rc) return rc;
     float* dtrace = nullptr;
     const size_t tb = (size_t)cap * (1 + d->L) * sizeof(float);
@@ -975,14 +1008,19 @@ int pcd_scl_trace(pcd_decoder* d, const float* llr_row, float* trace, unsigned c
     }
     (void)hipFree(dtrace);
     return rc;
+#endif
 }
 
 int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
                     unsigned cap, unsigned* count)
 {
+#ifndef PAMD_DIAG
+    return fail(PCD_ERR_UNSUPPORTED, "diagnostics (trace / cycle profile) exist in the diagnostic build only: make -C polar-codes_amd diag");
+#else
     if (!d || !llr_row || !cycles || !count) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "not a list decoder");
-    int rc = ensure_device(d);
+    pamd::DeviceScope scope;
+    int rc = ensure_device(d, scope);
     if (rc) return rc;
     const unsigned n = (unsigned)d->scl_prog.ins.size();
     *count = n;
@@ -1000,7 +1038,7 @@ int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t*
         HIP_TRY(hipDeviceSynchronize());
         std::vector<uint32_t> h((size_t)n * 5);
         HIP_TRY(hipMemcpy(h.data(), dcyc, (size_t)n * 5 * 4, hipMemcpyDeviceToHost));
-        if (const char* dump = std::getenv("PCD_SUBPROFILE")) {  // leaf phase stamps (diagnostics)
+        if (const char* dump = PAMD_ENV("PCD_SUBPROFILE")) {  // leaf phase stamps (diagnostics)
             if (FILE* f = std::fopen(dump, "w")) {
                 for (unsigned i = 0; i < n; ++i)
                     std::fprintf(f, "%u %u %u %u %u %u %u\n", (unsigned)d->scl_prog.ins[i].op, (unsigned)d->scl_prog.ins[i].stage,
@@ -1016,16 +1054,21 @@ int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t*
     }
     (void)hipFree(dcyc);
     return rc;
+#endif
 }
 
 int pcd_sc_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
                    unsigned cap, unsigned* count)
 {
+#ifndef PAMD_DIAG
+    return fail(PCD_ERR_UNSUPPORTED, "diagnostics (trace / cycle profile) exist in the diagnostic build only: make -C polar-codes_amd diag");
+#else
     if (!d || !llr_row || !cycles || !count) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
     if (d->sc_lcl != 4 || d->sc_arena_cw_words)
         return fail(PCD_ERR_UNSUPPORTED, "the SC cycle profile exists for the all-LDS kernel (N <= 1024) only");
-    int rc = ensure_device(d);
+    pamd::DeviceScope scope;
+    int rc = ensure_device(d, scope);
     if (rc) return rc;
     const unsigned n = (unsigned)d->sc_prog.ins.size();
     *count = n;
@@ -1051,6 +1094,7 @@ int pcd_sc_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* 
     }
     (void)hipFree(dcyc);
     return rc;
+#endif
 }
 
 const char* pcd_last_error(void) { return g_err.c_str(); }

@@ -58,13 +58,13 @@ int grow(T*& p, size_t& cap, size_t bytes)
     return PCD_OK;
 }
 
-int ensure_device(pce_encoder* e)
+int ensure_device(pce_encoder* e, pamd::DeviceScope& scope)
 {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return set_error(PCD_ERR_NO_DEVICE, "no HIP device: the encoder has no CPU fallback");
     if (e->device < 0 || e->device >= count) return set_error(PCD_ERR_NO_DEVICE, "HIP device ordinal out of range");
-    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(scope.enter(e->device));
     if (!e->dev_ready) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, e->device));
@@ -181,7 +181,8 @@ void pce_destroy(pce_encoder* e)
 {
     if (!e) return;
     if (e->dev_ready || e->d_gen || e->d_info || e->d_code) {
-        (void)hipSetDevice(e->device);
+        pamd::DeviceScope scope;
+        (void)scope.enter(e->device);
         (void)hipFree(e->d_dep);
         (void)hipFree(e->d_gen);
         (void)hipFree(e->d_info);
@@ -236,11 +237,12 @@ int pce_encode(pce_encoder* e, uint8_t* info, size_t rows, uint8_t* code, int me
     if (e->det.size != 0 && e->nb < e->det.check_bytes())
         return set_error(PCD_ERR_INVALID_ARG, "information word shorter than the detector's checksum field");
     if (e->det.size == 32 && e->nb < 4) return set_error(PCD_ERR_INVALID_ARG, "CRC-32 needs at least 4 information bytes");
-    int rc = ensure_device(e);
+    pamd::DeviceScope scope;
+    int rc = ensure_device(e, scope);
     if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (mem == PCD_MEM_DEVICE) return encode_device(e, info, rows, code, st);
-    if (mem != PCD_MEM_HOST) return set_error(PCD_ERR_INVALID_ARG, "mem must be PCD_MEM_HOST or PCD_MEM_DEVICE");
+    if (mem != PCD_MEM_HOST) return set_error(PCD_ERR_INVALID_ARG, "mem must be 0 (host pointers) or 1 (device pointers)");
     const size_t in_bytes = rows * e->nb, out_bytes = rows * (e->N / 8);
     if ((rc = grow(e->d_info, e->d_info_cap, in_bytes))) return rc;
     if ((rc = grow(e->d_code, e->d_code_cap, out_bytes))) return rc;

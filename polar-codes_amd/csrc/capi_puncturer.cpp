@@ -49,13 +49,13 @@ int grow(void*& p, size_t& cap, size_t bytes)
     return PCD_OK;
 }
 
-int ensure_device(ppu_puncturer* u)
+int ensure_device(ppu_puncturer* u, pamd::DeviceScope& scope)
 {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return set_error(PCD_ERR_NO_DEVICE, "no HIP device: the puncturer has no CPU fallback");
     if (u->device < 0 || u->device >= count) return set_error(PCD_ERR_NO_DEVICE, "HIP device ordinal out of range");
-    HIP_TRY(hipSetDevice(u->device));
+    HIP_TRY(scope.enter(u->device));
     if (!u->dev_ready) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, u->device));
@@ -78,7 +78,8 @@ int run(ppu_puncturer* u, int op, const void* in, size_t rows, void* out, unsign
     if (rows && (!in || !out)) return set_error(PCD_ERR_INVALID_ARG, "null input/output pointer");
     if (rows > 0xFFFFFFFFull) return set_error(PCD_ERR_INVALID_ARG, "rows must fit in 32 bits");
     if (op == 2 && (u->M % 8 || u->N % 8)) return set_error(PCD_ERR_INVALID_ARG, "packed puncturing needs block lengths that are multiples of 8");
-    int rc = ensure_device(u);
+    pamd::DeviceScope scope;
+    int rc = ensure_device(u, scope);
     if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t in_cols = op == 1 ? u->M : u->N, out_cols = op == 1 ? u->N : u->M;
@@ -93,7 +94,7 @@ int run(ppu_puncturer* u, int op, const void* in, size_t rows, void* out, unsign
         din = u->d_in;
         dout = u->d_out;
     } else if (mem != PCD_MEM_DEVICE) {
-        return set_error(PCD_ERR_INVALID_ARG, "mem must be PCD_MEM_HOST or PCD_MEM_DEVICE");
+        return set_error(PCD_ERR_INVALID_ARG, "mem must be 0 (host pointers) or 1 (device pointers)");
     }
     const unsigned grid = (unsigned)std::min<size_t>(rows ? (rows + 1) / 2 : 1, (size_t)u->num_cu * 4);  // (measured: 4 workgroups per CU 64 % of the HBM roofline, 8 58 %, 32 61 %)
     if (op == 2)
@@ -149,7 +150,8 @@ void ppu_destroy(ppu_puncturer* u)
 {
     if (!u) return;
     if (u->dev_ready || u->d_in || u->d_out) {
-        (void)hipSetDevice(u->device);
+        pamd::DeviceScope scope;
+        (void)scope.enter(u->device);
         (void)hipFree(u->d_pos);
         (void)hipFree(u->d_inv);
         (void)hipFree(u->d_in);

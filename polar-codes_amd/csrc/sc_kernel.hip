@@ -646,12 +646,18 @@ hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, uns
         }
         return hipGetLastError();
     }
-    if (lcl == 4 && P.cycles && !i8) {  // per-instruction cycle stamps (diagnostics)
+#ifdef PAMD_DIAG
+    if (lcl == 4 && P.cycles && !i8) {  // per-instruction cycle stamps (diagnostic build only)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // (an occupancy query must not launch: the caller caches the answer as the grid size of every later call)
+        if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, sc_decode_kernel<4, false, true>, (int)b.x, lds);
         hipLaunchKernelGGL((sc_decode_kernel<4, false, true>), g, b, lds, st, P);
         return hipGetLastError();
     }
+#else
+    if (P.cycles) return hipErrorInvalidValue;
+#endif
     if (lcl == 4 && P.logN >= 10) {  // (N = 1024 without arena: the two-deep variant)
         if (i8) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_decode_kernel<4, true, false, false, true>),

@@ -2254,11 +2254,15 @@ static hipError_t launch_scl_t(const DecodeParams& P, bool i8, bool diag, dim3 g
     constexpr unsigned fb = 6u - LPL - CWL;    // bits per slot field
     const bool slot64 = P.logN * fb > 32u;
     const bool hb = P.sb <= P.logN;            // high-stage bit blocks in the arena
+#ifdef PAMD_DIAG
     if (diag && !i8) {  // (diagnostic variant: the slot word of the production kernel where it exists)
         constexpr bool DS64 = fb > 3;
         if (slot64 && !DS64) return hipErrorInvalidValue;
         return launch_scl_k<LPL, false, DS64, true, true, CWL>(P, grid, block, lds, st, occ);
     }
+#else
+    if (diag) return hipErrorInvalidValue;  // (trace / cycle stamps / ablation: diagnostic build only)
+#endif
     if constexpr (fb <= 3) {
         if (!slot64 && !hb)
             return i8 ? launch_scl_k<LPL, true, false, false, false, CWL>(P, grid, block, lds, st, occ)

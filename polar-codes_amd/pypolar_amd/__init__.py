@@ -182,6 +182,33 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
 
 
+def _check_device(t, device, what):
+    """a CUDA tensor handed over as raw pointers must live on the GPU the handle was created for: the library
+    launches on that device, and a pointer of another GPU would fault or silently go through peer access"""
+    idx = t.device.index
+    if idx is None:
+        import torch
+        idx = torch.cuda.current_device()
+    if idx != device:
+        raise ValueError(f"{what} is on cuda:{idx} but this object was created for device {device}")
+
+
+def _check_out(t, shape, dtype, like, what):
+    """caller-supplied output tensors are written through raw pointers: exact shape, dtype, contiguity, device"""
+    if not _is_torch(t) or not t.is_cuda:
+        raise ValueError(f"{what} must be a CUDA tensor")
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.device != like.device:
+        raise ValueError(f"{what} must be a contiguous {dtype} tensor of shape {tuple(shape)} on {like.device}")
+
+
+def _foreign_stream(t_list, stream):
+    """temporaries made on torch's current stream but consumed on a caller-given stream stay alive for that stream"""
+    import torch
+    for t in t_list:
+        if t is not None:
+            t.record_stream(torch.cuda.ExternalStream(stream, device=t.device))
+
+
 class PolarDecoder:
     """``pypolar.PolarDecoder(blockLength, listSize, frozenBitPositions, decoderType)``."""
 
@@ -195,6 +222,7 @@ class PolarDecoder:
             self._h = None
             _raise(rc)
         self._lib = lib
+        self._device = int(device)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -291,6 +319,8 @@ class PolarDecoder:
         if not llr.is_cuda:
             res = self.decode_batch(llr.numpy(), want_metrics)
             return tuple(torch.from_numpy(np.ascontiguousarray(r)) for r in res)
+        _check_device(llr, self._device, "llr")
+        src = llr
         i8 = llr.dtype == torch.int8
         if not i8 and llr.dtype != torch.float32:
             llr = llr.float()
@@ -302,12 +332,20 @@ class PolarDecoder:
         L = max(1, self.listSize())
         if out is None:
             out = torch.empty((B, nb), dtype=torch.uint8, device=llr.device)
+        else:
+            _check_out(out, (B, nb), torch.uint8, llr, "out")
         if ok is None:
             ok = torch.empty((B,), dtype=torch.uint8, device=llr.device)
+        else:
+            _check_out(ok, (B,), torch.uint8, llr, "ok")
         if want_metrics and metrics is None:
             metrics = torch.empty((B, L), dtype=torch.float32, device=llr.device)
+        elif want_metrics:
+            _check_out(metrics, (B, L), torch.float32, llr, "metrics")
         if stream is None:
             stream = torch.cuda.current_stream(llr.device).cuda_stream
+        elif llr is not src:
+            _foreign_stream([llr], stream)
         fn = self._lib.pcd_decode_i8 if i8 else self._lib.pcd_decode_f32
         rc = fn(self._h, C.c_void_p(llr.data_ptr()), B, C.c_void_p(out.data_ptr()), C.c_void_p(ok.data_ptr()),
                 C.c_void_p(metrics.data_ptr()) if want_metrics else None, PCD_MEM_DEVICE, C.c_void_p(stream))
@@ -390,6 +428,7 @@ class PolarEncoder:
         lib = load_library()
         frozen = np.ascontiguousarray(np.asarray(frozenBitPositions, dtype=np.int64).astype(np.uint32))
         self._h = C.c_void_p()
+        self._device = int(device)
         rc = lib.pce_create(int(blockLength), frozen.ctypes.data_as(C.c_void_p), frozen.size, int(device),
                             C.byref(self._h))
         if rc:
@@ -468,6 +507,8 @@ class PolarEncoder:
 
             if not info.is_cuda:
                 return torch.from_numpy(self.encode_batch(info.numpy()))
+            _check_device(info, self._device, "info")
+            src = info
             if info.dtype != torch.uint8 or not info.is_contiguous():
                 info = info.to(torch.uint8).contiguous()
             if info.dim() != 2 or info.shape[1] != nb:
@@ -475,8 +516,12 @@ class PolarEncoder:
             B = info.shape[0]
             if out is None:
                 out = torch.empty((B, self.blockLength() // 8), dtype=torch.uint8, device=info.device)
+            else:
+                _check_out(out, (B, self.blockLength() // 8), torch.uint8, info, "out")
             if stream is None:
                 stream = torch.cuda.current_stream(info.device).cuda_stream
+            elif info is not src:
+                _foreign_stream([info], stream)
             rc = self._lib.pce_encode(self._h, C.c_void_p(info.data_ptr()), B, C.c_void_p(out.data_ptr()),
                                       PCD_MEM_DEVICE, C.c_void_p(stream))
             if rc:
@@ -509,6 +554,7 @@ class Puncturer:
         lib = load_library()
         frozen = np.ascontiguousarray(np.asarray(frozenBitPositions, dtype=np.int64).astype(np.uint32))
         self._h = C.c_void_p()
+        self._device = int(device)
         rc = lib.ppu_create(int(blockLength), frozen.ctypes.data_as(C.c_void_p), frozen.size, int(device), C.byref(self._h))
         if rc:
             self._h = None
@@ -584,6 +630,8 @@ class Puncturer:
 
             if not x.is_cuda:
                 return torch.from_numpy(self._batch(fn, x.numpy(), in_cols, out_cols, None, None))
+            _check_device(x, self._device, "the input")
+            src = x
             if x.dtype not in (torch.float64, torch.float32, torch.uint8):
                 x = x.double()
             x = x.contiguous()
@@ -591,8 +639,12 @@ class Puncturer:
                 raise ValueError(f"expected shape [B, {in_cols}]")
             if out is None:
                 out = torch.empty((x.shape[0], out_cols), dtype=x.dtype, device=x.device)
+            else:
+                _check_out(out, (x.shape[0], out_cols), x.dtype, x, "out")
             if stream is None:
                 stream = torch.cuda.current_stream(x.device).cuda_stream
+            elif x is not src:
+                _foreign_stream([x], stream)
             rc = fn(self._h, C.c_void_p(x.data_ptr()), x.shape[0], C.c_void_p(out.data_ptr()), x.element_size(),
                     PCD_MEM_DEVICE, C.c_void_p(stream))
             if rc:
@@ -617,13 +669,19 @@ class Puncturer:
         if _is_torch(x) and x.is_cuda:
             import torch
 
+            _check_device(x, self._device, "the input")
+            src = x
             x = x.to(torch.uint8).contiguous()
             if x.dim() != 2 or x.shape[1] != nin:
                 raise ValueError(f"expected shape [B, {nin}]")
             if out is None:
                 out = torch.empty((x.shape[0], nout), dtype=torch.uint8, device=x.device)
+            else:
+                _check_out(out, (x.shape[0], nout), torch.uint8, x, "out")
             if stream is None:
                 stream = torch.cuda.current_stream(x.device).cuda_stream
+            elif x is not src:
+                _foreign_stream([x], stream)
             rc = self._lib.ppu_puncture_packed(self._h, C.c_void_p(x.data_ptr()), x.shape[0], C.c_void_p(out.data_ptr()),
                                                PCD_MEM_DEVICE, C.c_void_p(stream))
             if rc:

@@ -23,13 +23,15 @@ class Fixture:
     frozen: np.ndarray      # uint32[nF], ascending
     crc_size: int
     crc_nr: bool
-    dectype: str            # "float" | "mixed"
+    dectype: str            # "float" | "mixed" | "char"
     llr: np.ndarray         # float32[count, N]
     info: np.ndarray        # uint8[count, nb]   payload incl. checksum, as encoded
     out: np.ndarray         # uint8[count, nb]   the reference decoder's output
     ok: np.ndarray          # uint8[count]
     npaths: np.ndarray      # uint8[count]
     metrics: np.ndarray     # float32[count, L]  reference path metrics, best first
+    systematic: bool = True  # False: setSystematic(false) on encoder and decoder
+    i8_input: bool = False   # True: the (int8-valued) row went through decode_vector(const char*)
 
     @property
     def count(self):
@@ -61,9 +63,9 @@ def load(path):
         ok = body[:, o].copy(); o += 1
         npaths = body[:, o].copy(); o += 1
         metrics = body[:, o:o + 4 * L].copy().view(np.float32).reshape(count, L)
-        out.append(Fixture(f"{base}#{idx}", N, K, L, frozen, crcsize, bool(crcnr),
-                           "mixed" if dectype == 2 else "float", llr, info, outb, ok, npaths,
-                           metrics))
+        kind = {0: "float", 2: "mixed", 3: "char"}[dectype & 0xFF]
+        out.append(Fixture(f"{base}#{idx}", N, K, L, frozen, crcsize, bool(crcnr), kind, llr, info, outb, ok, npaths,
+                           metrics, systematic=not (dectype & 0x100), i8_input=bool(dectype & 0x200)))
         idx += 1
     return out
 

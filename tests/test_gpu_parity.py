@@ -22,7 +22,13 @@ def _decoder(fx, device=0):
     import pypolar_amd
     d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, fx.dectype, device=device)
     d.setErrorDetection(fx.crc_size, fx.crc_type)
+    d.setSystematic(fx.systematic)
     return d
+
+
+def _rows(fx):
+    """the fixture's rows as the reference received them: float32, or int8 through decode_vector(const char*)"""
+    return fx.llr.astype(np.int8) if fx.i8_input else fx.llr
 
 
 def _check_metrics(got, ref, npaths, name):
@@ -37,7 +43,7 @@ def test_hip_matches_reference_vectors(built_library, path):
     for fx in gio.load(path):
         d = _decoder(fx)
         want_m = fx.L > 1 and fx.dectype == "float"
-        res = d.decode_batch(fx.llr, return_metrics=want_m)
+        res = d.decode_batch(_rows(fx), return_metrics=want_m)
         assert np.array_equal(res[0], fx.out), fx.name
         assert np.array_equal(res[1].astype(np.uint8), fx.ok), fx.name
         if want_m:
@@ -427,41 +433,40 @@ def test_mixed_decoder_grid(built_library, N, L):
 
 
 FUSE_SWITCHES = ["PCD_NO_FUSE", "PCD_NO_FUSE_C", "PCD_NO_FUSE_R0", "PCD_NO_FUSE_G0", "PCD_NO_FUSE_GRAND", "PCD_NO_FUSE_CW",
-                 "PCD_NO_FUSE_F", "PCD_NO_FUSE_G", "PCD_SC_NO_SKEW"]
+                 "PCD_NO_FUSE_F", "PCD_NO_FUSE_G", "PCD_SC_NO_SKEW", "PCD_NO_VTOP", "PCD_NO_VIRTUAL"]
 
 
 @pytest.mark.parametrize("switch", FUSE_SWITCHES)
-def test_fused_and_unfused_programs_agree(built_library, switch, monkeypatch):
+def test_fused_and_unfused_programs_agree(built_library, switch):
     """The host rewrites the decoders' instruction lists (capi.cpp: specialize_scl -- leaf prologues, COMBINE chains,
-    G0_S; fuse_sc -- leaf prologues / epilogues, COMBINE chains, tail G, left-descent F runs); every stage of that
-    rewrite can be switched off when the decoder is created.  All variants must reproduce the reference's vectors --
-    SC, 4 lanes per path (L = 8), 8 lanes per path (L = 2, 4) and random frozen sets."""
-    names = ["cfg3_n1024_k512_l8_crc24_awgn.bin", "cfg3_n1024_k512_l8_crc24_ties.bin", "cfg4_n1024_k176_l8_crc11_awgn.bin",
-             "mix_n256_k128_l4_crc8_awgn.bin", "sweep_n512.bin", "cfg2_n1024_k512_sc_awgn.bin", "cfg2_n1024_k512_sc_ties.bin",
-             "sweep_n2048.bin", "cfg1_n64_k40_sc_awgn.bin"]
-    monkeypatch.setenv(switch, "1")
-    for name in names:
-        for fx in gio.load(os.path.join(gio.GOLDEN_DIR, name)):
-            if fx.dectype != "float":
-                continue
-            res = _decoder(fx).decode_batch(fx.llr, return_metrics=fx.L > 1)
-            assert np.array_equal(res[0], fx.out), (switch, fx.name)
-            assert np.array_equal(res[1].astype(np.uint8), fx.ok), (switch, fx.name)
-            if fx.L > 1:
-                _check_metrics(res[2], fx.metrics, fx.npaths, fx.name)
-    rng = np.random.default_rng(5)
-    for N, L in [(256, 2), (256, 4), (512, 8), (128, 8), (256, 1), (2048, 1)]:
-        K = N // 2
-        frozen = np.sort(rng.choice(N, N - K, replace=False)).astype(np.uint32)
-        llr = (rng.standard_normal((48, N)) * 2.0 + 1.0).astype(np.float32)
-        try:
-            e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, 8, llr, True, "float")
-        except ValueError:
-            continue  # (a frozen set the reference's tree builder refuses)
-        import pypolar_amd
-        d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
-        d.setErrorDetection(8, "crc")
-        res = d.decode_batch(llr, return_metrics=L > 1)
-        assert np.array_equal(res[0], e_out) and np.array_equal(res[1].astype(np.uint8), e_ok), (switch, N, L)
-        if L > 1:
-            assert np.allclose(res[2], e_met, rtol=METRIC_RTOL, atol=0), (switch, N, L)
+    G0_S, SCL_VTOP; fuse_sc -- leaf prologues / epilogues, COMBINE chains, tail G, left-descent F runs); every stage of
+    that rewrite can be switched off in the DIAGNOSTIC build of the library (`make diag`: the release library reads no
+    environment variable).  All variants must reproduce the reference's vectors -- SC, 4 lanes per path (L = 8),
+    8 lanes per path (L = 2, 4) and random frozen sets.  One child process per switch (tests/diag_fuse_check.py) loads
+    the diagnostic library; the release library of this process is untouched."""
+    import subprocess
+    import sys
+    import pypolar_amd
+    diag = os.path.join(os.path.dirname(pypolar_amd.library_path()), "libpolar_amd_diag.so")
+    if not os.path.exists(diag):
+        subprocess.check_call(["make", "-C", os.path.dirname(os.path.dirname(diag)), "diag"])
+    env = dict(os.environ, PYPOLAR_AMD_LIB=diag)
+    env[switch] = "1"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag_fuse_check.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (switch, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_release_library_reads_no_environment(built_library, monkeypatch):
+    """a stray experiment variable must not change (let alone break) the shipped decoder"""
+    monkeypatch.setenv("PCD_ABLATE", "255")
+    monkeypatch.setenv("PCD_NO_FUSE", "1")
+    monkeypatch.setenv("PCD_S0", "3")
+    fx = gio.load_named("cfg3_n1024_k512_l8_crc24_awgn.bin")
+    res = _decoder(fx).decode_batch(fx.llr[:16])
+    assert np.array_equal(res[0], fx.out[:16])
+    import pypolar_amd
+    with open(pypolar_amd.library_path(), "rb") as f:
+        assert b"PCD_" not in f.read()
+
+

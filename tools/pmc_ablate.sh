@@ -4,7 +4,7 @@
 # 32 extraction, 64 all leaves, 128 every op; 256 = nothing off).  Run on the GPU box from the repo root.
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}
 for ab in 256 257 258 264 272 288 320 384; do
-  cd /tmp && PCD_ABLATE=$ab rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_BRANCH --output-format csv -d $R/gpurun_out/pmca_$ab -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --log2-batch 15 > /dev/null 2>&1
+  cd /tmp && PYPOLAR_AMD_LIB=$R/polar-codes_amd/lib/libpolar_amd_diag.so PCD_ABLATE=$ab rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_BRANCH --output-format csv -d $R/gpurun_out/pmca_$ab -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pmc-traffic --log2-batch 15 > /dev/null 2>&1
 done
 cd $R && python3 - <<'PY'
 import csv, glob, collections

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Instruction-cache counters of the dominant kernel (run on the GPU box from the repo root):  bash tools/pmc_icache.sh cfg3 scl_decode_kernel 16
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}; CFG=${1:-cfg3}; KER=${2:-scl_decode_kernel}; LB=${3:-16}
-cd /tmp && rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/pmcic_$CFG -- python3 $R/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --log2-batch $LB > /dev/null 2>&1
+cd /tmp && rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/pmcic_$CFG -- python3 $R/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-pmc-traffic --log2-batch $LB > /dev/null 2>&1
 cd $R && python3 - "$CFG" "$KER" "$LB" <<'PY'
 import csv, glob, collections, sys
 cfg, ker, lb = sys.argv[1], sys.argv[2], int(sys.argv[3])

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}; CFG=${1:-cfg3}; KER=${2:-scl_decode_kernel}; LB=${3:-18}
-cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/pmclds_$CFG -- python3 $R/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --log2-batch $LB > /dev/null 2>&1
+cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/pmclds_$CFG -- python3 $R/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-pmc-traffic --log2-batch $LB > /dev/null 2>&1
 cd $R && python3 - "$CFG" "$KER" "$LB" <<'PY'
 import csv, glob, collections, sys
 cfg, ker, lb = sys.argv[1], sys.argv[2], int(sys.argv[3])

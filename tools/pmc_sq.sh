@@ -4,7 +4,7 @@
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}; CFG=${1:-cfg3}; KER=${2:-scl_decode_kernel}; LB=${3:-16}
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAIT_INST_LDS"; do
   n=$(echo $grp | cut -d' ' -f1)
-  cd /tmp && rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmcsq_${CFG}_$n -- python3 $R/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --log2-batch $LB > /dev/null 2>&1
+  cd /tmp && rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmcsq_${CFG}_$n -- python3 $R/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-pmc-traffic --log2-batch $LB > /dev/null 2>&1
 done
 cd $R && python3 - "$CFG" "$KER" "$LB" <<'PY'
 import csv, glob, collections, sys

@@ -7,6 +7,7 @@ from collections import defaultdict
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(_R, 'polar-codes_amd'), os.path.join(_R, 'tests')]
 import golden_io as gio
+os.environ.setdefault('PYPOLAR_AMD_LIB', os.path.join(_R, 'polar-codes_amd', 'lib', 'libpolar_amd_diag.so'))  # trace / cycle stamps: diagnostic build (make -C polar-codes_amd diag)
 import pypolar_amd
 
 names = {1: 'F', 2: 'G', 3: 'G0R', 4: 'COMBINE', 5: 'COMBINE0R', 6: 'RONE', 7: 'R0', 8: 'R1', 9: 'REP', 10: 'SPC',
