@@ -332,6 +332,213 @@ int po_sc_decode_bits(unsigned N, const uint32_t* frozen, unsigned nF, const flo
 /* ------------------------------------------------------------------------------------------
  * Fast-SSCL      scl_avx_float.cpp
  * ---------------------------------------------------------------------------------------- */
+
+/* ------------------------------------------------------------------------------------------
+ * int8 ("char") decoders: FastSscFipChar (src/polarcode/decoding/fastssc_fip_char.cpp) and
+ * SclFipChar (scl_fip_char.cpp), primitives include/polarcode/decoding/fip_char.h.
+ * The list decoder below reuses the float routine: an int8 LLR is an exactly representable float,
+ * saturating int8 arithmetic is add + clamp, and the `long` path metrics (scl_fip_char.cpp:155)
+ * stay below 127 * N <= 2^22 in magnitude, i.e. exact in fp32 whatever the summation order.
+ * ---------------------------------------------------------------------------------------- */
+static inline int8_t sat8(int v) { return (int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v)); }
+/* F_function_calc fip_char.h:45-66: magnitudes clamped to [1, 127], sign = xor of the sign bits (never zero) */
+static inline int8_t f_char(int8_t a, int8_t b)
+{
+    const int neg = ((a ^ b) & 0x80) != 0;
+    int ma = a < -127 ? -127 : a, mb = b < -127 ? -127 : b;
+    ma = ma < 0 ? -ma : ma;
+    mb = mb < 0 ? -mb : mb;
+    if (ma < 1) ma = 1;
+    if (mb < 1) mb = 1;
+    const int m = ma < mb ? ma : mb;
+    return (int8_t)(neg ? -m : m);
+}
+/* G_function_calc fip_char.h:68-74: saturating right + left, or right - left where the bit's sign is set */
+static inline int8_t g_char(int8_t l, int8_t r, int bit) { return bit ? sat8((int)r - l) : sat8((int)r + l); }
+static inline float f_charf(float a, float b) { return (float)f_char((int8_t)a, (int8_t)b); }
+static inline float g_charf(float a, float b, unsigned u) { return (float)g_char((int8_t)a, (int8_t)b, (int)u); }
+/* char negation as the reference's `x = -x` on a char: -(-128) wraps to -128, -0 stays 0 */
+static inline int8_t neg8(int8_t v) { return (int8_t)(uint8_t)(0u - (uint8_t)v); }
+/* reduce_adds_epi8(__m256i) avxconvenience.h:92-101: tree of SATURATING adds over the 32 byte lanes */
+static int8_t reduce_adds32(const int8_t v[32])
+{
+    int8_t a[16], b[8], c[4], d[2];
+    for (int l = 0; l < 16; ++l) a[l] = sat8((int)v[l] + v[l + 16]);
+    for (int l = 0; l < 8; ++l) b[l] = sat8((int)a[l] + a[l + 8]);
+    for (int l = 0; l < 4; ++l) c[l] = sat8((int)b[l] + b[l + 4]);
+    for (int l = 0; l < 2; ++l) d[l] = sat8((int)c[l] + c[l + 2]);
+    return sat8((int)d[0] + d[1]);
+}
+/* half_reduce_adds_epi8 avxconvenience.h:202-210: every byte ends as the saturating sum of the lanes of its parity */
+static void half_reduce_adds32(const int8_t v[32], int8_t out[32])
+{
+    int8_t a[32], b[32], c[32];
+    for (int l = 0; l < 32; ++l) a[l] = sat8((int)v[l] + v[(l + 16) & 31]);
+    for (int l = 0; l < 32; ++l) b[l] = sat8((int)a[l] + a[(l & 16) | ((l + 8) & 15)]);
+    for (int l = 0; l < 32; ++l) c[l] = sat8((int)b[l] + b[(l & ~7) | ((l + 4) & 7)]);
+    for (int l = 0; l < 32; ++l) out[l] = sat8((int)c[l] + c[(l & ~3) | ((l + 2) & 3)]);
+}
+/* the 32 lane accumulators of the REP / DREP leaves: zero padded single vector, or vector-by-vector saturating sums */
+static void lane_sums32(const int8_t* x, unsigned n, int8_t v[32])
+{
+    for (unsigned l = 0; l < 32; ++l) v[l] = 0;
+    if (n <= 32) {
+        for (unsigned l = 0; l < n; ++l) v[l] = x[l];
+    } else {
+        for (unsigned i = 0; i < n; i += 32)
+            for (unsigned l = 0; l < 32; ++l) v[l] = sat8((int)v[l] + x[i + l]);
+    }
+}
+/* fi_abs_epi8 read as unsigned bytes (abs(-128) = 128) + minpos_epu8 avxconvenience.cpp:13-56: first index of the minimum */
+static unsigned minpos_abs32(const int8_t v[32], int8_t* val)
+{
+    unsigned best = 0, bv = 256;
+    for (unsigned l = 0; l < 32; ++l) {
+        const unsigned a = v[l] == -128 ? 128u : (unsigned)(v[l] < 0 ? -v[l] : v[l]);
+        if (a < bv) {
+            bv = a;
+            best = l;
+        }
+    }
+    if (val) *val = (int8_t)(uint8_t)bv;
+    return best;
+}
+
+static int g_scc_leaves, g_scc_inner;
+/* FastSscFip::createDecoder fastssc_fip_char.cpp:496-570 and the decode() bodies :196-494; BYTESPERVECTOR = 32 (AVX2).
+ * bits: int8 "soft bits" as the reference keeps them (only their signs matter outside the leaves). */
+static void scc_node(const uint32_t* F, unsigned c, unsigned n, const int8_t* x, int8_t* bits)
+{
+    const unsigned h = n / 2;
+    int8_t v[32];
+    if (c == n) { /* RateZeroDecoder :196-202 */
+        g_scc_leaves++;
+        memset(bits, 127, n);
+        return;
+    }
+    if (c == 0) { /* RateOneDecoder :204-209 */
+        g_scc_leaves++;
+        memcpy(bits, x, n);
+        return;
+    }
+    if (c == n - 1) { /* RepetitionDecoder :219-234 / ShortRepetitionDecoder :259-266 */
+        g_scc_leaves++;
+        lane_sums32(x, n, v);
+        memset(bits, reduce_adds32(v), n);
+        return;
+    }
+    if (c == 1) { /* SpcDecoder :268-297 / ShortSpcDecoder :299-313 */
+        g_scc_leaves++;
+        unsigned par = 0;
+        memcpy(bits, x, n);
+        for (unsigned i = 0; i < n; ++i) par ^= (uint8_t)x[i] >> 7;
+        if (n <= 32) {
+            for (unsigned l = 0; l < 32; ++l) v[l] = l < n ? x[l] : 127; /* SpcPrepare fip_char.h:231-236 */
+            if (par) {
+                const unsigned k = minpos_abs32(v, NULL);
+                if (k < n) bits[k] = neg8(bits[k]);
+            }
+        } else {
+            unsigned minIdx = 0;
+            int8_t minAbs = 127, t;
+            for (unsigned i = 0; i < n; i += 32) {
+                if (minAbs > 0) {
+                    const unsigned k = minpos_abs32(x + i, &t);
+                    if (t < minAbs) {
+                        minIdx = k + i;
+                        minAbs = t;
+                    }
+                }
+            }
+            if (par) bits[minIdx] = neg8(bits[minIdx]);
+        }
+        return;
+    }
+    if (c == n - 2 && n >= 32) { /* DoubleRepetitionDecoder :242-257 (no check WHICH two bits are free) */
+        g_scc_leaves++;
+        int8_t r[32];
+        lane_sums32(x, n, v);
+        half_reduce_adds32(v, r);
+        for (unsigned i = 0; i < n; ++i) bits[i] = r[i & 31];
+        return;
+    }
+    uint32_t* FL = (uint32_t*)malloc(sizeof(uint32_t) * (c + 1) * 2);
+    uint32_t* FR = FL + c + 1;
+    unsigned cl, cr;
+    split_frozen(F, c, h, FL, &cl, FR, &cr);
+    int8_t* child = (int8_t*)malloc(n);
+    if (cl == h && cr == 0 && n <= 32) { /* ShortZeroOneDecoder :386-395 */
+        g_scc_leaves++;
+        for (unsigned i = 0; i < h; ++i) bits[i] = bits[h + i] = sat8((int)x[i] + x[h + i]);
+    } else if (cl == h && cr == 1) { /* ZeroSpcDecoder :315-353 / ShortZeroSpcDecoder :355-384 */
+        g_scc_leaves++;
+        unsigned par = 0;
+        for (unsigned i = 0; i < h; ++i) {
+            child[i] = sat8((int)x[i] + x[h + i]);
+            par ^= (uint8_t)child[i] >> 7;
+        }
+        if (n <= 32) {
+            for (unsigned l = 0; l < 32; ++l) v[l] = l < h ? child[l] : 127;
+            if (par) {
+                const unsigned k = minpos_abs32(v, NULL);
+                if (k < h) child[k] = neg8(child[k]);
+            }
+            memcpy(bits, child, h);
+            memcpy(bits + h, child, h);
+        } else {
+            unsigned minIdx = 0;
+            int8_t minAbs = 127, t;
+            for (unsigned i = 0; i < h; i += 32) {
+                if (minAbs > 0) {
+                    const unsigned k = minpos_abs32(child + i, &t);
+                    if (t < minAbs) {
+                        minIdx = k + i;
+                        minAbs = t;
+                    }
+                }
+            }
+            memcpy(bits, child, h);
+            memcpy(bits + h, child, h);
+            if (par) {
+                bits[minIdx] = neg8(bits[minIdx]);
+                bits[minIdx + h] = neg8(bits[minIdx + h]);
+            }
+        }
+    } else if (cr == 0) { /* ROneNode :412-434 / ShortROneNode :436-470 */
+        g_scc_inner++;
+        for (unsigned i = 0; i < h; ++i) child[i] = f_char(x[i], x[h + i]);
+        scc_node(FL, cl, h, child, bits);
+        for (unsigned i = 0; i < h; ++i) {
+            const int8_t o = g_char(x[i], x[h + i], (uint8_t)bits[i] >> 7);
+            bits[i] = (int8_t)(bits[i] ^ o);
+            bits[h + i] = o;
+        }
+    } else if (cl == h) { /* ZeroRNode :473-480 / ShortZeroRNode :482-489 */
+        g_scc_inner++;
+        for (unsigned i = 0; i < h; ++i) child[i] = sat8((int)x[i] + x[h + i]);
+        scc_node(FR, cr, h, child, bits + h);
+        memcpy(bits, bits + h, h);
+    } else { /* RateRNode :397-408 / ShortRateRNode :410 (CombineBitsShort clamps to -127 first: signs unchanged) */
+        g_scc_inner++;
+        for (unsigned i = 0; i < h; ++i) child[i] = f_char(x[i], x[h + i]);
+        scc_node(FL, cl, h, child, bits);
+        for (unsigned i = 0; i < h; ++i) child[i] = g_char(x[i], x[h + i], (uint8_t)bits[i] >> 7);
+        scc_node(FR, cr, h, child, bits + h);
+        for (unsigned i = 0; i < h; ++i) bits[i] = (int8_t)(bits[i] ^ bits[h + i]);
+    }
+    free(child);
+    free(FL);
+}
+
+int po_scc_decode_bits(unsigned N, const uint32_t* frozen, unsigned nF, const int8_t* llr, uint8_t* bits_out)
+{
+    int8_t* b = (int8_t*)malloc(N);
+    scc_node(frozen, nF, N, llr, b);
+    for (unsigned i = 0; i < N; ++i) bits_out[i] = (uint8_t)b[i] >> 7;
+    free(b);
+    return 0;
+}
+
 typedef struct {
     float* llr;   /* stage s at offset (1<<s), 2N floats            (PathList::Llr)     */
     uint8_t* bit; /* stage s at offset (1<<s), 2N sign bits         (PathList::Bit)     */
@@ -341,6 +548,7 @@ typedef struct {
 
 typedef struct {
     unsigned N, L, n_paths, stages;
+    int chr; /* 1: SclFipChar (int8 LLRs held as exact small floats, see "int8 decoders" below) */
     po_path* cur;
     po_path* nxt;
     /* scratch for leaves */
@@ -426,11 +634,15 @@ static void scl_node(po_scl* d, const uint32_t* F, unsigned c, unsigned n, unsig
         for (unsigned p = 0; p < P; ++p) {
             const float m = d->cur[p].metric;
             for (unsigned i = 0; i < n; ++i) d->tmp[i] = fabs32(d->cur[p].llr[o + i]);
+            if (d->chr) /* abs(max(llr, -127)) scl_fip_char.cpp:413-417 */
+                for (unsigned i = 0; i < n; ++i) d->tmp[i] = minps(d->tmp[i], 127.0f);
             find_weak(d->tmpi, d->tmp, n, 2);
             d->cand_metric[p * 4 + 0] = m;
             d->cand_metric[p * 4 + 1] = m - d->tmp[0];
             d->cand_metric[p * 4 + 2] = m - d->tmp[1];
             d->cand_metric[p * 4 + 3] = (m - d->tmp[0]) - d->tmp[1];
+            if (d->chr && n == 1) /* scl_fip_char.cpp:455-457 (-0x100000000000: far below every metric) */
+                d->cand_metric[p * 4 + 2] = d->cand_metric[p * 4 + 3] = -17592186044416.0f;
             d->nflips[p * 4 + 0] = 0;
             d->nflips[p * 4 + 1] = 1;
             d->flips[p * 4 + 1][0] = d->tmpi[0];
@@ -465,11 +677,23 @@ static void scl_node(po_scl* d, const uint32_t* F, unsigned c, unsigned n, unsig
         scl_trace(d);
         return;
     }
-    if (c == n - 1 && n < 8) { /* RepetitionDecoder::decode :428-481 */
+    if (c == n - 1 && (n < 8 || d->chr)) { /* RepetitionDecoder::decode :428-481; SclFip: at every size, scl_fip_char.cpp:762-764 */
         d->leaves++;
         for (unsigned p = 0; p < P; ++p) {
             const float m = d->cur[p].metric;
             const float* x = d->cur[p].llr + o;
+            if (d->chr) { /* scl_fip_char.cpp:497-547: exact sums; candidate 0 is the non-negative result, 1 its complement */
+                float zs = 0.0f, os = 0.0f;
+                for (unsigned i = 0; i < n; ++i) {
+                    zs += minps(x[i], 0.0f);
+                    os += maxps(x[i], 0.0f);
+                }
+                d->rep_result[p * 2 + 0] = 1.0f;
+                d->rep_result[p * 2 + 1] = -1.0f;
+                d->cand_metric[p * 2 + 0] = m + zs;
+                d->cand_metric[p * 2 + 1] = m - os;
+                continue;
+            }
             float z[8], on[8];
             for (unsigned i = 0; i < n; ++i) {
                 z[i] = minps(x[i], 0.0f);
@@ -502,6 +726,7 @@ static void scl_node(po_scl* d, const uint32_t* F, unsigned c, unsigned n, unsig
             for (unsigned i = 0; i < n; ++i) {
                 par ^= sb(x[i]);
                 d->tmp[i] = fabs32(x[i]);
+                if (d->chr) d->tmp[i] = minps(d->tmp[i], 127.0f); /* scl_fip_char.cpp:587-590 */
             }
             find_weak(d->tmpi, d->tmp, n, 4);
             const float* v = d->tmp;
@@ -569,13 +794,19 @@ static void scl_node(po_scl* d, const uint32_t* F, unsigned c, unsigned n, unsig
     unsigned cl, cr;
     split_frozen(F, c, h, FL, &cl, FR, &cr);
 
-    for (unsigned p = 0; p < d->n_paths; ++p) po_f(d->cur[p].llr + o, d->cur[p].llr + ot, h);
+    for (unsigned p = 0; p < d->n_paths; ++p) {
+        if (d->chr)
+            for (unsigned i = 0; i < h; ++i) d->cur[p].llr[ot + i] = f_charf(d->cur[p].llr[o + i], d->cur[p].llr[o + h + i]);
+        else
+            po_f(d->cur[p].llr + o, d->cur[p].llr + ot, h);
+    }
     scl_node(d, FL, cl, h, t);
     for (unsigned p = 0; p < d->n_paths; ++p) { /* prepareRightDecoding :145-151 + G_function */
         po_path* q = &d->cur[p];
         for (unsigned i = 0; i < h; ++i) {
             q->left[ot + i] = q->bit[ot + i];
-            q->llr[ot + i] = polar_g(q->llr[o + i], q->llr[o + h + i], q->left[ot + i]);
+            q->llr[ot + i] = d->chr ? g_charf(q->llr[o + i], q->llr[o + h + i], q->left[ot + i])
+                                    : polar_g(q->llr[o + i], q->llr[o + h + i], q->left[ot + i]);
         }
     }
     scl_node(d, FR, cr, h, t);
@@ -873,13 +1104,21 @@ int po_decode_batch(unsigned N, unsigned L, const uint32_t* frozen, unsigned nF,
     uint8_t* scratch = (uint8_t*)malloc(N);
     uint8_t* tmp = (uint8_t*)calloc(nb + 8, 1);
     po_scl* d = (L > 1) ? scl_new(N, L) : NULL;
+    int8_t* row8 = (int8_t*)malloc(N);
     int rc = 0;
+    if (d) d->chr = dectype == 3;
     for (size_t r = 0; r < rows && !rc; ++r) {
         const float* x = llr + r * N;
         uint8_t* o = out + r * nb;
         float* m = metrics ? metrics + r * L : NULL;
         if (m) memset(m, 0, sizeof(float) * L);
-        if (L <= 1) {
+        if (dectype == 3 && L <= 1) { /* FastSscFipChar::decode fastssc_fip_char.cpp:617-631; the row holds int8 values */
+            for (unsigned i = 0; i < N; ++i) row8[i] = (int8_t)x[i];
+            po_scc_decode_bits(N, frozen, nF, row8, bits);
+            extract(bits, N, frozen, nF, systematic, scratch, tmp);
+            ok[r] = (uint8_t)po_det_check(det, tmp, (int)nb);
+            memcpy(o, tmp, nb);
+        } else if (L <= 1) {
             rc = sc_decode_row(N, frozen, nF, det, systematic, x, bits, scratch, tmp, &ok[r]);
             memcpy(o, tmp, nb);
         } else if (dectype == 2) { /* AdaptiveFloat::decode adaptive_float.cpp:33-45 */
@@ -892,6 +1131,7 @@ int po_decode_batch(unsigned N, unsigned L, const uint32_t* frozen, unsigned nF,
         }
     }
     if (d) scl_free(d);
+    free(row8);
     free(bits);
     free(scratch);
     free(tmp);

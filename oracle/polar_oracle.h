@@ -62,6 +62,11 @@ int po_decode_batch(unsigned N, unsigned L, const uint32_t* frozen, unsigned nF,
                     int systematic, int dectype, const float* llr, size_t rows, uint8_t* out,
                     uint8_t* ok, float* metrics);
 
+/* FastSscFipChar (fastssc_fip_char.cpp): hard decisions of the N code bits for one row of int8 LLRs.
+ * (po_decode_batch with dectype 3 runs the int8 decoders: FastSscFipChar for L <= 1, SclFipChar above; the rows are
+ * passed as int8-valued floats.) */
+int po_scc_decode_bits(unsigned N, const uint32_t* frozen, unsigned nF, const int8_t* llr, uint8_t* bits_out);
+
 /* ButterflyFipPacked::encode_vector (butterfly_fip_packed.cpp:45-59): info (K+7)/8 bytes in
  * (checksum written into its tail, as the reference does), codeword N/8 bytes out, MSB first. */
 void po_encode(unsigned N, const uint32_t* frozen, unsigned nF, int det, int systematic,

@@ -43,7 +43,7 @@
 //   u32 hdr[10] = {0x31584650 'PFX1', N, K, L, nF, count, nb=(K+7)/8, crcsize, crcnr, dectype}
 //   u32 F[nF]
 //   count x { f32 llr[N] | u8 info[nb] | u8 out[nb] | u8 ok | u8 npaths | f32 metrics[L] }
-// mode: awgn | noise | ties | quant      dectype (low byte): 0 float, 2 mixed; bit 8: non-systematic,
+// mode: awgn | noise | ties | quant | sat      dectype (low byte): 0 float, 2 mixed, 3 char; bit 8: non-systematic,
 // bit 9: the row was fed as int8 through decode_vector(const char*)
 
 #include <algorithm>
@@ -73,6 +73,8 @@
 #include <polarcode/decoding/adaptive_float.h>
 #include <polarcode/decoding/fastssc_avx_float.h>
 #include <polarcode/decoding/scl_avx_float.h>
+#include <polarcode/decoding/fastssc_fip_char.h>
+#include <polarcode/decoding/scl_fip_char.h>
 #undef class
 #undef private
 #undef protected
@@ -94,7 +96,10 @@ struct Code {
 static Decoding::Decoder* make_decoder(const Code& c)
 {
     Decoding::Decoder* d;
-    if (c.dectype == 2)
+    if (c.dectype == 3)  // "char": FastSscFipChar / SclFipChar (decoder.cpp:65-67,80-82)
+        d = c.L == 1 ? (Decoding::Decoder*)new Decoding::FastSscFipChar(c.N, c.F)
+                     : (Decoding::Decoder*)new Decoding::SclFipChar(c.N, c.L, c.F);
+    else if (c.dectype == 2)
         d = new Decoding::AdaptiveFloat(c.N, c.L, c.F);
     else if (c.L == 1)
         d = new Decoding::FastSscAvxFloat(c.N, c.F);
@@ -138,6 +143,10 @@ static void make_row(const Code& c, Encoding::ButterflyFipPacked& enc, Gauss& rn
             llr[i] = (float)rng();
         } else if (mode == "ties") {
             llr[i] = (float)((rng.g() % 16 == 0) ? -x : x);
+        } else if (mode == "sat") { // int8 LLRs that saturate: round(60 y) clipped to [-128, 127]
+            double v = std::nearbyint((x + sigma * rng()) * 60.0);
+            v = std::max(-128.0, std::min(127.0, v));
+            llr[i] = (float)v;
         } else { // quant: int8-valued LLRs (many equal magnitudes)
             double v = std::nearbyint((x + sigma * rng()) * 8.0);
             v = std::max(-127.0, std::min(127.0, v));
@@ -156,10 +165,12 @@ static int cmd_gen(int argc, char** argv)
     const unsigned count = atoi(argv[10]);
     const uint64_t seed = strtoull(argv[11], nullptr, 10);
     const std::string mode = argv[12];
-    c.dectype = (std::string(argv[13]) == "mixed") ? 2 : 0;
+    c.dectype = (std::string(argv[13]) == "mixed") ? 2 : (std::string(argv[13]) == "char" ? 3 : 0);
     const char* out = argv[14];
     const bool systematic = argc > 15 ? atoi(argv[15]) != 0 : true;
-    const bool in_i8 = argc > 16 && std::string(argv[16]) == "i8";
+    // (the int8 decoders are always fed through the char overload: their float overload converts with three different
+    //  rounding routines depending on the block length, bitcontainer.cpp:449-516)
+    const bool in_i8 = c.dectype == 3 || (argc > 16 && std::string(argv[16]) == "i8");
     if (!c.ctor.empty() && c.ctor[0] == '@') {  // explicit frozen set: one index per line in the named file
         FILE* ff = fopen(c.ctor.c_str() + 1, "r");
         if (!ff) { perror(c.ctor.c_str() + 1); return 1; }
@@ -198,7 +209,7 @@ static int cmd_gen(int argc, char** argv)
         if (in_i8) {  // the fixture keeps the row as (int8-valued) floats
             std::vector<char> row8(c.N);
             for (unsigned i = 0; i < c.N; ++i) {
-                const float v = std::max(-127.0f, std::min(127.0f, std::nearbyint(llr[i])));
+                const float v = std::max(-128.0f, std::min(127.0f, std::nearbyint(llr[i])));
                 row8[i] = (char)(int)v;
                 llr[i] = (float)(int)v;
             }
@@ -215,6 +226,13 @@ static int cmd_gen(int argc, char** argv)
             if (p < 1) p = 1;
             npaths = (uint8_t)p;
             for (unsigned i = 0; i < p && i < c.L; ++i) metrics[i] = scl->mPathList->mMetric[i];
+        }
+        if (c.dectype == 3 && c.L > 1) {  // exact `long` metrics (scl_fip_char.cpp:155), below 2^24 in magnitude: exact as f32
+            Decoding::SclFipChar* sc = dynamic_cast<Decoding::SclFipChar*>(dec.get());
+            unsigned p = sc->mPathList->mNextPathCount;
+            if (p < 1) p = 1;
+            npaths = (uint8_t)p;
+            for (unsigned i = 0; i < p && i < c.L; ++i) metrics[i] = (float)sc->mPathList->mMetric[i];
         }
         const uint8_t okb = ok ? 1 : 0;
         fwrite(llr.data(), 4, c.N, f);

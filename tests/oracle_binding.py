@@ -59,7 +59,7 @@ def decode_batch(N, L, frozen, det, llr, systematic=True, dectype="float"):
     ok = np.zeros(B, np.uint8)
     met = np.zeros((B, max(L, 1)), np.float32)
     rc = lib().po_decode_batch(N, L, _p(frozen), frozen.size, det, int(systematic),
-                               2 if dectype == "mixed" else 0, _p(llr), B, _p(out), _p(ok), _p(met))
+                               {"mixed": 2, "char": 3}.get(dectype, 0), _p(llr), B, _p(out), _p(ok), _p(met))
     if rc != 0:
         raise ValueError("oracle: the reference would throw for this frozen set (SURVEY Q6)")
     return out, ok, met

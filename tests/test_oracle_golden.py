@@ -14,20 +14,20 @@ FILES = gio.all_files()
 def test_fixture_inventory():
     names = [f.split("/")[-1] for f in FILES]
     for cfg in ("cfg1_", "cfg2_", "cfg3_", "cfg4_", "cfg5_", "mix_", "sweep_", "nsys_cfg2", "nsys_cfg3", "nsys_cfg4",
-                "nsys_sweep", "nsys_mix", "i8_cfg2", "i8_cfg3", "i8_cfg4", "i8_sweep", "i8_nsys"):
+                "nsys_sweep", "nsys_mix", "i8_cfg2", "i8_cfg3", "i8_cfg4", "i8_sweep", "i8_nsys",
+                "char_cfg2", "char_cfg3", "char_cfg4", "char_sweep", "char_n4096", "char_nsys"):
         assert any(n.startswith(cfg) for n in names), cfg
 
 
 @pytest.mark.parametrize("path", FILES, ids=[f.split("/")[-1] for f in FILES])
 def test_oracle_matches_reference_vectors(path):
     for fx in gio.load(path):
-        if fx.dectype == "char":
-            continue  # the int8 decoders have their own oracle entry point (test_oracle_char.py)
+        # ("char" fixtures: FastSscFipChar / SclFipChar restated in the same oracle, rows are int8-valued floats)
         # (int8 input: FloatContainer::insertLlr(const char*) is an exact widening, the fixture keeps the widened row)
         out, ok, met = ob.decode_batch(fx.N, fx.L, fx.frozen, fx.crc_size, fx.llr, fx.systematic, fx.dectype)
         assert np.array_equal(out, fx.out), fx.name
         assert np.array_equal(ok, fx.ok), fx.name
-        if fx.L > 1 and fx.dectype == "float":
+        if fx.L > 1 and fx.dectype in ("float", "char"):
             for r in range(fx.count):
                 p = int(fx.npaths[r])
                 # bit-identical, i.e. far inside the 1e-5 relative tolerance of the north star
