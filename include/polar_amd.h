@@ -31,7 +31,7 @@ typedef enum {
     PCD_OK = 0,
     PCD_ERR_INVALID_ARG = -1,   /* bad N / L / frozen set / null pointer                              */
     PCD_ERR_UNKNOWN_TYPE = -2,  /* reference: std::logic_error("Unknown PolarDecoder type!")          */
-    PCD_ERR_UNSUPPORTED = -3,   /* "char"/"scan" decoders, CMAC / CRC-6 / CRC-16: not on this path     */
+    PCD_ERR_UNSUPPORTED = -3,   /* "scan" decoder, CMAC / CRC-6 / CRC-16: not on this path              */
     PCD_ERR_FROZEN_SET = -4,    /* reference: std::invalid_argument from FastSscAvx::createDecoder     */
     PCD_ERR_CRC_SIZE = -5,      /* reference: std::logic_error("CRC INVALID SIZE!")                    */
     PCD_ERR_UNKNOWN_DETECTOR = -6, /* reference: std::runtime_error("Unknown Error detector requested!") */
@@ -45,9 +45,9 @@ typedef enum {
 enum { PCD_MEM_HOST = 0, PCD_MEM_DEVICE = 1 };
 
 /* Decoding::create(blockLength, listSize, frozenBits, decoderType)  decoder.cpp:26-52.
- * type is matched like the reference (lower-cased substring): "float", "mixed"; "char" and "scan"
- * are recognised but PCD_ERR_UNSUPPORTED.  listSize < 2 with a non-char type selects float SC
- * (decoder.cpp:48-50).  frozen[] must be strictly ascending (what frozen_bits() returns).
+ * type is matched like the reference (lower-cased substring): "char" (the int8 decoders FastSscFipChar /
+ * SclFipChar, the factory's default branch decoder.cpp:65-67,80-82), "float", "mixed"; "scan" is recognised
+ * but PCD_ERR_UNSUPPORTED.  listSize < 2 with a non-char type selects float SC (decoder.cpp:48-50).  frozen[] must be strictly ascending (what frozen_bits() returns).
  * The new decoder carries the CRC-8 detector, as makeDecoder does (decoder.cpp:85).
  * device: HIP device ordinal used by later decode calls (nothing touches the GPU here). */
 int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, size_t n_frozen,
@@ -80,8 +80,11 @@ size_t pcd_out_bytes(const pcd_decoder* d);                    /* (K + 7) / 8   
  *             the SC pass failed on from device memory.) */
 int pcd_decode_f32(pcd_decoder* d, const float* llr, size_t rows, uint8_t* out, uint8_t* ok,
                    float* metrics, int mem, void* stream);
-/* Batched Decoder::decode_vector(const char*, void*): int8 LLRs widened to float exactly as
- * FloatContainer::insertLlr(const char*) does (bitcontainer.cpp:202-207). */
+/* Batched Decoder::decode_vector(const char*, void*): float decoders widen the int8 LLRs exactly as
+ * FloatContainer::insertLlr(const char*) does (bitcontainer.cpp:202-207); the int8 ("char") decoders take them as
+ * they are (CharContainer::insertLlr(const char*) bitcontainer.cpp:518).  pcd_decode_f32 on an int8 decoder converts
+ * like CharContainer::insertLlr(const float*) :505-516 (round to nearest even, saturate to [-128, 127]).  Path metrics
+ * of the int8 list decoder are exact integers (the reference's `long`, scl_fip_char.cpp:155) returned as float. */
 int pcd_decode_i8(pcd_decoder* d, const int8_t* llr, size_t rows, uint8_t* out, uint8_t* ok,
                   float* metrics, int mem, void* stream);
 

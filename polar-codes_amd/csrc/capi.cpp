@@ -58,7 +58,7 @@ int pamd::set_error(int code, const std::string& msg) { return fail(code, msg); 
 struct pcd_decoder {
     unsigned N = 0, logN = 0, L = 1, K = 0, nb = 0;
     int device = 0;
-    int dectype = 1;  // 1 float, 2 mixed
+    int dectype = 1;  // 0 char (int8 arithmetic), 1 float, 2 mixed
     bool systematic = true;
     std::vector<uint32_t> frozen;
     pamd::Detector det;
@@ -89,6 +89,8 @@ struct pcd_decoder {
     // staging for host-pointer calls and the mixed decoder
     void* d_in = nullptr;
     size_t d_in_cap = 0;
+    int8_t* d_i8 = nullptr;  // int8 decoders called with float rows: CharContainer::insertLlr(const float*) on the device
+    size_t d_i8_cap = 0;
     uint8_t* d_out = nullptr;
     size_t d_out_cap = 0;
     uint8_t* d_ok = nullptr;
@@ -150,6 +152,7 @@ void compute_geometry(pcd_decoder* d)
     if (const char* e = PAMD_ENV("PCD_SC_LCL")) {  // experiments
         const int v = std::atoi(e);
         d->sc_lcl = (v == 3 || v == 6) ? v : 4;
+        if (d->dectype == 0 && d->sc_lcl == 3) d->sc_lcl = 4;  // (the int8 reductions need the 32 byte lanes on 16 or 64 lanes)
     }
     d->sc_s0 = d->logN;
     d->sc_arena_cw_words = 0;
@@ -273,7 +276,7 @@ void fuse_sc(pcd_decoder* d)
 {
     if (PAMD_ENV("PCD_NO_FUSE")) return;
     auto& v = d->sc_prog.ins;
-    auto is_leaf = [](const pamd::Ins& in) { return in.op >= pamd::SC_R0 && in.op <= pamd::SC_ZEROSPC; };
+    auto is_leaf = [](const pamd::Ins& in) { return in.op >= pamd::SC_R0 && in.op <= pamd::SCC_ZEROSPC; };
     const unsigned top = d->logN - (d->sc_virtual_top ? 1u : 0u);  // first stage that is not a stored LDS / arena stage
     auto lds_stage = [&](unsigned t) { return t < top && t < d->sc_s0; };
     std::vector<pamd::Ins> out;
@@ -423,7 +426,7 @@ void specialize_scl(pcd_decoder* d)
     if ((d->lpl == 2 || d->lpl == 3) && !PAMD_ENV("PCD_NO_FUSE")) {
         auto& v = d->scl_prog.ins;
         auto small_leaf = [](const pamd::Ins& in) {
-            return in.stage <= 3 &&
+            return in.stage <= 3 && !(in.op == pamd::SCL_REP && in.stage > 2) &&
                    (in.op == pamd::SCL_R0 || in.op == pamd::SCL_REP || in.op == pamd::SCL_SPC_S || in.op == pamd::SCL_R1_S);
         };
         std::vector<pamd::Ins> out;
@@ -599,6 +602,7 @@ pamd::DecodeParams base_params(const pcd_decoder* d, const void* llr, size_t row
     P.ok = ok;
     P.metrics = metrics;
     P.det_on = d->det.size != 0;
+    P.chr = d->dectype == 0 ? 1u : 0u;
     P.systematic = d->systematic ? 1u : 0u;
     if (const char* ab = PAMD_ENV("PCD_ABLATE")) P.ablate = (uint32_t)std::atoi(ab);
     return P;
@@ -692,6 +696,14 @@ int decode_device(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t
             for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
         }
         HIP_TRY(hipEventRecord(d->ev[2 * d->ev_count], st));
+    }
+    if (d->dectype == 0 && !i8) {
+        // float rows into an int8 decoder: CharContainer::insertLlr(const float*) bitcontainer.cpp:505-516 -- round to
+        // nearest even, saturate to [-128, 127] (convert_f32_to_int8_large / vectorizedFtoC; N >= 8 here)
+        if ((rc = grow(d->d_i8, d->d_i8_cap, rows * d->N))) return rc;
+        HIP_TRY(pamd::launch_f32_to_i8(reinterpret_cast<const float*>(llr), d->d_i8, rows * d->N, st));
+        llr = d->d_i8;
+        i8 = true;
     }
     if (d->L <= 1) {
         if (metrics) HIP_TRY(hipMemsetAsync(metrics, 0, rows * sizeof(float), st));
@@ -791,9 +803,6 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
     else
         return fail(PCD_ERR_UNKNOWN_TYPE, "Unknown PolarDecoder type!");
     if (list_size < 2 && flag != 0) flag = 1;
-    if (flag == 0)
-        return fail(PCD_ERR_UNSUPPORTED,
-                    "the int8 fixed-point (\"char\") decoders are not on the accelerated path; use \"float\" or \"mixed\"");
     if (flag == 3) return fail(PCD_ERR_UNSUPPORTED, "the SCAN decoder is not on the accelerated path");
 
     const size_t N = block_length;
@@ -821,8 +830,9 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
     d->det.size = 8;  // makeDecoder: dec->setErrorDetection(new CRC8()) decoder.cpp:85
     d->det.nr = false;
 
+    const bool chr = d->dectype == 0;  // makeDecoder decoder.cpp:65-67,80-82: FastSscFipChar / SclFipChar
     if (d->L == 1 || d->dectype == 2) {
-        const std::string e = pamd::compile_sc(d->N, d->frozen, d->sc_prog);
+        const std::string e = pamd::compile_sc(d->N, d->frozen, d->sc_prog, chr);
         if (!e.empty()) {
             delete d;
             return fail(PCD_ERR_FROZEN_SET, e);
@@ -830,7 +840,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         d->has_sc = true;
     }
     if (d->L > 1) {
-        pamd::compile_scl(d->N, d->frozen, d->scl_prog);
+        pamd::compile_scl(d->N, d->frozen, d->scl_prog, chr);
         d->has_scl = true;
     }
     compute_geometry(d);
@@ -873,6 +883,7 @@ void pcd_destroy(pcd_decoder* d)
         if (d->last_ev) (void)hipEventDestroy(d->last_ev);
     }
     if (d->d_in) (void)hipFree(d->d_in);
+    if (d->d_i8) (void)hipFree(d->d_i8);
     if (d->d_out) (void)hipFree(d->d_out);
     if (d->d_ok) (void)hipFree(d->d_ok);
     if (d->d_met) (void)hipFree(d->d_met);

@@ -68,6 +68,50 @@ __device__ __forceinline__ float polar_g(float a, float b, uint32_t u)
 {
     return bitsf(fbits(a) ^ (u << 31)) + b;
 }
+// ---- int8 ("char") decoders: FastSscFipChar / SclFipChar (include/polarcode/decoding/fip_char.h) ---------------
+// An int8 LLR is held as the float of the same value: every operation below is exact (small integers), saturation is a
+// clamp (v_med3_f32), and a zero is always +0.0 (converted from int8, a + (-a), or b - b), so the IEEE sign bit is the
+// char's sign bit.
+// F_function_calc fip_char.h:45-66: magnitudes clamped to [1, 127] (abs(-128) counts as 127, a zero as 1), sign = xor
+__device__ __forceinline__ float polar_f_char(float a, float b)
+{
+    const float ma = __builtin_amdgcn_fmed3f(absf(a), 1.0f, 127.0f), mb = __builtin_amdgcn_fmed3f(absf(b), 1.0f, 127.0f);
+    const float m = ma < mb ? ma : mb;
+    return bitsf(((fbits(a) ^ fbits(b)) & 0x80000000u) | fbits(m));
+}
+// G_function_calc fip_char.h:68-74: _mm_adds_epi8 / _mm_subs_epi8 = add, then clamp to [-128, 127]
+__device__ __forceinline__ float polar_g_char(float a, float b, uint32_t u)
+{
+    return __builtin_amdgcn_fmed3f(bitsf(fbits(a) ^ (u << 31)) + b, -128.0f, 127.0f);
+}
+template <bool CH>
+__device__ __forceinline__ float polar_fx(float a, float b)
+{
+    if constexpr (CH) return polar_f_char(a, b);
+    else return polar_f(a, b);
+}
+template <bool CH>
+__device__ __forceinline__ float polar_gx(float a, float b, uint32_t u)
+{
+    if constexpr (CH) return polar_g_char(a, b, u);
+    else return polar_g(a, b, u);
+}
+// G_function_0R (all-frozen left child): a + b, saturating for the int8 decoders (fip_char.h:118-140)
+template <bool CH>
+__device__ __forceinline__ float addx(float a, float b)
+{
+    if constexpr (CH) return __builtin_amdgcn_fmed3f(a + b, -128.0f, 127.0f);
+    else return a + b;
+}
+// |x| as an unsigned-comparable bit pattern; the int8 leaves use abs(max(x, -127)) (scl_fip_char.cpp:413-417,587-590)
+template <bool CH>
+__device__ __forceinline__ uint32_t magbits(float x)
+{
+    const uint32_t a = fbits(x) & 0x7FFFFFFFu;
+    if constexpr (CH) return a < 0x42FE0000u ? a : 0x42FE0000u;  // 127.0f
+    else return a;
+}
+
 // _mm256_min_ps(x, 0) / _mm256_max_ps(x, 0): second operand on ties
 __device__ __forceinline__ float min0(float x) { return x < 0.0f ? x : 0.0f; }
 __device__ __forceinline__ float max0(float x) { return x > 0.0f ? x : 0.0f; }

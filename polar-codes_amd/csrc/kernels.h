@@ -19,6 +19,7 @@ struct DecodeParams {
     uint8_t* out;            // rows x nb
     uint8_t* ok;             // rows (nullable)
     float* metrics;          // rows x L (nullable)
+    uint32_t chr;            // 1 = int8 ("char") decoders: int8 rows, saturating int8 arithmetic (FastSscFipChar / SclFipChar)
     uint32_t det_on;         // 0 = dummy detector (always passes)
     uint32_t systematic;
     uint32_t path_stride;    // SCL: floats per path LLR buffer (N + bank padding)
@@ -45,6 +46,8 @@ hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, uns
                      hipStream_t st, int* occupancy = nullptr);
 hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, unsigned waves_per_block,
                       size_t lds, hipStream_t st, int* occupancy = nullptr);
+// CharContainer::insertLlr(const float*) (bitcontainer.cpp:449-516, N >= 8): round to nearest even, saturate to int8
+hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st);
 hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,
                                  hipStream_t st);
 

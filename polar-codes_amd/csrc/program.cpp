@@ -112,8 +112,48 @@ std::string sc_build(const std::vector<uint32_t>& F, unsigned n, unsigned off, P
     return e;
 }
 
-// SclAvx::createDecoder  scl_avx_float.cpp:624-651
-void scl_build(const std::vector<uint32_t>& F, unsigned n, unsigned side, Program& p)
+// FastSscFip::createDecoder  fastssc_fip_char.cpp:496-570 (same order of tests; BYTESPERVECTOR = 32).  The Short*
+// node classes compute what their long twins compute, so one op serves both; ShortZeroOneDecoder (left half frozen,
+// right half rate 1, n <= 32) is the ZeroR form with a rate-1 child: sat(a + b) copied to both halves.
+void scc_build(const std::vector<uint32_t>& F, unsigned n, unsigned off, Program& p)
+{
+    const unsigned c = (unsigned)F.size();
+    const unsigned s = ilog2(n);
+    auto leaf = [&](Op op) {
+        emit(p, op, s, off);
+        p.leaves++;
+    };
+    if (c == n) return leaf(SC_R0);
+    if (c == 0) return leaf(SC_R1);
+    if (c == n - 1) return leaf(SCC_REP);
+    if (c == 1) return leaf(SCC_SPC);
+    if (c == n - 2 && n >= 32) return leaf(SCC_DREP);
+    const unsigned h = n / 2;
+    std::vector<uint32_t> FL, FR;
+    split(F, h, FL, FR);
+    if (FL.size() == h && FR.size() == 1) return leaf(SCC_ZEROSPC);
+    p.inner++;
+    if (FL.size() == h) {  // ShortZeroOneDecoder, ZeroRNode / ShortZeroRNode
+        emit(p, SC_G0R, s, off);
+        scc_build(FR, h, off + h, p);
+        emit(p, SC_COMBINE0R, s, off);
+        return;
+    }
+    if (FR.empty()) {  // ROneNode / ShortROneNode
+        emit(p, SC_F, s, off);
+        scc_build(FL, h, off, p);
+        emit(p, SC_RONE, s, off);
+        return;
+    }
+    emit(p, SC_F, s, off);  // RateRNode / ShortRateRNode
+    scc_build(FL, h, off, p);
+    emit(p, SC_G, s, off);
+    scc_build(FR, h, off + h, p);
+    emit(p, SC_COMBINE, s, off);
+}
+
+// SclAvx::createDecoder  scl_avx_float.cpp:624-651; chr: SclFip::createDecoder scl_fip_char.cpp:745-775
+void scl_build(const std::vector<uint32_t>& F, unsigned n, unsigned side, Program& p, bool chr)
 {
     const unsigned c = (unsigned)F.size();
     const unsigned s = ilog2(n);
@@ -123,33 +163,37 @@ void scl_build(const std::vector<uint32_t>& F, unsigned n, unsigned side, Progra
     };
     if (c == 0) return leaf(SCL_R1);
     if (c == n) return leaf(SCL_R0);
-    if (c == n - 1 && n < 8) return leaf(SCL_REP);
+    if (c == n - 1 && (n < 8 || chr)) return leaf(SCL_REP);
     if (c == 1) return leaf(SCL_SPC);
     p.inner++;
     const unsigned h = n / 2;
     std::vector<uint32_t> FL, FR;
     split(F, h, FL, FR);
     emit(p, SCL_F, s, 0, side);
-    scl_build(FL, h, 0, p);
+    scl_build(FL, h, 0, p, chr);
     emit(p, SCL_G, s, 0, side);
-    scl_build(FR, h, 1, p);
+    scl_build(FR, h, 1, p, chr);
     emit(p, SCL_COMBINE, s, 0, side);
 }
 
 }  // namespace
 
-std::string compile_sc(unsigned N, const std::vector<uint32_t>& frozen, Program& out)
+std::string compile_sc(unsigned N, const std::vector<uint32_t>& frozen, Program& out, bool chr)
 {
     out = Program();
-    std::string e = sc_build(frozen, N, 0, out);
+    std::string e;
+    if (chr)
+        scc_build(frozen, N, 0, out);
+    else
+        e = sc_build(frozen, N, 0, out);
     emit(out, OP_END, 0, 0);
     return e;
 }
 
-std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program& out)
+std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program& out, bool chr)
 {
     out = Program();
-    scl_build(frozen, N, 0, out);
+    scl_build(frozen, N, 0, out, chr);
     emit(out, OP_END, 0, 0);
     return std::string();
 }

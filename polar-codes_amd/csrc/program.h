@@ -32,6 +32,12 @@ enum Op : uint8_t {
     SC_REPONE8,
     SC_ZSPC8,
     SC_ZEROSPC,
+    // leaves of the int8 decoder FastSscFipChar (fastssc_fip_char.cpp:219-384): saturating sums in the reference's
+    // lane / tree order, unsigned |x| with abs(-128) = 128, flips by char negation (0 and -128 keep their sign)
+    SCC_REP,       // RepetitionDecoder / ShortRepetitionDecoder
+    SCC_DREP,      // DoubleRepetitionDecoder (n >= 32)
+    SCC_SPC,       // SpcDecoder (n > 32) / ShortSpcDecoder
+    SCC_ZEROSPC,   // ZeroSpcDecoder (n > 32) / ShortZeroSpcDecoder
     // ---- Fast-SSCL (L > 1) -----------------------------------------------------------------
     SCL_F = 32,    // per path: llr[s-1] = f(llr[s])               RateRNode::decode :229-263
     SCL_G,         // per path: llr[s-1] = g(llr[s], left bits)
@@ -74,8 +80,10 @@ struct Program {
 
 // Returns "" on success, otherwise the text of the std::invalid_argument the reference throws
 // (SURVEY Q6).  frozen: strictly ascending indices < N.
-std::string compile_sc(unsigned N, const std::vector<uint32_t>& frozen, Program& out);
-std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program& out);
+// chr: the node selection of the int8 decoders (FastSscFip::createDecoder fastssc_fip_char.cpp:496-570, which never
+// throws; SclFip::createDecoder scl_fip_char.cpp:745-775: repetition leaves at every block length)
+std::string compile_sc(unsigned N, const std::vector<uint32_t>& frozen, Program& out, bool chr = false);
+std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program& out, bool chr = false);
 
 // ---- error detection -------------------------------------------------------------------------
 // All supported detectors are linear over GF(2) with a zero initial value, so

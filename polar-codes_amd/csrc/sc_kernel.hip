@@ -107,8 +107,73 @@ struct ScLanes {
         s = s + bitsf(dpp_u32<0x107>(a));
         return (slice(ballot64(l == 0 && sgn(s))) & 1ull) != 0;
     }
+    // ---- int8 decoder (FastSscFipChar) reductions: saturating adds in the reference's order ------------------------
+    // value of lane l + d of the group (l + d < LC), by DPP row shift inside a 16-lane group, ds_bpermute otherwise
+    __device__ __forceinline__ uint32_t pull_u32(uint32_t v, int d) const
+    {
+        if constexpr (LC == 16) {
+            switch (d) {
+            case 1: return dpp_u32<0x101>(v);
+            case 2: return dpp_u32<0x102>(v);
+            case 4: return dpp_u32<0x104>(v);
+            default: return dpp_u32<0x128>(v);  // 8: rotation of the row by 8
+            }
+        } else {
+            return shfl_u32(v, lbase + ((l + d) & (LC - 1)));
+        }
+    }
+    __device__ __forceinline__ static float sat8f(float v) { return __builtin_amdgcn_fmed3f(v, -128.0f, 127.0f); }
+    // byte lane v of the 32 accumulators "LlrSum = adds(LlrSum, load(LlrIn + i))": elements v, v + 32, ... one after the
+    // other, saturating; a block of at most 32 elements is one zero-padded vector
+    template <typename X>
+    __device__ __forceinline__ float char_lane_sum(const X& x, uint32_t n, uint32_t v) const
+    {
+        float acc = 0.0f;
+        for (uint32_t i = v; i < n; i += 32) acc = sat8f(acc + x(i));
+        return acc;
+    }
+    // first step of reduce_adds_epi8 / half_reduce_adds_epi8: lane v + lane v + 16, v < 16 (lanes 0..15 of the group)
+    template <typename X>
+    __device__ __forceinline__ float char_lane_pairs(const X& x, uint32_t n) const
+    {
+        if constexpr (LC <= 16) {
+            return sat8f(char_lane_sum(x, n, (uint32_t)l) + char_lane_sum(x, n, (uint32_t)l + 16u));
+        } else {
+            const float a = l < 32 ? char_lane_sum(x, n, (uint32_t)l) : 0.0f;
+            return sat8f(a + bitsf(pull_u32(fbits(a), 16)));
+        }
+    }
+    // reduce_adds_epi8 avxconvenience.h:92-101 from the 16 pair sums: (v, v + 8), (v, v + 4), (v, v + 2), (0, 1); lane 0
+    __device__ __forceinline__ float char_reduce16(float t) const
+    {
+        t = sat8f(t + bitsf(pull_u32(fbits(t), 8)));
+        t = sat8f(t + bitsf(pull_u32(fbits(t), 4)));
+        t = sat8f(t + bitsf(pull_u32(fbits(t), 2)));
+        t = sat8f(t + bitsf(pull_u32(fbits(t), 1)));
+        return t;
+    }
+    // half_reduce_adds_epi8 avxconvenience.h:202-210 from the 16 pair sums: butterflies over lane ^ 8, ^ 4, ^ 2
+    __device__ __forceinline__ float char_class_sums(float t) const
+    {
+        if constexpr (LC == 16) {
+            t = sat8f(t + bitsf(dpp_u32<0x128>(fbits(t))));
+            t = sat8f(t + bitsf(xor4_u32(fbits(t))));
+            t = sat8f(t + bitsf(dpp_u32<0x4E>(fbits(t))));
+        } else {
+            t = sat8f(t + bitsf(shflx_u32(fbits(t), 8)));
+            t = sat8f(t + bitsf(shflx_u32(fbits(t), 4)));
+            t = sat8f(t + bitsf(shflx_u32(fbits(t), 2)));
+        }
+        return t;
+    }
     // lexicographic (value, index) minimum over the group; key of a lane without candidates = (inf, ~0)
     __device__ __forceinline__ uint32_t min_index(uint32_t best, uint32_t bidx, bool any) const
+    {
+        const uint32_t idx = (uint32_t)min_key(best, bidx, any);
+        return idx == 0xFFFFFFFFu ? 0u : idx;
+    }
+    // ... the winning (value << 32 | index) itself
+    __device__ __forceinline__ uint64_t min_key(uint32_t best, uint32_t bidx, bool any) const
     {
         uint64_t key = any ? (((uint64_t)best << 32) | bidx) : (((uint64_t)0x7F800000u << 32) | 0xFFFFFFFFu);
         // all-reduce inside the group: DPP partners inside a 16-lane row (no LDS round trips), ds_bpermute beyond
@@ -125,8 +190,7 @@ struct ScLanes {
         step(std::integral_constant<int, 8>{});
         step(std::integral_constant<int, 16>{});
         step(std::integral_constant<int, 32>{});
-        const uint32_t idx = (uint32_t)key;
-        return idx == 0xFFFFFFFFu ? 0u : idx;
+        return key;
     }
     // first index of the minimum of |x[0..n)| (SpcDecoder::decode :342-373)
     template <typename X>
@@ -155,7 +219,8 @@ __device__ __forceinline__ float reduce_add8(const float a[8])
 // B2: the wide F / G loops take two elements per lane and trip (their loads are in flight together).  Worth 2-3 % from
 // N = 1024 on; it costs registers (86 -> 115 VGPRs, 4 instead of 5 waves per SIMD), which shorter blocks -- whose LDS
 // footprint would allow the fifth wave -- pay with 15 %, so the host picks by block length.
-template <int LCL, bool I8, bool DIAG = false, bool ARENA = false, bool B2 = false>
+// CH: int8 arithmetic (FastSscFipChar): saturating f / g on int8-valued floats and the SCC_* leaves
+template <int LCL, bool I8, bool DIAG = false, bool ARENA = false, bool B2 = false, bool CH = false>
 __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
 {
     constexpr int LC = 1 << LCL;
@@ -217,12 +282,12 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     const float a = X[i], b = X[n + i];
                     float r;
                     if (pro == 1u) {
-                        r = polar_f(a, b);
+                        r = polar_fx<CH>(a, b);
                     } else if (pro == 3u) {
-                        r = a + b;
+                        r = addx<CH>(a, b);
                     } else {
                         const uint32_t bi = lo + i;
-                        r = polar_g(a, b, (bits[bi >> 5] >> (bi & 31u)) & 1u);
+                        r = polar_gx<CH>(a, b, (bits[bi >> 5] >> (bi & 31u)) & 1u);
                     }
                     d[i] = r;
                 }
@@ -251,42 +316,42 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                 switch (op) {
                 case SC_F:
                     if (ARENA && s - 1 >= s0)
-                        for (uint32_t i = l; i < h; i += LC) ar[h + i] = polar_f(x(i), x(h + i));
+                        for (uint32_t i = l; i < h; i += LC) ar[h + i] = polar_fx<CH>(x(i), x(h + i));
                     else if (B2 && h >= 2u * LC) {  // two elements per lane and trip: their loads are in flight together
                         for (uint32_t i0 = l; i0 < h; i0 += 2u * LC) {
                             const float a0 = x(i0), b0 = x(h + i0), a1 = x(i0 + LC), b1 = x(h + i0 + LC);
-                            llr[h + i0] = polar_f(a0, b0);
-                            llr[h + i0 + LC] = polar_f(a1, b1);
+                            llr[h + i0] = polar_fx<CH>(a0, b0);
+                            llr[h + i0 + LC] = polar_fx<CH>(a1, b1);
                         }
                     } else
-                        for (uint32_t i = l; i < h; i += LC) llr[h + i] = polar_f(x(i), x(h + i));
+                        for (uint32_t i = l; i < h; i += LC) llr[h + i] = polar_fx<CH>(x(i), x(h + i));
                     break;
                 case SC_G:
                     if (ARENA && s - 1 >= s0) {
                         for (uint32_t i = l; i < h; i += LC) {
                             const uint32_t b = off + i;
-                            ar[h + i] = polar_g(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
+                            ar[h + i] = polar_gx<CH>(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
                         }
                     } else if (B2 && h >= 2u * LC) {
                         for (uint32_t i0 = l; i0 < h; i0 += 2u * LC) {
                             const uint32_t bi0 = off + i0, bi1 = bi0 + LC;
                             const float a0 = x(i0), b0 = x(h + i0), a1 = x(i0 + LC), b1 = x(h + i0 + LC);
                             const uint32_t u0 = (bits[bi0 >> 5] >> (bi0 & 31u)) & 1u, u1 = (bits[bi1 >> 5] >> (bi1 & 31u)) & 1u;
-                            llr[h + i0] = polar_g(a0, b0, u0);
-                            llr[h + i0 + LC] = polar_g(a1, b1, u1);
+                            llr[h + i0] = polar_gx<CH>(a0, b0, u0);
+                            llr[h + i0 + LC] = polar_gx<CH>(a1, b1, u1);
                         }
                     } else {
                         for (uint32_t i = l; i < h; i += LC) {
                             const uint32_t b = off + i;
-                            llr[h + i] = polar_g(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
+                            llr[h + i] = polar_gx<CH>(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
                         }
                     }
                     break;
                 case SC_G0R:
                     if (ARENA && s - 1 >= s0)
-                        for (uint32_t i = l; i < h; i += LC) ar[h + i] = x(i) + x(h + i);
+                        for (uint32_t i = l; i < h; i += LC) ar[h + i] = addx<CH>(x(i), x(h + i));
                     else
-                        for (uint32_t i = l; i < h; i += LC) llr[h + i] = x(i) + x(h + i);
+                        for (uint32_t i = l; i < h; i += LC) llr[h + i] = addx<CH>(x(i), x(h + i));
                     break;
                 case SC_COMBINE:
                 case SC_COMBINE0R:
@@ -300,7 +365,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                         if (act) {
                             const uint32_t b = off + i;
                             u = (bits[b >> 5] >> (b & 31u)) & 1u;
-                            sl = sgn(polar_g(x(i), x(h + i), u));
+                            sl = sgn(polar_gx<CH>(x(i), x(h + i), u));
                         }
                         const uint64_t mr = g.slice(ballot64(act && sl));
                         const uint64_t ml = g.slice(ballot64(act && (sl ^ u)));
@@ -429,11 +494,11 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                         for (int v = 0; v < 8; ++v) v8[v] = x(v);
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) q[j] = polar_f(v8[j], v8[j + 4]);
+                    for (int j = 0; j < 4; ++j) q[j] = polar_fx<CH>(v8[j], v8[j + 4]);
                     const float rho = (q[0] + q[1]) + (q[2] + q[3]);
                     const uint32_t sr = sgn(rho);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) gg[j] = polar_g(v8[j], v8[j + 4], sr);
+                    for (int j = 0; j < 4; ++j) gg[j] = polar_gx<CH>(v8[j], v8[j + 4], sr);
                     uint32_t ss;
                     if (op == SC_TYPE5)
                         ss = spc4_signs(gg);
@@ -482,6 +547,65 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     }
                     break;
                 }
+                case SCC_REP: {  // sign of reduce_adds_epi8 over the 32 byte-lane sums (fastssc_fip_char.cpp:219-234,259-266)
+                    if constexpr (CH) {
+                        const float t = g.char_lane_pairs(x, n);
+                        g.fill_pattern(bits, off, n, g.from_lane0(sgn(g.char_reduce16(t)) ? 0xFFFFFFFFu : 0u));
+                    }
+                    break;
+                }
+                case SCC_DREP: {  // half_reduce_adds_epi8: even / odd positions take the saturating sum of their class (:242-257)
+                    if constexpr (CH) {
+                        float t = g.char_lane_pairs(x, n);
+                        t = g.char_class_sums(t);
+                        const uint32_t ev = sgn(t) ? 0x55555555u : 0u;  // (lane 0: even class, lane 1: odd class)
+                        const uint32_t od = g.pull_u32(sgn(t) ? 0xAAAAAAAAu : 0u, 1);
+                        g.fill_pattern(bits, off, n, g.from_lane0(ev | od));
+                    }
+                    break;
+                }
+                case SCC_SPC:        // SpcDecoder :268-297 / ShortSpcDecoder :299-313
+                case SCC_ZEROSPC: {  // ZeroSpcDecoder :315-353 / ShortZeroSpcDecoder :355-384 (on y = sat(a + b), output twice)
+                    if constexpr (CH) {
+                        const bool zs = op == SCC_ZEROSPC;
+                        const uint32_t m_ = zs ? h : n;  // elements searched
+                        auto y = [&](uint32_t i) { return zs ? addx<true>(x(i), x(h + i)) : x(i); };
+                        uint32_t par = 0, best = 0x7F800000u, bidx = 0;
+                        bool any = false;
+                        for (uint32_t i0 = 0; i0 < m_; i0 += LC) {
+                            const uint32_t i = i0 + l;
+                            const bool in = i < m_;
+                            const uint32_t yb = fbits(y(in ? i : 0));
+                            const uint64_t m = g.slice(ballot64(in && (yb >> 31)));
+                            par ^= (uint32_t)__popcll(m) & 1u;
+                            const uint32_t cnt = m_ < (uint32_t)LC ? m_ : (uint32_t)LC;
+                            g.put_bits(bits, off + i0, cnt, m);
+                            if (zs) g.put_bits(bits, off + h + i0, cnt, m);
+                            const uint32_t a = yb & 0x7FFFFFFFu;  // fi_abs_epi8 read as unsigned: |-128| = 128 sorts last
+                            if (in && a < best) {
+                                best = a;
+                                bidx = i;
+                                any = true;
+                            }
+                        }
+                        const uint64_t key = g.min_key(best, bidx, any);  // first index of the minimum (minpos_epu8)
+                        const uint32_t mv = (uint32_t)(key >> 32);
+                        uint32_t im = (uint32_t)key;
+                        bool flip = par != 0;
+                        if (n > 32) {  // vector-wise search, `testAbs < minAbs` from minAbs = 127: nothing below 127 -> index 0
+                            if (mv >= 0x42FE0000u) im = 0;
+                        } else if (mv > 0x42FE0000u) {  // one padded vector: the 127 padding wins against all -128
+                            flip = false;
+                        }
+                        // the flip is the char negation: 0 and -128 keep their sign
+                        const float v = y(im);
+                        if (flip && v != 0.0f && v != -128.0f) {
+                            g.flip_bit(bits, off + im);
+                            if (zs) g.flip_bit(bits, off + h + im);
+                        }
+                    }
+                    break;
+                }
                 default: break;
                 }
             };
@@ -500,11 +624,11 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                 // the root's left output still sits untouched in bits[0, N/2)
                 const uint32_t hN = N >> 1;
                 if (off == 0)
-                    run([&](uint32_t i) { return polar_f(ch(i), ch(hN + i)); });
+                    run([&](uint32_t i) { return polar_fx<CH>(ch(i), ch(hN + i)); });
                 else if (P.prog_root_g0r)
-                    run([&](uint32_t i) { return ch(i) + ch(hN + i); });
+                    run([&](uint32_t i) { return addx<CH>(ch(i), ch(hN + i)); });
                 else
-                    run([&](uint32_t i) { return polar_g(ch(i), ch(hN + i), (bits[i >> 5] >> (i & 31u)) & 1u); });
+                    run([&](uint32_t i) { return polar_gx<CH>(ch(i), ch(hN + i), (bits[i >> 5] >> (i & 31u)) & 1u); });
             } else if (ARENA && s >= s0) {
                 const float* xs = ar + n;  // written earlier by this wave, waited for below
                 run([&](uint32_t i) { return xs[i]; });
@@ -534,7 +658,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     float* d = llr + gh;
                     for (uint32_t i = l; i < gh; i += LC) {
                         const uint32_t bi = coff + i;
-                        d[i] = polar_g(X[i], X[gh + i], (bits[bi >> 5] >> (bi & 31u)) & 1u);
+                        d[i] = polar_gx<CH>(X[i], X[gh + i], (bits[bi >> 5] >> (bi & 31u)) & 1u);
                     }
                     fbase = gh;
                 }
@@ -543,7 +667,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     WAVE_SYNC();
                     const float* X = llr + fn;
                     float* d = llr + fh;
-                    for (uint32_t i = l; i < fh; i += LC) d[i] = polar_f(X[i], X[fh + i]);
+                    for (uint32_t i = l; i < fh; i += LC) d[i] = polar_fx<CH>(X[i], X[fh + i]);
                 }
             }
             if (ARENA && (op == SC_F || op == SC_G || op == SC_G0R) && s - 1 >= s0) {
@@ -612,6 +736,16 @@ __global__ void collect_failed_kernel(const uint8_t* ok, uint32_t rows, uint32_t
     }
 }
 
+// float rows for an int8 decoder: _mm256_cvtps_epi32 (round to nearest even) + saturating packs (bitcontainer.cpp:468-503)
+__global__ void f32_to_i8_kernel(const float* in, int8_t* out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = rintf(in[i]);
+        out[i] = (int8_t)(int)(v < -128.0f ? -128.0f : (v > 127.0f ? 127.0f : v));
+    }
+}
+
 // =============================================================================================
 //  launchers
 // =============================================================================================
@@ -630,6 +764,23 @@ hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, uns
                      hipStream_t st, int* occupancy)
 {
     dim3 g(grid), b(64 * waves_per_block);
+    if (P.chr) {  // FastSscFipChar: int8 rows, int8 arithmetic; 16 or 64 lanes per codeword
+        if (!i8 || P.cycles) return hipErrorInvalidValue;
+#define PAMD_SCC_LAUNCH(LCL_, ARENA_, B2_)                                                                            \
+    do {                                                                                                             \
+        auto kern = sc_decode_kernel<LCL_, true, false, ARENA_, B2_, true>;                                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, kern, (int)b.x, lds);          \
+        hipLaunchKernelGGL(kern, g, b, lds, st, P);                                                                  \
+        return hipGetLastError();                                                                                    \
+    } while (0)
+        if (lcl == 4 && P.s0 < P.logN) PAMD_SCC_LAUNCH(4, true, true);
+        if (lcl == 4 && P.logN >= 10) PAMD_SCC_LAUNCH(4, false, true);
+        if (lcl == 4) PAMD_SCC_LAUNCH(4, false, false);
+        if (lcl == 6) PAMD_SCC_LAUNCH(6, false, false);
+#undef PAMD_SCC_LAUNCH
+        return hipErrorInvalidValue;
+    }
     if (lcl == 3)
         return i8 ? launch_sc_k<3, true>(P, g, b, lds, st, occupancy) : launch_sc_k<3, false>(P, g, b, lds, st, occupancy);
     if (lcl == 4 && P.s0 < P.logN && !P.cycles) {  // long blocks: upper LLR stages in the arena
@@ -693,6 +844,13 @@ hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, un
     case 3 * 4 + 2: return launch_scl_inst_3_2(P, i8, diag, g, b, lds, st, occupancy);  // L <= 2: 8 lanes per path, 4 codewords
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(f32_to_i8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,

@@ -86,8 +86,9 @@ struct Wr {
 // 1 << CWL codewords of LCW groups each; a group is BOTH a path buffer (LDS / arena / bit areas, index p) and, at any
 // moment, the home of the path with index pl inside its codeword.  Everything per path is unchanged by CWL; what
 // becomes per codeword is the list management (candidate selection, fork sources), the channel row and the output.
-template <int LPL, bool S64, bool HB, int CWL = 0>
+template <int LPL, bool S64, bool HB, int CWL = 0, bool CHAR = false>
 struct SclCtx {
+    static constexpr bool CH = CHAR;  // int8 ("char") arithmetic: SclFipChar
     using SlotT = std::conditional_t<S64, uint64_t, uint32_t>;
     static constexpr int LP = 1 << LPL;     // lanes per path
     static constexpr int LMAX = 64 >> LPL;  // path groups per wave
@@ -279,7 +280,7 @@ __device__ __forceinline__ void find_weak(const CTX& c, const SRC& x, uint32_t n
 #pragma unroll
     for (int e = 0; e < CNT; ++e) {
         const bool in = (uint32_t)e < n;
-        hv[e] = in ? (fbits(x[in ? e : 0]) & 0x7FFFFFFFu) : INFB;
+        hv[e] = in ? magbits<CTX::CH>(x[in ? e : 0]) : INFB;
         hp[e] = in ? (uint32_t)e : INFB;
     }
     uint32_t tv[CNT], tp[CNT];
@@ -302,7 +303,7 @@ __device__ __forceinline__ void find_weak(const CTX& c, const SRC& x, uint32_t n
                 const uint32_t fb = fbits(e4[e]);
                 sx ^= fb;
                 uint32_t ap = (ch << 2) + (uint32_t)e;
-                uint32_t a = ap >= (uint32_t)CNT ? (fb & 0x7FFFFFFFu) : INFB;
+                uint32_t a = ap >= (uint32_t)CNT ? magbits<CTX::CH>(e4[e]) : INFB;
                 bool placed = false;
 #pragma unroll
                 for (int k = 0; k < CNT; ++k) {  // positions arrive ascending: strict '<' keeps earlier ones first
@@ -1167,25 +1168,28 @@ __device__ __forceinline__ void write_leaf_bits(const CTX& c, const SRC& x, uint
 // "Virtual" stage logN-1: the LLRs right below the root are never stored.  Left child of the root:
 // f(x_i, x_{i+N/2}); right child: g(x_i, x_{i+N/2}, u_i) with u = the root's left-child bits of the path (held by
 // the path buffer its slot word names).  Four consecutive values from two 16-byte channel loads.
-template <bool I8>
+template <bool I8, bool CH = false>
 __device__ __forceinline__ float4 virt_top4(const void* chan, uint32_t halfN, uint32_t i, bool right, const uint32_t* rootleft)
 {
     const Rd<I8 ? K_GI8 : K_GF32> x{ chan };
     const float4 a = x.ld4(i), b = x.ld4(halfN + i);
     if (right) {
         const uint32_t u = (rootleft[i >> 5] >> (i & 31u)) & 0xFu;
-        return make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u), polar_g(a.z, b.z, (u >> 2) & 1u),
-                           polar_g(a.w, b.w, u >> 3));
+        return make_float4(polar_gx<CH>(a.x, b.x, u & 1u), polar_gx<CH>(a.y, b.y, (u >> 1) & 1u), polar_gx<CH>(a.z, b.z, (u >> 2) & 1u),
+                           polar_gx<CH>(a.w, b.w, u >> 3));
     }
-    return make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z), polar_f(a.w, b.w));
+    return make_float4(polar_fx<CH>(a.x, b.x), polar_fx<CH>(a.y, b.y), polar_fx<CH>(a.z, b.z), polar_fx<CH>(a.w, b.w));
 }
 
 // 4 waves per SIMD (<= 128 VGPRs) for the L <= 8 production kernels: occupancy is what hides the LDS / arena latency
-template <int LPL, bool I8, bool S64, bool DIAG, bool HB, int CWL>
+// IN: 0 = fp32 channel rows, 1 = int8 rows widened to float (the float decoder's decode_vector(const char*)), 2 = int8
+// rows AND int8 arithmetic (SclFipChar)
+template <int LPL, int IN, bool S64, bool DIAG, bool HB, int CWL>
 // (at most 128 VGPRs for the kernels that reach 16 waves per CU; capping at 96 for 20 waves measured slower: spills)
 __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void scl_decode_kernel(DecodeParams P)
 {
-    using Ctx = SclCtx<LPL, S64, HB, CWL>;
+    constexpr bool I8 = IN != 0, CH = IN == 2;
+    using Ctx = SclCtx<LPL, S64, HB, CWL, CH>;
     constexpr int LCW = Ctx::LCW;  // path groups per codeword
     constexpr int CW = Ctx::CW;    // codewords per wave
     constexpr int LP = Ctx::LP;
@@ -1339,56 +1343,56 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         const float a0 = X[c.j], b0 = X[8 + c.j], a1 = X[4 + c.j], b1 = X[12 + c.j];
                         float v0, v1;
                         if (grand == 1) {
-                            v0 = polar_f(a0, b0);
-                            v1 = polar_f(a1, b1);
+                            v0 = polar_fx<CH>(a0, b0);
+                            v1 = polar_fx<CH>(a1, b1);
                         } else if (grand == 2) {
                             const uint32_t lw = (c.area(0, c.p) + woff(3))[0];
-                            v0 = polar_g(a0, b0, (lw >> c.j) & 1u);
-                            v1 = polar_g(a1, b1, (lw >> (c.j + 4)) & 1u);
+                            v0 = polar_gx<CH>(a0, b0, (lw >> c.j) & 1u);
+                            v1 = polar_gx<CH>(a1, b1, (lw >> (c.j + 4)) & 1u);
                         } else {
                             float acc[NACC];
 #pragma unroll
                             for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
-                            acc[0] = acc[0] + min0(polar_f(a0, b0));
-                            if constexpr (NACC > 1) acc[1] = acc[1] + min0(polar_f(a1, b1));
+                            acc[0] = acc[0] + min0(polar_fx<CH>(a0, b0));
+                            if constexpr (NACC > 1) acc[1] = acc[1] + min0(polar_fx<CH>(a1, b1));
                             const float sum = c.lanesum_finish(acc);
                             if (active) {
                                 c.metric = c.metric + sum;
                                 if (c.j == 0) (c.area(0, c.p) + woff(3))[0] = 0u;
                             }
-                            v0 = a0 + b0;
-                            v1 = a1 + b1;
+                            v0 = addx<CH>(a0, b0);
+                            v1 = addx<CH>(a1, b1);
                         }
                         if (active) {
                             d[c.j] = v0;
                             d[c.j + 4] = v1;
                         }
                         c.slot = (c.slot & ~(FM << gsh)) | ((typename Ctx::SlotT)c.pl << gsh);
-                        x0 = polar_f(v0, v1);
+                        x0 = polar_fx<CH>(v0, v1);
                         x1 = 0.0f;
                     } else
                     if (pro == 1) {  // SCL_F_S
                         const float* X = c.path_llr(c.p) + 2 * n;
-                        x0 = polar_f(X[i0], X[n + i0]);
-                        x1 = polar_f(X[i1], X[n + i1]);
+                        x0 = polar_fx<CH>(X[i0], X[n + i0]);
+                        x1 = polar_fx<CH>(X[i1], X[n + i1]);
                     } else if (pro == 2) {  // SCL_G_S
                         const uint32_t srcq = (uint32_t)c.g0 + ((uint32_t)(c.slot >> psh) & (uint32_t)(LCW - 1));
                         const float* X = c.path_llr(srcq) + 2 * n;
                         const uint32_t lw = (c.area(0, c.p) + woff(s))[0];
-                        x0 = polar_g(X[i0], X[n + i0], (lw >> i0) & 1u);
-                        x1 = polar_g(X[i1], X[n + i1], (lw >> i1) & 1u);
+                        x0 = polar_gx<CH>(X[i0], X[n + i0], (lw >> i0) & 1u);
+                        x1 = polar_gx<CH>(X[i1], X[n + i1], (lw >> i1) & 1u);
                     } else {  // SCL_F_S, SCL_R0 on its output (:316-337, no fork), SCL_G_S with all-zero left bits
                         const float* X = c.path_llr(c.p) + 2 * n;
                         const float a0 = X[i0], b0 = X[n + i0], a1 = X[i1], b1 = X[n + i1];
                         float acc[NACC];
 #pragma unroll
                         for (int a = 0; a < NACC; ++a) acc[a] = 0.0f;
-                        acc[0] = acc[0] + (in0 ? min0(polar_f(a0, b0)) : 0.0f);
-                        if constexpr (NACC > 1) acc[1] = acc[1] + (in1 ? min0(polar_f(a1, b1)) : 0.0f);
+                        acc[0] = acc[0] + (in0 ? min0(polar_fx<CH>(a0, b0)) : 0.0f);
+                        if constexpr (NACC > 1) acc[1] = acc[1] + (in1 ? min0(polar_fx<CH>(a1, b1)) : 0.0f);
                         const float sum = c.lanesum_finish(acc);
                         if (active) c.metric = c.metric + sum;
-                        x0 = a0 + b0;
-                        x1 = a1 + b1;
+                        x0 = addx<CH>(a0, b0);
+                        x1 = addx<CH>(a1, b1);
                     }
                     c.slot = (c.slot & ~(FM << psh)) | ((typename Ctx::SlotT)c.pl << psh);
                 }
@@ -1455,7 +1459,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         const bool in0 = (uint32_t)c.j < n, in1 = n == 8;
                         float x0, x1;
                         leaf_input4(x0, x1);
-                        const uint32_t a0 = in0 ? (fbits(x0) & 0x7FFFFFFFu) : INFB, a1 = in1 ? (fbits(x1) & 0x7FFFFFFFu) : INFB;
+                        const uint32_t a0 = in0 ? magbits<CH>(x0) : INFB, a1 = in1 ? magbits<CH>(x1) : INFB;
                         const uint64_t sg0 = ballot64(in0 && sgn(x0)), sg1 = ballot64(in1 && sgn(x1));
                         signword = ((uint32_t)(sg0 >> c.base) & 0xFu) | (((uint32_t)(sg1 >> c.base) & 0xFu) << 4);
                         if (spc) {
@@ -1487,7 +1491,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         const bool in = (uint32_t)c.j < n;
                         float xj, xunused;
                         leaf_input4(xj, xunused);
-                        const uint32_t a = in ? (fbits(xj) & 0x7FFFFFFFu) : INFB;
+                        const uint32_t a = in ? magbits<CH>(xj) : INFB;
                         const uint64_t sg = ballot64(in && sgn(xj));
                         signword = (uint32_t)(sg >> c.base) & 0xFFu;
                         if (spc) {
@@ -1700,10 +1704,10 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         const Wr<K_LDS> dw{ d };
                         for (uint32_t i = 4u * (uint32_t)c.j; i < h; i += 4u * LP) {
                             const float4 a = xr.ld4(i), b = xr.ld4(h + i);
-                            dw.st4(i, make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z), polar_f(a.w, b.w)));
+                            dw.st4(i, make_float4(polar_fx<CH>(a.x, b.x), polar_fx<CH>(a.y, b.y), polar_fx<CH>(a.z, b.z), polar_fx<CH>(a.w, b.w)));
                         }
                     } else {
-                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_f(x[i], x[h + i]);
+                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_fx<CH>(x[i], x[h + i]);
                     }
                 }
                 c.slot = (c.slot & ~((typename Ctx::SlotT)(LCW - 1) << fsh)) | ((typename Ctx::SlotT)c.pl << fsh);
@@ -1719,11 +1723,11 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         for (uint32_t i = 4u * (uint32_t)c.j; i < h; i += 4u * LP) {
                             const float4 a = xr.ld4(i), b = xr.ld4(h + i);
                             const uint32_t u = lw >> i;
-                            dw.st4(i, make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
-                                                  polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, (u >> 3) & 1u)));
+                            dw.st4(i, make_float4(polar_gx<CH>(a.x, b.x, u & 1u), polar_gx<CH>(a.y, b.y, (u >> 1) & 1u),
+                                                  polar_gx<CH>(a.z, b.z, (u >> 2) & 1u), polar_gx<CH>(a.w, b.w, (u >> 3) & 1u)));
                         }
                     } else {
-                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_g(x[i], x[h + i], (lw >> i) & 1u);
+                        for (uint32_t i = c.j; i < h; i += LP) d[i] = polar_gx<CH>(x[i], x[h + i], (lw >> i) & 1u);
                     }
                 }
                 c.slot = (c.slot & ~((typename Ctx::SlotT)(LCW - 1) << fsh)) | ((typename Ctx::SlotT)c.pl << fsh);
@@ -1739,15 +1743,15 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
                         for (uint32_t i = v; i < h; i += 8) {
                             const float xa = x[i], xb = x[h + i];
-                            acc[a] = acc[a] + min0(polar_f(xa, xb));
-                            if constexpr (LP <= 8) d[i] = xa + xb;
+                            acc[a] = acc[a] + min0(polar_fx<CH>(xa, xb));
+                            if constexpr (LP <= 8) d[i] = addx<CH>(xa, xb);
                         }
                         if (v >= h) acc[a] = acc[a] + 0.0f;
                     }
                 }
                 if constexpr (LP > 8) {
                     if (active)
-                        for (uint32_t i = c.j; i < h; i += LP) d[i] = x[i] + x[h + i];
+                        for (uint32_t i = c.j; i < h; i += LP) d[i] = addx<CH>(x[i], x[h + i]);
                 }
                 const float sum = c.lanesum_finish(acc);
                 if (active) {
@@ -1795,9 +1799,9 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         const uint32_t holder = c.field(c.slot_from_lane((int)(q << LPL)), logN, q);
                         if (in) {
                             const uint32_t* rl = c.bits(0, holder, logN - 1);
-                            const float4 a = virt_top4<I8>(chan_of(ct), N >> 1, i, right, rl), b = virt_top4<I8>(chan_of(ct), N >> 1, h + i, right, rl);
-                            const float4 r = make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z),
-                                                         polar_f(a.w, b.w));
+                            const float4 a = virt_top4<I8, CH>(chan_of(ct), N >> 1, i, right, rl), b = virt_top4<I8, CH>(chan_of(ct), N >> 1, h + i, right, rl);
+                            const float4 r = make_float4(polar_fx<CH>(a.x, b.x), polar_fx<CH>(a.y, b.y), polar_fx<CH>(a.z, b.z),
+                                                         polar_fx<CH>(a.w, b.w));
                             if (dst_arena)
                                 Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
                             else
@@ -1816,8 +1820,8 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                             const uint32_t q = item_group(e >> ish, ct), i = (e & (ipp - 1)) << 2;
                             const Rd<SK> x{ (SK == K_GI8 || s == logN) ? chan_of(ct) : c.template src_base<SK>(s, q) };
                             const float4 a = x.ld4(i), b = x.ld4(h + i);
-                            const float4 r = make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z),
-                                                         polar_f(a.w, b.w));
+                            const float4 r = make_float4(polar_fx<CH>(a.x, b.x), polar_fx<CH>(a.y, b.y), polar_fx<CH>(a.z, b.z),
+                                                         polar_fx<CH>(a.w, b.w));
                             if (dst_arena)
                                 Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
                             else
@@ -1827,7 +1831,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 } else if (active) {  // (stages in LDS normally run as SCL_F_S)
                     c.template with_src<I8>(s, c.p, [&](auto x) {
                         c.with_dst(s - 1, c.p, [&](auto d) {
-                            for (uint32_t i = c.j; i < h; i += LP) d.set(i, polar_f(x[i], x[h + i]));
+                            for (uint32_t i = c.j; i < h; i += LP) d.set(i, polar_fx<CH>(x[i], x[h + i]));
                         });
                     });
                 }
@@ -1850,10 +1854,10 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                         const uint32_t holder = c.field(c.slot_from_lane((int)(q << LPL)), logN, q);
                         if (in) {
                             const uint32_t* rl = c.bits(0, holder, logN - 1);
-                            const float4 a = virt_top4<I8>(chan_of(ct), N >> 1, i, right, rl), b = virt_top4<I8>(chan_of(ct), N >> 1, h + i, right, rl);
+                            const float4 a = virt_top4<I8, CH>(chan_of(ct), N >> 1, i, right, rl), b = virt_top4<I8, CH>(chan_of(ct), N >> 1, h + i, right, rl);
                             const uint32_t u = (c.bits(0, q, s - 1)[i >> 5] >> (i & 31u)) & 0xFu;
-                            const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
-                                                         polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, u >> 3));
+                            const float4 r = make_float4(polar_gx<CH>(a.x, b.x, u & 1u), polar_gx<CH>(a.y, b.y, (u >> 1) & 1u),
+                                                         polar_gx<CH>(a.z, b.z, (u >> 2) & 1u), polar_gx<CH>(a.w, b.w, u >> 3));
                             if (dst_arena)
                                 Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
                             else
@@ -1877,8 +1881,8 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                                 const Rd<SK> x{ (SK == K_GI8 || s == logN) ? chan_of(ct) : c.template src_base<SK>(s, srcq) };
                                 const float4 a = x.ld4(i), b = x.ld4(h + i);
                                 const uint32_t u = (c.bits(0, q, s - 1)[i >> 5] >> (i & 31u)) & 0xFu;
-                                const float4 r = make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
-                                                             polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, u >> 3));
+                                const float4 r = make_float4(polar_gx<CH>(a.x, b.x, u & 1u), polar_gx<CH>(a.y, b.y, (u >> 1) & 1u),
+                                                             polar_gx<CH>(a.z, b.z, (u >> 2) & 1u), polar_gx<CH>(a.w, b.w, u >> 3));
                                 if (dst_arena)
                                     Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(i, r);
                                 else
@@ -1892,7 +1896,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                     c.template with_src<I8>(s, srcq, [&](auto x) {
                         c.with_dst(s - 1, c.p, [&](auto d) {
                             for (uint32_t i = c.j; i < h; i += LP)
-                                d.set(i, polar_g(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u));
+                                d.set(i, polar_gx<CH>(x[i], x[h + i], (lb[i >> 5] >> (i & 31u)) & 1u));
                         });
                     });
                 }
@@ -1977,9 +1981,17 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
 #pragma unroll
                         for (int a = 0; a < NACC; ++a) {
                             const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
-                            const float xv = v < n ? x[v < n ? v : 0] : 0.0f;
-                            az[a] = az[a] + min0(xv);
-                            ao[a] = ao[a] + max0(xv);
+                            if constexpr (CH) {  // SclFipChar: repetition leaves of every size (scl_fip_char.cpp:762-764), exact sums
+                                for (uint32_t i = v; i < n; i += 8) {
+                                    const float xv = x[i];
+                                    az[a] = az[a] + min0(xv);
+                                    ao[a] = ao[a] + max0(xv);
+                                }
+                            } else {
+                                const float xv = v < n ? x[v < n ? v : 0] : 0.0f;
+                                az[a] = az[a] + min0(xv);
+                                ao[a] = ao[a] + max0(xv);
+                            }
                         }
                     };
                     if (s < c.s0 && s < logN)
@@ -1987,7 +1999,10 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                     else
                         c.template with_src<I8>(s, c.p, body);
                 }
-                const float z = c.lanesum_low4(az), o = c.lanesum_low4(ao);  // (n <= 4; min0 / max0 never yield -0.0)
+                // (float: n <= 4, and min0 / max0 never yield -0.0, so the four trailing additions of the reference's order
+                //  are dropped; int8: sums of integers, any order)
+                const float z = (CH && n > 4) ? c.lanesum_finish(az) : c.lanesum_low4(az);
+                const float o = (CH && n > 4) ? c.lanesum_finish(ao) : c.lanesum_low4(ao);
                 constexpr int CPL = (2 >> LPL) ? (2 >> LPL) : 1;
                 float val[CPL];
 #pragma unroll
@@ -2018,7 +2033,13 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 if ((uint32_t)c.pl < c.P) {
                     c.metric = nval;
                     c.slot = nslot;
-                    leaf_bits_out(c.j == 0, q ? ((1u << n) - 1u) : 0u);
+                    if (CH && !(kFuse && fuse)) {  // blocks of any size: n identical bits
+                        uint32_t* ob = c.bits(side, c.p, s);
+                        const uint32_t nw = n >= 32 ? (n >> 5) : 1u, pat = q ? (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u)) : 0u;
+                        for (uint32_t w = c.j; w < nw; w += LP) ob[w] = pat;
+                    } else {
+                        leaf_bits_out(c.j == 0, q ? ((1u << n) - 1u) : 0u);
+                    }
                 }
             } else if (ins.op == SCL_SPC) {
                 fork_leaf(std::true_type{}, std::false_type{});
@@ -2041,11 +2062,11 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                     const uint32_t wi = ci >> 5, wsh = ci & 31u;  // (h = 256 is a multiple of 32: chunk ci + h has the same shift)
                     const uint32_t wo_root = woff(logN - 1) - c.wsb + wi, wo_u = woff(s - 1) - c.wsb + wi;
                     auto f4 = [](float4 a, float4 b) {
-                        return make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z), polar_f(a.w, b.w));
+                        return make_float4(polar_fx<CH>(a.x, b.x), polar_fx<CH>(a.y, b.y), polar_fx<CH>(a.z, b.z), polar_fx<CH>(a.w, b.w));
                     };
                     auto g4 = [](float4 a, float4 b, uint32_t u) {
-                        return make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u),
-                                           polar_g(a.z, b.z, (u >> 2) & 1u), polar_g(a.w, b.w, (u >> 3) & 1u));
+                        return make_float4(polar_gx<CH>(a.x, b.x, u & 1u), polar_gx<CH>(a.y, b.y, (u >> 1) & 1u),
+                                           polar_gx<CH>(a.z, b.z, (u >> 2) & 1u), polar_gx<CH>(a.w, b.w, (u >> 3) & 1u));
                     };
                     for (uint32_t t = 0; t < (uint32_t)CW; ++t) {
                         const void* chp = chanv[0];
@@ -2217,10 +2238,10 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
 //  launchers
 // =============================================================================================
 // occ != nullptr: do not launch, report the resident workgroups per CU for this block size / LDS size in *occ
-template <int LPL, bool I8, bool S64, bool DIAG, bool HB, int CWL>
+template <int LPL, int IN, bool S64, bool DIAG, bool HB, int CWL>
 static hipError_t launch_scl_k(const DecodeParams& P, dim3 grid, dim3 block, size_t lds, hipStream_t st, int* occ)
 {
-    auto kern = scl_decode_kernel<LPL, I8, S64, DIAG, HB, CWL>;
+    auto kern = scl_decode_kernel<LPL, IN, S64, DIAG, HB, CWL>;
     if (occ) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kern, (int)block.x, lds);
@@ -2258,28 +2279,29 @@ static hipError_t launch_scl_t(const DecodeParams& P, bool i8, bool diag, dim3 g
     if (diag && !i8) {  // (diagnostic variant: the slot word of the production kernel where it exists)
         constexpr bool DS64 = fb > 3;
         if (slot64 && !DS64) return hipErrorInvalidValue;
-        return launch_scl_k<LPL, false, DS64, true, true, CWL>(P, grid, block, lds, st, occ);
+        return launch_scl_k<LPL, 0, DS64, true, true, CWL>(P, grid, block, lds, st, occ);
     }
 #else
     if (diag) return hipErrorInvalidValue;  // (trace / cycle stamps / ablation: diagnostic build only)
 #endif
+    // input kind (template parameter IN of the kernel): 0 fp32 rows, 1 int8 rows widened, 2 int8 rows + int8 arithmetic
+    const int in = P.chr ? 2 : (i8 ? 1 : 0);
+    if (P.chr && !i8) return hipErrorInvalidValue;  // (the int8 decoders read int8 rows; float rows are converted first)
+#define PAMD_SCL_LAUNCH(S64_, HB_)                                                                       \
+    return in == 2 ? launch_scl_k<LPL, 2, S64_, false, HB_, CWL>(P, grid, block, lds, st, occ)           \
+         : in == 1 ? launch_scl_k<LPL, 1, S64_, false, HB_, CWL>(P, grid, block, lds, st, occ)           \
+                   : launch_scl_k<LPL, 0, S64_, false, HB_, CWL>(P, grid, block, lds, st, occ)
     if constexpr (fb <= 3) {
-        if (!slot64 && !hb)
-            return i8 ? launch_scl_k<LPL, true, false, false, false, CWL>(P, grid, block, lds, st, occ)
-                      : launch_scl_k<LPL, false, false, false, false, CWL>(P, grid, block, lds, st, occ);
-        if (!slot64)
-            return i8 ? launch_scl_k<LPL, true, false, false, true, CWL>(P, grid, block, lds, st, occ)
-                      : launch_scl_k<LPL, false, false, false, true, CWL>(P, grid, block, lds, st, occ);
+        if (!slot64 && !hb) PAMD_SCL_LAUNCH(false, false);
+        if (!slot64) PAMD_SCL_LAUNCH(false, true);
     }
     if constexpr (fb <= 2) {  // log2(N) * fb <= 32 for every supported N: no 64-bit variant needed
         return hipErrorInvalidValue;
     } else {
-        if (hb)
-            return i8 ? launch_scl_k<LPL, true, true, false, true, CWL>(P, grid, block, lds, st, occ)
-                      : launch_scl_k<LPL, false, true, false, true, CWL>(P, grid, block, lds, st, occ);
-        return i8 ? launch_scl_k<LPL, true, true, false, false, CWL>(P, grid, block, lds, st, occ)
-                  : launch_scl_k<LPL, false, true, false, false, CWL>(P, grid, block, lds, st, occ);
+        if (hb) PAMD_SCL_LAUNCH(true, true);
+        PAMD_SCL_LAUNCH(true, false);
     }
+#undef PAMD_SCL_LAUNCH
 }
 
 }  // namespace pamd

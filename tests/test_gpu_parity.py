@@ -28,7 +28,7 @@ def _decoder(fx, device=0):
 
 def _rows(fx):
     """the fixture's rows as the reference received them: float32, or int8 through decode_vector(const char*)"""
-    return fx.llr.astype(np.int8) if fx.i8_input else fx.llr
+    return fx.llr.astype(np.int8) if (fx.i8_input or fx.dectype == "char") else fx.llr
 
 
 def _check_metrics(got, ref, npaths, name):
@@ -42,7 +42,7 @@ def _check_metrics(got, ref, npaths, name):
 def test_hip_matches_reference_vectors(built_library, path):
     for fx in gio.load(path):
         d = _decoder(fx)
-        want_m = fx.L > 1 and fx.dectype == "float"
+        want_m = fx.L > 1 and fx.dectype in ("float", "char")
         res = d.decode_batch(_rows(fx), return_metrics=want_m)
         assert np.array_equal(res[0], fx.out), fx.name
         assert np.array_equal(res[1].astype(np.uint8), fx.ok), fx.name
@@ -470,3 +470,72 @@ def test_release_library_reads_no_environment(built_library, monkeypatch):
         assert b"PCD_" not in f.read()
 
 
+
+
+# ---- int8 ("char") decoders: FastSscFipChar / SclFipChar -------------------------------------------------------
+def test_char_round_trip_like_polarcodetest(built_library):
+    """test/polarcode/polarcodetest.cpp:45-183: N = 4096, K = 3072 (Bhattacharyya), systematic encode, BPSK to +-1
+    int8, FastSscFipChar and SclFipChar (L = 4, CRC-32) must return the information word."""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    N, K = 4096, 3072
+    frozen = frozen_bits(N, K, 0.0, "BB")
+    rng = np.random.default_rng(5489)
+    for L, crc in ((1, 8), (4, 32)):
+        info = rng.integers(0, 256, (16, K // 8), dtype=np.uint8)
+        enc = pypolar_amd.PolarEncoder(N, frozen)
+        enc.setErrorDetection(crc, "crc")
+        code = enc.encode_batch(info)                      # (fills the checksum field of `info`)
+        sig = (1 - 2 * np.unpackbits(code, axis=1).astype(np.int16)).astype(np.int8)   # bpskModulate :27-41
+        d = pypolar_amd.PolarDecoder(N, L, frozen, "char")
+        d.setErrorDetection(crc, "crc")
+        out, ok = d.decode_batch(sig)
+        assert ok.all() and np.array_equal(out, info)
+        assert np.array_equal(d.decode_vector(sig[0]), info[0])
+
+
+@pytest.mark.parametrize("N,L", [(64, 1), (64, 4), (256, 8), (1024, 1), (1024, 8), (2048, 2), (512, 16), (4096, 1)])
+def test_char_decoders_vs_oracle_random(built_library, N, L):
+    """seeded int8 rows (full range incl. -128 and 0, clipped Gaussians, +-1) on Bhattacharyya and random frozen sets"""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    rng = np.random.default_rng(N * 131 + L)
+    sets = [frozen_bits(N, N // 2, 0.0, "BB"), frozen_bits(N, (N // 4) // 8 * 8 or 8, 0.0, "BE"),
+            np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32)]
+    for frozen in sets:
+        K = N - len(frozen)
+        det = 8 if K >= 16 and K % 8 == 0 else 0
+        rows = np.concatenate([
+            rng.integers(-128, 128, (24, N)),
+            np.clip(np.rint(rng.normal(6.0, 9.0, (24, N))), -128, 127),
+            np.clip(np.rint(rng.normal(40.0, 60.0, (24, N))), -128, 127),
+            rng.choice([-1, 0, 1], (16, N)),
+        ]).astype(np.int8)
+        d = pypolar_amd.PolarDecoder(N, L, frozen, "char")
+        d.setErrorDetection(det, "crc")
+        res = d.decode_batch(rows, return_metrics=L > 1)
+        e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, det, rows.astype(np.float32), True, "char")
+        assert np.array_equal(res[0], e_out), (N, L, K)
+        assert np.array_equal(res[1].astype(np.uint8), e_ok), (N, L, K)
+        if L > 1:
+            assert np.array_equal(res[2], e_met), (N, L, K)      # exact integers
+        d.setSystematic(False)
+        res = d.decode_batch(rows[:32])
+        e_out, e_ok, _ = ob.decode_batch(N, L, frozen, det, rows[:32].astype(np.float32), False, "char")
+        assert np.array_equal(res[0], e_out) and np.array_equal(res[1].astype(np.uint8), e_ok), (N, L, K, "nsys")
+
+
+def test_char_decoder_float_rows_are_converted_like_the_reference(built_library):
+    """CharContainer::insertLlr(const float*) bitcontainer.cpp:505-516 (N >= 8): round to nearest EVEN, saturate"""
+    import pypolar_amd
+    fx = gio.load_named("cfg3_n1024_k512_l8_crc24_awgn.bin")
+    x = (fx.llr[:32] * 9.5).astype(np.float32)
+    x[0, :8] = [0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 300.0, -300.0]
+    conv = np.clip(np.rint(x), -128, 127).astype(np.int8)        # np.rint rounds half to even
+    d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, "char")
+    d.setErrorDetection(fx.crc_size, fx.crc_type)
+    a = d.decode_batch(x)
+    b = d.decode_batch(conv)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    e_out, e_ok, _ = ob.decode_batch(fx.N, fx.L, fx.frozen, fx.crc_size, conv.astype(np.float32), True, "char")
+    assert np.array_equal(a[0], e_out) and np.array_equal(a[1].astype(np.uint8), e_ok)

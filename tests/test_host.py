@@ -99,8 +99,8 @@ def test_error_mapping(built_library):
     F = _frozen("cfg1_n64_k40_sc_awgn.bin")
     with pytest.raises(RuntimeError, match="Unknown PolarDecoder type!"):
         pypolar_amd.PolarDecoder(64, 1, F, "bogus")
-    with pytest.raises(NotImplementedError):
-        pypolar_amd.PolarDecoder(64, 1, F, "char")
+    assert pypolar_amd.PolarDecoder(64, 1, F, "char").listSize() == 1     # FastSscFipChar (decoder.cpp:65-67)
+    assert pypolar_amd.PolarDecoder(64, 4, F, "Char").listSize() == 4     # SclFipChar (type strings are lower-cased)
     with pytest.raises(NotImplementedError):
         pypolar_amd.PolarDecoder(64, 4, F, "scan")
     with pytest.raises(ValueError):
