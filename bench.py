@@ -94,6 +94,11 @@ CONFIGS = {
                  name="N=1024 K=512 SC, batch=2^20"),
     "cfg3": dict(N=1024, K=512, L=8, dsnr=0.0, crc=24, crc_type="crcnr", ebn0=2.0, log2_batch=20,
                  name="N=1024 K=512 SCL L=8 + CRC-24C, batch=2^20"),
+    # the int8 ("char") decoders: int8 rows = round(8 y) clipped to +-127, 1 byte per LLR from HBM
+    "cfg3_i8": dict(N=1024, K=512, L=8, dsnr=0.0, crc=24, crc_type="crcnr", ebn0=2.0, log2_batch=20, dectype="char",
+                    name="N=1024 K=512 SclFipChar (int8) L=8 + CRC-24C, batch=2^20"),
+    "cfg2_i8": dict(N=1024, K=512, L=1, dsnr=0.0, crc=0, crc_type="crc", ebn0=2.5, log2_batch=20, dectype="char",
+                    name="N=1024 K=512 FastSscFipChar (int8) SC, batch=2^20"),
     # the 8-GPU configurations of SURVEY 8(d), runnable per GPU (weak scaling: the batch below is per GPU)
     "cfg4": dict(N=1024, K=176, L=8, dsnr=0.0, crc=11, crc_type="crcnr", ebn0=1.0, log2_batch=19, ctor="5G",
                  name="5G-table N=1024 K=176 SCL L=8 + CRC-11, batch=2^19 per GPU (2^22 over 8)"),
@@ -337,7 +342,8 @@ def cpu_baseline(cfg, seconds):
     if os.path.exists(harness):
         try:
             out = subprocess.run([harness, "time", str(cfg["N"]), str(cfg["K"]), str(cfg["L"]), cfg.get("ctor", "BB"), str(cfg["dsnr"]),
-                                  str(cfg["crc"]), cfg["crc_type"], str(cfg["ebn0"]), str(rows), str(cores), str(seconds)],
+                                  str(cfg["crc"]), cfg["crc_type"], str(cfg["ebn0"]), str(rows), str(cores), str(seconds)]
+                                 + (["char"] if cfg.get("dectype") == "char" else []),
                                  capture_output=True, text=True, timeout=seconds * 6 + 120, check=True)
             r = json.loads(out.stdout.strip().splitlines()[-1])
             return {"value": r["cw_per_s"], "unit": "codewords/s", "cores": cores, "kind": "reference",
@@ -350,9 +356,11 @@ def cpu_baseline(cfg, seconds):
     frozen = config_frozen_set(cfg)
     rng = np.random.default_rng(0)
     llr = rng.normal(1.0, 0.8, (256, cfg["N"])).astype(np.float32)
+    if cfg.get("dectype") == "char":
+        llr = np.clip(np.rint(llr * 8.0), -127, 127).astype(np.float32)
     t0, n = time.time(), 0
     while time.time() - t0 < seconds:
-        ob.decode_batch(cfg["N"], cfg["L"], frozen, cfg["crc"], llr)
+        ob.decode_batch(cfg["N"], cfg["L"], frozen, cfg["crc"], llr, True, cfg.get("dectype", "float"))
         n += llr.shape[0]
     el = time.time() - t0
     return {"value": n / el, "unit": "codewords/s", "cores": 1, "kind": "port",
@@ -439,10 +447,13 @@ def main():
     N, K, L = cfg["N"], cfg["K"], cfg["L"]
     nb = (K + 7) // 8
     frozen = config_frozen_set(cfg)
-    dec = pypolar_amd.PolarDecoder(N, L, frozen, "float", device=dev_index)
+    chr_dec = cfg.get("dectype") == "char"
+    dec = pypolar_amd.PolarDecoder(N, L, frozen, "char" if chr_dec else "float", device=dev_index)
     dec.setErrorDetection(cfg["crc"], cfg["crc_type"])
 
     llr, info = make_batch(cfg, frozen, B, dev, seed=1234 + rank)
+    if chr_dec:  # int8 rows resident in HBM: round(8 y), clipped to +-127
+        llr = torch.clamp(torch.round(llr * 8.0), -127, 127).to(torch.int8)
     out = torch.empty((B, nb), dtype=torch.uint8, device=dev)
     ok = torch.empty((B,), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
@@ -514,14 +525,14 @@ def main():
         cw_s = total_cw / elapsed
         payload_bits = K - cfg["crc"] if cfg["crc"] != 11 else K - 16
         k_ms = float(np.mean(kms)) if len(kms) else float("nan")
-        bytes_per_cw = 4 * N + nb                    # fp32 row in + packed bytes out
+        bytes_per_cw = (N if chr_dec else 4 * N) + nb   # fp32 (int8: SURVEY 8f-3) row in + packed bytes out
         achieved = bytes_per_cw * B / (k_ms * 1e-3) / 1e9
         res = {
             "metric": "codewords/sec + info-Gbit/s, N=1024 K=512 SCL L=8, batch=2^20" if args.config == "cfg3"
                       else f"codewords/sec + info-Gbit/s, {cfg['name']}",
             "value": cw_s, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "i8" if chr_dec else "f32", "data": "synthetic",
             "config": {"workload": cfg["name"] + (" per GPU" if world > 1 else ""), "block_length": N,
                        "info_bits": K, "list_size": L, "detector": f"{cfg['crc_type']}-{cfg['crc']}",
                        "ebn0_db": cfg["ebn0"], "codewords_per_gpu": B,

@@ -18,7 +18,7 @@
 //         decode_vector(const char*) overload (decoder.cpp:169-181, bitcontainer.cpp:202-207)
 //         writes a golden fixture (format below).  A FRESH decoder object is used for every
 //         codeword (the reference carries mMetric[0] over between calls).
-//   time  N K L ctor dsnr crcsize crctype ebn0_db rows threads seconds
+//   time  N K L ctor dsnr crcsize crctype ebn0_db rows threads seconds [char]
 //         the reference's own CPU throughput: one decoder object per std::thread
 //         (simulator.cpp:95-101), prints one JSON line.
 //   enc   N K ctor dsnr crcsize crctype systematic count seed out.bin
@@ -260,18 +260,23 @@ static int cmd_time(int argc, char** argv)
     const unsigned rows = atoi(argv[10]);
     const unsigned threads = atoi(argv[11]);
     const double seconds = atof(argv[12]);
-    c.dectype = 0;
+    // optional: "char" = the int8 decoders on rows quantised as round(8 y) through decode_vector(const char*)
+    const bool chr = argc > 13 && std::string(argv[13]) == "char";
+    c.dectype = chr ? 3 : 0;
     c.F = Construction::frozen_bits(c.N, c.K, c.dsnr, c.ctor);
     const unsigned nb = (c.K + 7) / 8;
     Encoding::ButterflyFipPacked enc(c.N, c.F);
     enc.setErrorDetection(ErrorDetection::create(c.crcsize, c.crctype));
     Gauss rng(12345);
     std::vector<float> all((size_t)rows * c.N);
+    std::vector<char> all8(chr ? (size_t)rows * c.N : 0);
     std::vector<uint8_t> info;
     std::vector<float> llr;
     for (unsigned r = 0; r < rows; ++r) {
-        make_row(c, enc, rng, "awgn", ebn0_db, info, llr);
+        make_row(c, enc, rng, chr ? "quant" : "awgn", ebn0_db, info, llr);
         memcpy(&all[(size_t)r * c.N], llr.data(), 4 * c.N);
+        if (chr)
+            for (unsigned i = 0; i < c.N; ++i) all8[(size_t)r * c.N + i] = (char)(int)llr[i];
     }
     std::atomic<uint64_t> total(0);
     std::atomic<uint64_t> oks(0);
@@ -284,7 +289,8 @@ static int cmd_time(int argc, char** argv)
             uint64_t n = 0, ok = 0;
             for (;;) {
                 for (unsigned r = t; r < rows; r += threads) {
-                    ok += dec->decode_vector(&all[(size_t)r * c.N], outb.data());
+                    ok += chr ? dec->decode_vector(&all8[(size_t)r * c.N], outb.data())
+                              : dec->decode_vector(&all[(size_t)r * c.N], outb.data());
                     ++n;
                 }
                 const double el = std::chrono::duration<double>(
