@@ -5,10 +5,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "internal.h"
@@ -89,6 +91,13 @@ struct pcd_decoder {
     // staging for host-pointer calls and the mixed decoder
     void* d_in = nullptr;
     size_t d_in_cap = 0;
+    // host-pointer calls: ring of pinned host chunks + device chunks, copy-in / compute streams (decode_host_pipelined)
+    static constexpr int kRing = 3;
+    void* h_ring[kRing] = { nullptr, nullptr, nullptr };
+    void* d_ring[kRing] = { nullptr, nullptr, nullptr };
+    size_t ring_bytes = 0;
+    hipStream_t s_in = nullptr, s_run = nullptr;
+    hipEvent_t ev_h2d[kRing] = { nullptr, nullptr, nullptr }, ev_run[kRing] = { nullptr, nullptr, nullptr };
     int8_t* d_i8 = nullptr;  // int8 decoders called with float rows: CharContainer::insertLlr(const float*) on the device
     size_t d_i8_cap = 0;
     uint8_t* d_out = nullptr;
@@ -743,6 +752,92 @@ int decode_device(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t
     return PCD_OK;
 }
 
+// Host pointers, large batches: the rows are cut into chunks that travel through a ring of PINNED host buffers.  A few
+// host threads copy chunk k + 1 .. k + 2 from the caller's (pageable) memory into the ring while the DMA engine moves
+// chunk k to the device and the decode kernel works on chunk k - 1 -- a copy from pageable memory would be staged by the
+// runtime synchronously and serialise with the kernel.  Results stay on the device until the end (65 bytes per row).
+int decode_host_pipelined(pcd_decoder* d, const void* llr, bool i8, size_t rows, float* dmet)
+{
+    constexpr int R = pcd_decoder::kRing;
+    const size_t row_bytes = (size_t)d->N * (i8 ? 1 : 4);
+    const size_t chunk_rows = std::max<size_t>(1024, ((size_t)32 << 20) / row_bytes);  // 32 MiB per chunk
+    const size_t chunk_bytes = chunk_rows * row_bytes;
+    const size_t nchunks = (rows + chunk_rows - 1) / chunk_rows;
+    int rc;
+    if (d->ring_bytes < chunk_bytes) {
+        for (int b = 0; b < R; ++b) {
+            if (d->h_ring[b]) HIP_TRY(hipHostFree(d->h_ring[b]));
+            if (d->d_ring[b]) HIP_TRY(hipFree(d->d_ring[b]));
+            d->h_ring[b] = d->d_ring[b] = nullptr;
+        }
+        d->ring_bytes = 0;
+        for (int b = 0; b < R; ++b) {
+            HIP_TRY(hipHostMalloc(&d->h_ring[b], chunk_bytes, hipHostMallocDefault));
+            HIP_TRY(hipMalloc(&d->d_ring[b], chunk_bytes));
+        }
+        d->ring_bytes = chunk_bytes;
+    }
+    if (!d->s_in) {
+        HIP_TRY(hipStreamCreateWithFlags(&d->s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&d->s_run, hipStreamNonBlocking));
+        for (int b = 0; b < R; ++b) {
+            HIP_TRY(hipEventCreateWithFlags(&d->ev_h2d[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&d->ev_run[b], hipEventDisableTiming));
+        }
+    }
+    // worker threads: thread t copies slice t of every chunk once the main thread has released the chunk's ring slot
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = std::min(16u, std::max(2u, hw / 2));
+    std::atomic<long> released(-1);
+    std::vector<std::atomic<unsigned>> done(nchunks);
+    for (auto& x : done) x.store(0, std::memory_order_relaxed);
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(llr);
+    auto worker = [&](unsigned t) {
+        for (size_t k = 0; k < nchunks; ++k) {
+            while (released.load(std::memory_order_acquire) < (long)k) std::this_thread::yield();
+            const size_t r0 = k * chunk_rows, nr = std::min(chunk_rows, rows - r0), bytes = nr * row_bytes;
+            const size_t lo = bytes * t / T, hi = bytes * (t + 1) / T;
+            std::memcpy(reinterpret_cast<uint8_t*>(d->h_ring[k % R]) + lo, src + r0 * row_bytes + lo, hi - lo);
+            done[k].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t) pool.emplace_back(worker, t);
+    auto finish = [&](int code) {
+        released.store((long)nchunks, std::memory_order_release);  // let the workers run out
+        for (auto& th : pool) th.join();
+        return code;
+    };
+    const unsigned Lm = std::max(1u, d->L);
+    size_t rel = 0;  // chunks released to the workers so far
+    for (size_t k = 0; k < nchunks; ++k) {
+        const int b = (int)(k % R);
+        const size_t r0 = k * chunk_rows, nr = std::min(chunk_rows, rows - r0);
+        // the workers fill the ring up to R - 1 chunks ahead: a slot is free once the H2D of the chunk that used it
+        // last (R chunks earlier, enqueued in an earlier iteration) has completed
+        while (rel < nchunks && rel < k + (size_t)R) {
+            if (rel >= (size_t)R && hipEventSynchronize(d->ev_h2d[rel % R]) != hipSuccess)
+                return finish(fail(PCD_ERR_HIP, "hipEventSynchronize failed in the host-pointer pipeline"));
+            released.store((long)rel, std::memory_order_release);
+            ++rel;
+        }
+        while (done[k].load(std::memory_order_acquire) < T) std::this_thread::yield();
+        hipError_t e = hipSuccess;
+        if (k >= (size_t)R) e = hipStreamWaitEvent(d->s_in, d->ev_run[b], 0);  // device slot b: its kernel has finished
+        if (e == hipSuccess) e = hipMemcpyAsync(d->d_ring[b], d->h_ring[b], nr * row_bytes, hipMemcpyHostToDevice, d->s_in);
+        if (e == hipSuccess) e = hipEventRecord(d->ev_h2d[b], d->s_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(d->s_run, d->ev_h2d[b], 0);
+        if (e != hipSuccess) return finish(fail(PCD_ERR_HIP, std::string("host-pointer pipeline: ") + hipGetErrorString(e)));
+        if ((rc = decode_device(d, d->d_ring[b], i8, nr, d->d_out + r0 * d->nb, d->d_ok + r0,
+                                dmet ? dmet + r0 * Lm : nullptr, d->s_run)))
+            return finish(rc);
+        if (hipEventRecord(d->ev_run[b], d->s_run) != hipSuccess) return finish(fail(PCD_ERR_HIP, "hipEventRecord failed"));
+    }
+    finish(PCD_OK);
+    HIP_TRY(hipStreamSynchronize(d->s_run));
+    return PCD_OK;
+}
+
 int decode_any(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t* out, uint8_t* ok, float* metrics,
                int mem, void* stream)
 {
@@ -760,6 +855,22 @@ int decode_any(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t* o
     // host pointers: stage through device buffers, synchronous
     const size_t esz = i8 ? 1 : 4;
     const size_t in_bytes = rows * d->N * esz, out_bytes = rows * d->nb;
+    if (in_bytes >= ((size_t)96 << 20) && d->dectype != 2) {
+        // large batch: pinned ring, copies overlapped with the kernels ("mixed" keeps the simple path: its list pass
+        // addresses rows of the whole batch through an index list)
+        if ((rc = grow(d->d_out, d->d_out_cap, out_bytes))) return rc;
+        if ((rc = grow(d->d_ok, d->d_ok_cap, rows))) return rc;
+        float* dm = nullptr;
+        if (metrics) {
+            if ((rc = grow(d->d_met, d->d_met_cap, rows * std::max(1u, d->L) * sizeof(float)))) return rc;
+            dm = d->d_met;
+        }
+        if ((rc = decode_host_pipelined(d, llr, i8, rows, dm))) return rc;
+        HIP_TRY(hipMemcpy(out, d->d_out, out_bytes, hipMemcpyDeviceToHost));
+        if (ok) HIP_TRY(hipMemcpy(ok, d->d_ok, rows, hipMemcpyDeviceToHost));
+        if (metrics) HIP_TRY(hipMemcpy(metrics, dm, rows * std::max(1u, d->L) * sizeof(float), hipMemcpyDeviceToHost));
+        return PCD_OK;
+    }
     if ((rc = grow(d->d_in, d->d_in_cap, in_bytes))) return rc;
     if ((rc = grow(d->d_out, d->d_out_cap, out_bytes))) return rc;
     if ((rc = grow(d->d_ok, d->d_ok_cap, rows))) return rc;
@@ -884,6 +995,14 @@ void pcd_destroy(pcd_decoder* d)
     }
     if (d->d_in) (void)hipFree(d->d_in);
     if (d->d_i8) (void)hipFree(d->d_i8);
+    for (int b = 0; b < pcd_decoder::kRing; ++b) {
+        if (d->h_ring[b]) (void)hipHostFree(d->h_ring[b]);
+        if (d->d_ring[b]) (void)hipFree(d->d_ring[b]);
+        if (d->ev_h2d[b]) (void)hipEventDestroy(d->ev_h2d[b]);
+        if (d->ev_run[b]) (void)hipEventDestroy(d->ev_run[b]);
+    }
+    if (d->s_in) (void)hipStreamDestroy(d->s_in);
+    if (d->s_run) (void)hipStreamDestroy(d->s_run);
     if (d->d_out) (void)hipFree(d->d_out);
     if (d->d_ok) (void)hipFree(d->d_ok);
     if (d->d_met) (void)hipFree(d->d_met);
