@@ -539,3 +539,23 @@ def test_char_decoder_float_rows_are_converted_like_the_reference(built_library)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     e_out, e_ok, _ = ob.decode_batch(fx.N, fx.L, fx.frozen, fx.crc_size, conv.astype(np.float32), True, "char")
     assert np.array_equal(a[0], e_out) and np.array_equal(a[1].astype(np.uint8), e_ok)
+
+
+def test_large_host_batch_goes_through_the_pinned_ring(built_library):
+    """host pointers, >= 96 MiB of rows: pinned-ring pipeline (capi.cpp decode_host_pipelined) -- ragged last chunk,
+    fp32 and int8 rows, metrics; must equal the small-batch path row for row"""
+    fx = gio.load_named("cfg3_n1024_k512_l8_crc24_awgn.bin")
+    d = _decoder(fx)
+    reps = 40000 // fx.count + 1
+    rows = np.tile(fx.llr, (reps, 1))[:40003]                       # 156 MiB of fp32 rows, not a multiple of the chunk
+    out, ok, met = d.decode_batch(rows, return_metrics=True)
+    idx = np.arange(rows.shape[0]) % fx.count
+    assert np.array_equal(out, fx.out[idx]) and np.array_equal(ok.astype(np.uint8), fx.ok[idx])
+    assert np.array_equal(met.view(np.uint32), fx.metrics[idx].view(np.uint32))
+    fq = gio.load_named("i8_cfg3_n1024_k512_l8_crc24.bin")
+    dq = _decoder(fq)
+    reps = 120000 // fq.count + 1
+    rows8 = np.tile(fq.llr.astype(np.int8), (reps, 1))[:120001]     # 117 MiB of int8 rows
+    out, ok = dq.decode_batch(rows8)
+    idx = np.arange(rows8.shape[0]) % fq.count
+    assert np.array_equal(out, fq.out[idx]) and np.array_equal(ok.astype(np.uint8), fq.ok[idx])
