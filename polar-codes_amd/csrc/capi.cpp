@@ -257,7 +257,7 @@ void compute_geometry(pcd_decoder* d)
             best_s0 = hb_s0;
             best_sb = hb_sb;
         }
-        if (const char* dbg = PAMD_ENV("PCD_S0")) best_s0 = std::min(d->logN, std::max(lo, (unsigned)std::atoi(dbg)));  // experiments
+        if (const char* dbg = PAMD_ENV("PCD_S0")) best_s0 = std::min(d->logN, std::max(4u, (unsigned)std::atoi(dbg)));  // experiments
         if (const char* dbg = PAMD_ENV("PCD_SB")) best_sb = std::max(sb_lo, (unsigned)std::atoi(dbg));
         if (best_sb > d->logN) best_sb = d->logN + 1;
         d->s0 = best_s0;
@@ -403,6 +403,26 @@ void specialize_scl(pcd_decoder* d)
                 }
                 in.off = (in.op == pamd::SCL_G ? 1u : 0u) | (k << 1);
                 in.op = pamd::SCL_VTOP;
+            }
+            out.push_back(in);
+        }
+        v.swap(out);
+    }
+    // Wide F / G whose output is read next by the F of the stage below: that F runs on the values in registers
+    // (SCL_WFG, scl_kernel.h) -- every stage is then read once (by its G) instead of twice.  The stage below the output
+    // must still be a plain stored stage (not specialised away later: this pass runs before F_S / G_S are chosen).
+    if (!PAMD_ENV("PCD_NO_WFG")) {
+        auto& v = d->scl_prog.ins;
+        std::vector<pamd::Ins> out;
+        out.reserve(v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            pamd::Ins in = v[i];
+            const bool plain_fg = (in.op == pamd::SCL_F || in.op == pamd::SCL_G) && (in.side & 0xEu) == 0 && in.pad == 0;
+            if (plain_fg && in.stage >= 7 && i + 1 < v.size() && v[i + 1].op == pamd::SCL_F && v[i + 1].stage + 1u == in.stage &&
+                (v[i + 1].side & 0xEu) == 0 && v[i + 1].pad == 0) {
+                in.off = in.op == pamd::SCL_G ? 1u : 0u;
+                in.op = pamd::SCL_WFG;
+                ++i;
             }
             out.push_back(in);
         }

@@ -62,6 +62,11 @@ enum Op : uint8_t {
     // descent applied to the values while they are still in registers (4 lanes per path x 2 codewords, N = 1024).
     // `off`: bit 0 = the op is a G, bits 1-2 = number of fused F levels below (0..2)
     SCL_VTOP,
+    // wide F / G (input not virtual, at least 64 outputs per path) with the F of the stage below applied to its
+    // outputs while they are in registers: a lane takes the chunks i and i + h/2 of the output block, stores both
+    // (the G of the stage below comes back to them) and their f.  Saves one of the two read passes over every arena
+    // stage.  `off` bit 0 = the op is a G.
+    SCL_WFG,
 };
 
 struct Ins {

@@ -2045,6 +2045,50 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 fork_leaf(std::true_type{}, std::false_type{});
             } else if (ins.op == SCL_R1) {
                 fork_leaf(std::false_type{}, std::false_type{});
+            } else if (ins.op == SCL_WFG) {
+                const bool isg = (aux & 1u) != 0;
+                const uint32_t hh = h >> 1, ish = s - 4, ipp = h >> 3, total = (c.P * CW) << ish;
+                c.template with_src_kind<I8>(s, [&](auto KS) {
+                    constexpr int SK = decltype(KS)::value;
+#pragma unroll 2
+                    for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+                        const uint32_t e = e0 + (uint32_t)lane;
+                        const bool in = e < total;
+                        const uint32_t ee = in ? e : 0u;  // (idle lanes load item 0 and store nothing)
+                        uint32_t ct;
+                        const uint32_t q = item_group(ee >> ish, ct), i = (ee & (ipp - 1)) << 2;
+                        uint32_t srcq = q, u0 = 0, u1 = 0;
+                        if (isg) {  // LLR[s] through the slot word (all lanes take part in the move), left bits at identity
+                            srcq = c.field(c.slot_from_lane((int)(q << LPL)), s, q);
+                            const uint32_t* lb = c.bits(0, q, s - 1);
+                            u0 = (lb[i >> 5] >> (i & 31u)) & 0xFu;
+                            u1 = (lb[(hh + i) >> 5] >> (i & 31u)) & 0xFu;
+                        }
+                        const Rd<SK> x{ (SK == K_GI8 || s == logN) ? chan_of(ct) : c.template src_base<SK>(s, srcq) };
+                        const float4 a0 = x.ld4(i), b0 = x.ld4(h + i), a1 = x.ld4(hh + i), b1 = x.ld4(h + hh + i);
+                        float4 r0, r1;
+                        if (isg) {
+                            r0 = make_float4(polar_gx<CH>(a0.x, b0.x, u0 & 1u), polar_gx<CH>(a0.y, b0.y, (u0 >> 1) & 1u),
+                                             polar_gx<CH>(a0.z, b0.z, (u0 >> 2) & 1u), polar_gx<CH>(a0.w, b0.w, u0 >> 3));
+                            r1 = make_float4(polar_gx<CH>(a1.x, b1.x, u1 & 1u), polar_gx<CH>(a1.y, b1.y, (u1 >> 1) & 1u),
+                                             polar_gx<CH>(a1.z, b1.z, (u1 >> 2) & 1u), polar_gx<CH>(a1.w, b1.w, u1 >> 3));
+                        } else {
+                            r0 = make_float4(polar_fx<CH>(a0.x, b0.x), polar_fx<CH>(a0.y, b0.y), polar_fx<CH>(a0.z, b0.z), polar_fx<CH>(a0.w, b0.w));
+                            r1 = make_float4(polar_fx<CH>(a1.x, b1.x), polar_fx<CH>(a1.y, b1.y), polar_fx<CH>(a1.z, b1.z), polar_fx<CH>(a1.w, b1.w));
+                        }
+                        const float4 r2 = make_float4(polar_fx<CH>(r0.x, r1.x), polar_fx<CH>(r0.y, r1.y), polar_fx<CH>(r0.z, r1.z),
+                                                      polar_fx<CH>(r0.w, r1.w));
+                        if (in) {
+                            c.with_dst(s - 1, q, [&](auto d) {
+                                d.st4(i, r0);
+                                d.st4(hh + i, r1);
+                            });
+                            c.with_dst(s - 2, q, [&](auto d) { d.st4(i, r2); });
+                        }
+                    }
+                });
+                c.set_field(s);
+                c.set_field(s - 1);
             } else if (ins.op == SCL_VTOP) {
                 if constexpr (kMerge && !S64 && HB) {
                     // Stage s = logN - 1 block of every live path from the channel row: h = 256 outputs per path = one
@@ -2121,7 +2165,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 }
             }
         op_done:
-            if ((ins.op <= SCL_G || ins.op == SCL_VTOP) && s - 1 >= c.s0 && !(vflags & 2u)) {
+            if ((ins.op <= SCL_G || ins.op == SCL_VTOP || ins.op == SCL_WFG) && s - 1 >= c.s0 && !(vflags & 2u)) {
                 // this op stored LLRs to the global arena: wait for the stores (L2 is the meeting point; the
                 // arena is read back with sc1 loads)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
