@@ -418,11 +418,19 @@ void specialize_scl(pcd_decoder* d)
         for (size_t i = 0; i < v.size(); ++i) {
             pamd::Ins in = v[i];
             const bool plain_fg = (in.op == pamd::SCL_F || in.op == pamd::SCL_G) && (in.side & 0xEu) == 0 && in.pad == 0;
-            if (plain_fg && in.stage >= 7 && i + 1 < v.size() && v[i + 1].op == pamd::SCL_F && v[i + 1].stage + 1u == in.stage &&
-                (v[i + 1].side & 0xEu) == 0 && v[i + 1].pad == 0) {
-                in.off = in.op == pamd::SCL_G ? 1u : 0u;
-                in.op = pamd::SCL_WFG;
-                ++i;
+            if (plain_fg && in.stage >= 7) {
+                // up to kmax F levels; k levels need chunks that are 32 (h >> k) apart to be whole bit words: h >= 32 << k
+                const unsigned kmax = 1u;  // (more levels per instruction measured slower, see scl_kernel.h)
+                unsigned k = 0;
+                while (k < kmax && i + 1 < v.size() && v[i + 1].op == pamd::SCL_F && v[i + 1].stage + 1u + k == in.stage &&
+                       (v[i + 1].side & 0xEu) == 0 && v[i + 1].pad == 0 && (1u << (in.stage - 1)) >= (32u << (k + 1))) {
+                    ++k;
+                    ++i;
+                }
+                if (k) {
+                    in.off = (in.op == pamd::SCL_G ? 1u : 0u) | (k << 1);
+                    in.op = pamd::SCL_WFG;
+                }
             }
             out.push_back(in);
         }

@@ -232,7 +232,6 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
     ScLanes<LCL> g;
     g.l = lane & (LC - 1);
     g.lbase = lane & ~(LC - 1);
-    const int l = g.l;
     const uint32_t slot = (uint32_t)lane >> LCL;
     const uint32_t N = P.N, logN = P.logN;
     const uint32_t nwords = N >= 32 ? (N >> 5) : 1u;
@@ -256,7 +255,15 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                               : (const void*)(reinterpret_cast<const float*>(P.llr) + (size_t)row * N);
 
         uint64_t iw_next = prog64[0];
+        int lane_v = lane;
         for (uint32_t pc = 0;; ++pc) {
+            // the lane number is made opaque once per instruction: lane predicates (64-bit SGPR masks) and other values
+            // derived from it are then re-derived per instruction instead of being hoisted out of the interpreter loop
+            // (the kernel sits at the SGPR limit: hoisted masks were spilled to VGPR lanes)
+            asm volatile("" : "+v"(lane_v));
+            g.l = lane_v & (LC - 1);
+            g.lbase = lane_v & ~(LC - 1);
+            const int l = g.l;
             const uint64_t iw = iw_next;
             const uint32_t op = (uint32_t)(iw & 0xFF);
             if (op == OP_END) break;
@@ -683,6 +690,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
         }
 
         // ---- output: FastSscAvxFloat::decode :940-955 ------------------------------------------
+        const int l = g.l;
         if (!P.systematic) {  // re-encode (butterfly_fip.cpp:15-63) on the packed words
             for (uint32_t w = l; w < nwords; w += LC) {
                 uint32_t v = bits[w];
