@@ -2003,6 +2003,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 //  are dropped; int8: sums of integers, any order)
                 const float z = (CH && n > 4) ? c.lanesum_finish(az) : c.lanesum_low4(az);
                 const float o = (CH && n > 4) ? c.lanesum_finish(ao) : c.lanesum_low4(ao);
+                PAMD_STAMP(0)
                 constexpr int CPL = (2 >> LPL) ? (2 >> LPL) : 1;
                 float val[CPL];
 #pragma unroll
@@ -2027,8 +2028,10 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                     if (!done) select_literal_cw<Ctx, LPL, 2>(c, val, newP, nval, nidx);
                 } else
                 select_dispatch<Ctx, LPL, 2>(c, val, (c.metric + z > c.metric - o) ? c.metric + z : c.metric - o, newP, nval, nidx);
+                PAMD_STAMP(1)
                 const uint32_t srcp = (uint32_t)c.g0 + (nidx >> 1), q = nidx & 1u;
                 const typename Ctx::SlotT nslot = c.slot_from_lane((int)(srcp << LPL));
+                PAMD_STAMP(2)
                 c.P = newP;
                 if ((uint32_t)c.pl < c.P) {
                     c.metric = nval;
