@@ -408,6 +408,44 @@ void specialize_scl(pcd_decoder* d)
         }
         v.swap(out);
     }
+    // The G of the root's grandchildren with a virtual input as well (SCL_VG2): its stage logN-2 block is recomputed from
+    // the channel row, so the SCL_VTOP in front that produced the block (and consumed it through its fused F) need not
+    // store it -- the largest stage leaves the arena.  Same geometry as SCL_VTOP.
+    if (d->virtual_top && d->lpl == 2 && d->cwl == 1 && d->logN == 10 && d->logN * fb <= 32 && d->s0 == d->logN - 3 &&
+        d->sb <= d->logN - 3 && !PAMD_ENV("PCD_NO_VTOP") && PAMD_ENV("PCD_VG2")) {
+        // (measured on MI355X, cfg 3: fabric traffic 25.3x -> 20.1x of the algorithmic bytes, but 27.2 -> 26.4 M cw/s -- the
+        //  recomputation costs more than the arena round trip it saves -- so the op stays an experiment of the diagnostic
+        //  build: PCD_VG2=1)
+        auto& v = d->scl_prog.ins;
+        std::vector<pamd::Ins> out;
+        out.reserve(v.size());
+        bool r9 = false, r8 = false;
+        long producer = -1;  // index (in out) of the SCL_VTOP whose output block the next stage logN-2 G would read
+        for (size_t i = 0; i < v.size(); ++i) {
+            pamd::Ins in = v[i];
+            if (in.stage == d->logN && in.op == pamd::SCL_G) r9 = true;
+            if (in.op == pamd::SCL_VTOP) {
+                r8 = (in.off & 1u) != 0;  // the grandchild that follows is the right child iff this op is the G
+                producer = ((in.off >> 1) & 3u) >= 1u ? (long)out.size() : -1;  // (its F must be fused: no other reader)
+            } else if (in.stage == d->logN - 1) {
+                producer = -1;  // (an unfused F / G of the root's child, or its COMBINE: nothing to pair with)
+            }
+            if (in.op == pamd::SCL_G && in.stage == d->logN - 2 && (in.side & 0xEu) == 0 && in.pad == 0 && producer >= 0) {
+                unsigned k = 0;
+                if (i + 1 < v.size() && v[i + 1].op == pamd::SCL_F && v[i + 1].stage + 1u == in.stage && (v[i + 1].side & 0xEu) == 0 &&
+                    v[i + 1].pad == 0) {
+                    k = 1;
+                    ++i;
+                }
+                in.op = pamd::SCL_VG2;
+                in.off = (r9 ? 1u : 0u) | (r8 ? 2u : 0u) | (k << 2);
+                out[(size_t)producer].off |= 32u;  // the producer's block is never read back: do not store it
+                producer = -1;
+            }
+            out.push_back(in);
+        }
+        v.swap(out);
+    }
     // Wide F / G whose output is read next by the F of the stage below: that F runs on the values in registers
     // (SCL_WFG, scl_kernel.h) -- every stage is then read once (by its G) instead of twice.  The stage below the output
     // must still be a plain stored stage (not specialised away later: this pass runs before F_S / G_S are chosen).

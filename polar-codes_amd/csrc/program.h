@@ -67,6 +67,13 @@ enum Op : uint8_t {
     // (the G of the stage below comes back to them) and their f.  Saves one of the two read passes over every arena
     // stage.  `off` bit 0 = the op is a G.
     SCL_WFG,
+    // G of stage logN-2 (the right child of a grandchild of the root) with a virtual input as well: the stage logN-2
+    // block it reads is recomputed from the channel row through TWO levels (root child, grandchild) for all paths of
+    // both codewords at once -- one 16-byte chunk of the 128 outputs per lane (N = 1024, 4 lanes per path x 2 codewords).
+    // The matching SCL_VTOP then does not store that block at all (its `off` bit 5), which removes the largest arena
+    // stage.  `off`: bit 0 = the root child is the RIGHT one, bit 1 = the grandchild is a RIGHT child, bits 2-3 = fused F
+    // levels below (0..1)
+    SCL_VG2,
 };
 
 struct Ins {

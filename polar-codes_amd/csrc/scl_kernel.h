@@ -2092,6 +2092,94 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 });
                 c.set_field(s);
                 c.set_field(s - 1);
+            } else if (ins.op == SCL_VG2) {
+                if constexpr (kMerge && !S64 && HB) {
+                    // s = logN - 2 = 8: 128 outputs per path = 32 chunks: lane l serves codeword l / 32, chunk l % 32 and loops
+                    // over the paths of its codeword.  Output chunk c needs the chunks c, c + 32 of the (never stored)
+                    // stage-8 block, those need the chunks c, c + 32, c + 64, c + 96 of the stage-9 block, and those the
+                    // channel chunks at the same places and 128 chunks further on: eight 16-byte channel loads per lane,
+                    // once for all paths.  What does not depend on the path (f of the channel when the root child is
+                    // the left one, f of that when the grandchild is a left child too) is computed once.
+                    const bool r9 = (aux & 1u) != 0, r8 = (aux & 2u) != 0;
+                    const uint32_t kf = (aux >> 2) & 3u;
+                    const uint32_t t = (uint32_t)lane >> 5, c4 = 4u * ((uint32_t)lane & 31u);
+                    const uint32_t wi = c4 >> 5, wsh = c4 & 31u;  // (all chunk distances are multiples of 32 elements)
+                    const uint32_t g0q = t * (uint32_t)LCW;
+                    auto f4 = [](float4 a, float4 b) {
+                        return make_float4(polar_fx<CH>(a.x, b.x), polar_fx<CH>(a.y, b.y), polar_fx<CH>(a.z, b.z), polar_fx<CH>(a.w, b.w));
+                    };
+                    auto g4 = [](float4 a, float4 b, uint32_t u) {
+                        return make_float4(polar_gx<CH>(a.x, b.x, u & 1u), polar_gx<CH>(a.y, b.y, (u >> 1) & 1u),
+                                           polar_gx<CH>(a.z, b.z, (u >> 2) & 1u), polar_gx<CH>(a.w, b.w, (u >> 3) & 1u));
+                    };
+                    const Rd<I8 ? K_GI8 : K_GF32> x{ chan_of(t) };
+                    const uint32_t halfN = N >> 1;
+                    float4 v0 = x.ld4(c4), v1 = x.ld4(c4 + 128u), v2 = x.ld4(c4 + 256u), v3 = x.ld4(c4 + 384u);
+                    float4 w0 = x.ld4(halfN + c4), w1 = x.ld4(halfN + c4 + 128u), w2 = x.ld4(halfN + c4 + 256u), w3 = x.ld4(halfN + c4 + 384u);
+                    if (!r9) {  // stage-9 chunks, the same for every path
+                        v0 = f4(v0, w0);
+                        v1 = f4(v1, w1);
+                        v2 = f4(v2, w2);
+                        v3 = f4(v3, w3);
+                        if (!r8) {  // ... and so are the stage-8 chunks c (from v0, v2) and c + 32 (from v1, v3)
+                            v0 = f4(v0, v2);
+                            v1 = f4(v1, v3);
+                        }
+                    }
+                    const uint32_t wo_root = woff(logN - 1) - c.wsb + wi, wo_9 = woff(logN - 2) - c.wsb + wi, wo_8 = woff(s - 1) - c.wsb + wi;
+                    // the seven 4-bit groups that steer the g's of one path, packed: bits 0-15 the root's left-child bits at
+                    // the four stage-9 chunks, 16-23 the stage-9 node's left-child bits at the two stage-8 chunks, 24-27 the
+                    // left-child bits of this node.  Fetched one path ahead (plain global loads, counted waits).
+                    auto fetch = [&](uint32_t ql) -> uint32_t {
+                        const uint32_t q = g0q + ql;  // (per lane: the path group of this lane's codeword)
+                        const uint32_t sq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q << (LPL + 2)), (int)(uint32_t)c.slot);
+                        uint32_t nb = (((c.gbits + __umul24(q, c.gwpp) + wo_8)[0] >> wsh) & 0xFu) << 24;  // left-child bits at identity
+                        if (r9) {
+                            const uint32_t holder = g0q + ((sq >> ((logN - 1u) * (uint32_t)Ctx::FB)) & (uint32_t)(LCW - 1));
+                            const uint32_t* rl = c.gbits + __umul24(holder, c.gwpp) + wo_root;
+                            nb |= ((rl[0] >> wsh) & 0xFu) | (((rl[4] >> wsh) & 0xFu) << 4) | (((rl[8] >> wsh) & 0xFu) << 8) |
+                                  (((rl[12] >> wsh) & 0xFu) << 12);
+                        }
+                        if (r8) {
+                            const uint32_t h9 = g0q + ((sq >> ((logN - 2u) * (uint32_t)Ctx::FB)) & (uint32_t)(LCW - 1));
+                            const uint32_t* b9 = c.gbits + __umul24(h9, c.gwpp) + wo_9;
+                            nb |= (((b9[0] >> wsh) & 0xFu) << 16) | (((b9[4] >> wsh) & 0xFu) << 20);
+                        }
+                        return nb;
+                    };
+                    uint32_t nxt = fetch(0);
+                    for (uint32_t ql = 0; ql < c.P; ++ql) {
+                        const uint32_t q = g0q + ql;
+                        const uint32_t nb = nxt;
+                        if (ql + 1u < c.P) nxt = fetch(ql + 1u);
+                        float4 a, b;  // stage-8 chunks c and c + 32 of path q
+                        if (r9) {
+                            const float4 s0_ = g4(v0, w0, nb & 0xFu), s1_ = g4(v1, w1, (nb >> 4) & 0xFu),
+                                         s2_ = g4(v2, w2, (nb >> 8) & 0xFu), s3_ = g4(v3, w3, (nb >> 12) & 0xFu);
+                            a = r8 ? g4(s0_, s2_, (nb >> 16) & 0xFu) : f4(s0_, s2_);
+                            b = r8 ? g4(s1_, s3_, (nb >> 20) & 0xFu) : f4(s1_, s3_);
+                        } else if (r8) {
+                            a = g4(v0, v2, (nb >> 16) & 0xFu);
+                            b = g4(v1, v3, (nb >> 20) & 0xFu);
+                        } else {
+                            a = v0;
+                            b = v1;
+                        }
+                        const uint32_t u8 = (nb >> 24) & 0xFu;
+                        const float4 r = g4(a, b, u8);
+                        Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(c4, r);
+                        if (kf >= 1u) {  // F of stage 7: chunk c with c + 16 (the other DPP row of the codeword)
+                            const auto tx = __builtin_amdgcn_permlane16_swap(fbits(r.x), fbits(r.x), false, false);
+                            const auto ty = __builtin_amdgcn_permlane16_swap(fbits(r.y), fbits(r.y), false, false);
+                            const auto tz = __builtin_amdgcn_permlane16_swap(fbits(r.z), fbits(r.z), false, false);
+                            const auto tw = __builtin_amdgcn_permlane16_swap(fbits(r.w), fbits(r.w), false, false);
+                            const float4 r2 = f4(r, make_float4(bitsf(tx[1]), bitsf(ty[1]), bitsf(tz[1]), bitsf(tw[1])));
+                            if (((uint32_t)lane & 31u) < 16u) Wr<K_LDS>{ c.path_llr(q) + (1u << (s - 2)) }.st4(c4, r2);
+                        }
+                    }
+                    c.set_field(s);
+                    if (kf >= 1u) c.set_field(s - 1);
+                }
             } else if (ins.op == SCL_VTOP) {
                 if constexpr (kMerge && !S64 && HB) {
                     // Stage s = logN - 1 block of every live path from the channel row: h = 256 outputs per path = one
@@ -2141,7 +2229,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                             if (ql + 1u < c.P) fetch(ql + 1u, na, nb, nu);
                             const float4 a = right ? g4(c0, c2, ua) : f4(c0, c2), b = right ? g4(c1, c3, ub) : f4(c1, c3);
                             const float4 r = isg ? g4(a, b, u) : f4(a, b);
-                            Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(ci, r);
+                            if (!(aux & 32u)) Wr<K_GF32>{ c.arena_stage(q, s - 1) }.st4(ci, r);  // (bit 5: nobody reads it back, SCL_VG2)
                             if (kf >= 1u) {
                                 // lanes 0..31: chunk l of stage s - 2 = f(chunk l, chunk l + 32)
                                 const auto sx = __builtin_amdgcn_permlane32_swap(fbits(r.x), fbits(r.x), false, false);
@@ -2168,7 +2256,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
                 }
             }
         op_done:
-            if ((ins.op <= SCL_G || ins.op == SCL_VTOP || ins.op == SCL_WFG) && s - 1 >= c.s0 && !(vflags & 2u)) {
+            if ((ins.op <= SCL_G || ins.op == SCL_VTOP || ins.op == SCL_WFG || ins.op == SCL_VG2) && s - 1 >= c.s0 && !(vflags & 2u)) {
                 // this op stored LLRs to the global arena: wait for the stores (L2 is the meeting point; the
                 // arena is read back with sc1 loads)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -5,7 +5,7 @@ import golden_io as gio
 os.environ.setdefault('PYPOLAR_AMD_LIB', os.path.join(_R, 'polar-codes_amd', 'lib', 'libpolar_amd_diag.so'))  # trace / cycle stamps: diagnostic build (make -C polar-codes_amd diag)
 import pypolar_amd
 names = {32: 'F', 33: 'G', 34: 'COMBINE', 35: 'R0', 36: 'R1', 37: 'REP', 38: 'SPC', 40: 'F_S', 41: 'G_S', 42: 'C_S',
-         43: 'C_W', 44: 'SPC_S', 45: 'R1_S', 46: 'G0_S', 47: 'VTOP', 48: 'WFG', 0: 'END'}
+         43: 'C_W', 44: 'SPC_S', 45: 'R1_S', 46: 'G0_S', 47: 'VTOP', 48: 'WFG', 49: 'VG2', 0: 'END'}
 fx = gio.load_named("cfg3_n1024_k512_l8_crc24_awgn.bin")
 d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, "float")
 d.setErrorDetection(fx.crc_size, fx.crc_type)

@@ -10,7 +10,7 @@ os.environ.setdefault('PYPOLAR_AMD_LIB', os.path.join(_R, 'polar-codes_amd', 'li
 import pypolar_amd
 
 names = {32: 'F', 33: 'G', 34: 'COMBINE', 35: 'R0', 36: 'R1', 37: 'REP', 38: 'SPC', 40: 'F_S', 41: 'G_S', 42: 'C_S',
-         43: 'C_W', 44: 'SPC_S', 45: 'R1_S', 46: 'G0_S', 47: 'VTOP', 48: 'WFG', 0: 'END'}
+         43: 'C_W', 44: 'SPC_S', 45: 'R1_S', 46: 'G0_S', 47: 'VTOP', 48: 'WFG', 49: 'VG2', 0: 'END'}
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3_n1024_k512_l8_crc24_awgn.bin"
 fx = gio.load_named(name)
 d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, "float")
