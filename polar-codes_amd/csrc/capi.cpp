@@ -686,6 +686,7 @@ pamd::DecodeParams base_params(const pcd_decoder* d, const void* llr, size_t row
 int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
     P.prog = d->d_sc_prog;
+    P.prog_len = (uint32_t)d->sc_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->sc_wave_words;
     P.metrics = nullptr;
     P.sc_virtual_top = d->sc_virtual_top;
@@ -719,6 +720,7 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
     P.prog = d->d_scl_prog;
+    if (!P.prog_len) P.prog_len = (uint32_t)d->scl_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->scl_wave_words;
     P.path_stride = d->path_stride;
     P.wppL = d->wppL;
@@ -1228,7 +1230,7 @@ int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t*
     HIP_TRY(hipMemcpy(d->d_in, llr_row, (size_t)d->N * 4, hipMemcpyHostToDevice));
     pamd::DecodeParams P = base_params(d, d->d_in, 1, d->d_out, nullptr, nullptr);
     P.cycles = dcyc;
-    P.prog_len = n;
+    P.prog_len = n - 1;  // (the kernel's loop count and the offset of the phase stamps; the OP_END word is not executed)
     for (int rep = 0; rep < 2 && !rc; ++rep) rc = run_scl(d, P, false, nullptr);  // second run: warm caches
     if (!rc) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1236,9 +1238,9 @@ int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t*
         HIP_TRY(hipMemcpy(h.data(), dcyc, (size_t)n * 5 * 4, hipMemcpyDeviceToHost));
         if (const char* dump = PAMD_ENV("PCD_SUBPROFILE")) {  // leaf phase stamps (diagnostics)
             if (FILE* f = std::fopen(dump, "w")) {
-                for (unsigned i = 0; i < n; ++i)
+                for (unsigned i = 0; i + 1 < n; ++i)
                     std::fprintf(f, "%u %u %u %u %u %u %u\n", (unsigned)d->scl_prog.ins[i].op, (unsigned)d->scl_prog.ins[i].stage,
-                                 h[i], h[n + 4 * i], h[n + 4 * i + 1], h[n + 4 * i + 2], h[n + 4 * i + 3]);
+                                 h[i], h[(n - 1) + 4 * i], h[(n - 1) + 4 * i + 1], h[(n - 1) + 4 * i + 2], h[(n - 1) + 4 * i + 3]);
                 std::fclose(f);
             }
         }

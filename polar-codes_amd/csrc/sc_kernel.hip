@@ -254,9 +254,11 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
         const void* chan = I8 ? (const void*)(reinterpret_cast<const int8_t*>(P.llr) + (size_t)row * N)
                               : (const void*)(reinterpret_cast<const float*>(P.llr) + (size_t)row * N);
 
-        uint64_t iw_next = prog64[0];
+        const_u64_ptr pp = prog64;
+        uint64_t iw_next = pp[0];
         int lane_v = lane;
-        for (uint32_t pc = 0;; ++pc) {
+        // (P.prog_len = instructions in front of the OP_END word, which is still there: the fetch runs one ahead)
+        for (uint32_t pc = 0; pc < P.prog_len; ++pc) {
             // the lane number is made opaque once per instruction: lane predicates (64-bit SGPR masks) and other values
             // derived from it are then re-derived per instruction instead of being hoisted out of the interpreter loop
             // (the kernel sits at the SGPR limit: hoisted masks were spilled to VGPR lanes)
@@ -266,8 +268,8 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
             const int l = g.l;
             const uint64_t iw = iw_next;
             const uint32_t op = (uint32_t)(iw & 0xFF);
-            if (op == OP_END) break;
-            iw_next = prog64[pc + 1];  // scalar load, in flight while this instruction executes
+            ++pp;
+            iw_next = pp[0];  // scalar load, in flight while this instruction executes
             const uint32_t s = (uint32_t)((iw >> 8) & 0xFF), n = 1u << s, h = n >> 1, off = (uint32_t)(iw >> 32);
             uint64_t t_start = 0;
             if (DIAG && P.cycles && grp == 0) t_start = __builtin_amdgcn_s_memtime();

@@ -1262,9 +1262,11 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
         c.slot = 0;
         uint32_t trace_n = 0;
 
-        uint64_t iw_next = prog64[0];
+        const_u64_ptr pp = prog64;
+        uint64_t iw_next = pp[0];
         int lane_v = threadIdx.x & 63;
-        for (uint32_t pc = 0;; ++pc) {
+        // (P.prog_len = instructions in front of the OP_END word, which is still there: the fetch runs one ahead)
+        for (uint32_t pc = 0; pc < P.prog_len; ++pc) {
             // The lane number is made opaque once per instruction so that nothing derived from it (addresses, lane
             // predicates as 64-bit SGPR masks) is hoisted out of the interpreter loop: the kernel is at its register
             // limits (128 VGPRs, 102 SGPRs) and hoisted values were spilled; re-deriving them costs a few VALU ops.
@@ -1279,8 +1281,8 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void
             const uint64_t iw = iw_next;
             Ins ins;
             ins.op = (uint8_t)(iw & 0xFF);
-            if (ins.op == OP_END) break;
-            iw_next = prog64[pc + 1];  // scalar load, in flight while this instruction executes
+            ++pp;
+            iw_next = pp[0];  // scalar load, in flight while this instruction executes
             ins.stage = (uint8_t)((iw >> 8) & 0xFF);
             ins.side = (uint8_t)((iw >> 16) & 0xFF);
             const uint32_t s = ins.stage, n = 1u << s, h = n >> 1, side = ins.side & 1u;
