@@ -563,3 +563,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+else:
+    heavy_imports()  # imported as a library (tools/*.py use make_batch / CONFIGS): no launcher logic, load everything

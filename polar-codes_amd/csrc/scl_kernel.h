@@ -1181,12 +1181,15 @@ __device__ __forceinline__ float4 virt_top4(const void* chan, uint32_t halfN, ui
     return make_float4(polar_fx<CH>(a.x, b.x), polar_fx<CH>(a.y, b.y), polar_fx<CH>(a.z, b.z), polar_fx<CH>(a.w, b.w));
 }
 
+#ifndef PAMD_WAVES_PER_EU
+#define PAMD_WAVES_PER_EU 4
+#endif
 // 4 waves per SIMD (<= 128 VGPRs) for the L <= 8 production kernels: occupancy is what hides the LDS / arena latency
 // IN: 0 = fp32 channel rows, 1 = int8 rows widened to float (the float decoder's decode_vector(const char*)), 2 = int8
 // rows AND int8 arithmetic (SclFipChar)
 template <int LPL, int IN, bool S64, bool DIAG, bool HB, int CWL>
 // (at most 128 VGPRs for the kernels that reach 16 waves per CU; capping at 96 for 20 waves measured slower: spills)
-__global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? 4 : 1) void scl_decode_kernel(DecodeParams P)
+__global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? PAMD_WAVES_PER_EU : 1) void scl_decode_kernel(DecodeParams P)
 {
     constexpr bool I8 = IN != 0, CH = IN == 2;
     using Ctx = SclCtx<LPL, S64, HB, CWL, CH>;
