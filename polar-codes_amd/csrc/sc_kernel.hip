@@ -283,11 +283,21 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
             //   side bits 0-2: F ops of the stages below that follow this F / G / G0R or that tail G (left descent)
             const uint32_t fzz = (uint32_t)(iw >> 16) & 0xFFFFu;
             const uint32_t fz = fzz >> 8;
+            // fn(i) for i = l, l + LC, ... < cnt (cnt a power of two).  Written with a wave-uniform trip count: a loop that
+            // starts at the lane number is compiled as an exec-mask loop (three scalar instructions per trip for the mask,
+            // and this kernel is bound by the scalar unit)
+            auto lanes = [&](uint32_t cnt, auto&& fn) {
+                if (cnt >= (uint32_t)LC) {
+                    for (uint32_t i0 = 0; i0 < cnt; i0 += LC) fn(i0 + (uint32_t)l);
+                } else if ((uint32_t)l < cnt) {
+                    fn((uint32_t)l);
+                }
+            };
             if (__builtin_expect(fz != 0u, 0) && (fz & 3u)) {
                 const float* X = llr + 2 * n;
                 float* d = llr + n;
                 const uint32_t pro = fz & 3u, lo = off - n;  // (G: the left sibling's bits sit right below this block)
-                for (uint32_t i = l; i < n; i += LC) {
+                lanes(n, [&](uint32_t i) {
                     const float a = X[i], b = X[n + i];
                     float r;
                     if (pro == 1u) {
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                         r = polar_gx<CH>(a, b, (bits[bi >> 5] >> (bi & 31u)) & 1u);
                     }
                     d[i] = r;
-                }
+                });
                 WAVE_SYNC();
             }
             auto combine = [&](uint32_t coff, uint32_t ch_, bool copy) {  // Combine / Combine_0R avx_float.h:190-204
@@ -325,24 +335,26 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                 switch (op) {
                 case SC_F:
                     if (ARENA && s - 1 >= s0)
-                        for (uint32_t i = l; i < h; i += LC) ar[h + i] = polar_fx<CH>(x(i), x(h + i));
+                        lanes(h, [&](uint32_t i) { ar[h + i] = polar_fx<CH>(x(i), x(h + i)); });
                     else if (B2 && h >= 2u * LC) {  // two elements per lane and trip: their loads are in flight together
-                        for (uint32_t i0 = l; i0 < h; i0 += 2u * LC) {
+                        for (uint32_t b0_ = 0; b0_ < h; b0_ += 2u * LC) {
+                            const uint32_t i0 = b0_ + (uint32_t)l;
                             const float a0 = x(i0), b0 = x(h + i0), a1 = x(i0 + LC), b1 = x(h + i0 + LC);
                             llr[h + i0] = polar_fx<CH>(a0, b0);
                             llr[h + i0 + LC] = polar_fx<CH>(a1, b1);
                         }
                     } else
-                        for (uint32_t i = l; i < h; i += LC) llr[h + i] = polar_fx<CH>(x(i), x(h + i));
+                        lanes(h, [&](uint32_t i) { llr[h + i] = polar_fx<CH>(x(i), x(h + i)); });
                     break;
                 case SC_G:
                     if (ARENA && s - 1 >= s0) {
-                        for (uint32_t i = l; i < h; i += LC) {
+                        lanes(h, [&](uint32_t i) {
                             const uint32_t b = off + i;
                             ar[h + i] = polar_gx<CH>(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
-                        }
+                        });
                     } else if (B2 && h >= 2u * LC) {
-                        for (uint32_t i0 = l; i0 < h; i0 += 2u * LC) {
+                        for (uint32_t b0_ = 0; b0_ < h; b0_ += 2u * LC) {
+                            const uint32_t i0 = b0_ + (uint32_t)l;
                             const uint32_t bi0 = off + i0, bi1 = bi0 + LC;
                             const float a0 = x(i0), b0 = x(h + i0), a1 = x(i0 + LC), b1 = x(h + i0 + LC);
                             const uint32_t u0 = (bits[bi0 >> 5] >> (bi0 & 31u)) & 1u, u1 = (bits[bi1 >> 5] >> (bi1 & 31u)) & 1u;
@@ -350,17 +362,17 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                             llr[h + i0 + LC] = polar_gx<CH>(a1, b1, u1);
                         }
                     } else {
-                        for (uint32_t i = l; i < h; i += LC) {
+                        lanes(h, [&](uint32_t i) {
                             const uint32_t b = off + i;
                             llr[h + i] = polar_gx<CH>(x(i), x(h + i), (bits[b >> 5] >> (b & 31u)) & 1u);
-                        }
+                        });
                     }
                     break;
                 case SC_G0R:
                     if (ARENA && s - 1 >= s0)
-                        for (uint32_t i = l; i < h; i += LC) ar[h + i] = addx<CH>(x(i), x(h + i));
+                        lanes(h, [&](uint32_t i) { ar[h + i] = addx<CH>(x(i), x(h + i)); });
                     else
-                        for (uint32_t i = l; i < h; i += LC) llr[h + i] = addx<CH>(x(i), x(h + i));
+                        lanes(h, [&](uint32_t i) { llr[h + i] = addx<CH>(x(i), x(h + i)); });
                     break;
                 case SC_COMBINE:
                 case SC_COMBINE0R:
@@ -665,10 +677,10 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     WAVE_SYNC();
                     const float* X = llr + 2 * gh;
                     float* d = llr + gh;
-                    for (uint32_t i = l; i < gh; i += LC) {
+                    lanes(gh, [&](uint32_t i) {
                         const uint32_t bi = coff + i;
                         d[i] = polar_gx<CH>(X[i], X[gh + i], (bits[bi >> 5] >> (bi & 31u)) & 1u);
-                    }
+                    });
                     fbase = gh;
                 }
                 for (uint32_t t = 0; t < (fzz & 7u); ++t) {  // F of the stages below (left descent)
@@ -676,7 +688,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                     WAVE_SYNC();
                     const float* X = llr + fn;
                     float* d = llr + fh;
-                    for (uint32_t i = l; i < fh; i += LC) d[i] = polar_fx<CH>(X[i], X[fh + i]);
+                    lanes(fh, [&](uint32_t i) { d[i] = polar_fx<CH>(X[i], X[fh + i]); });
                 }
             }
             if (ARENA && (op == SC_F || op == SC_G || op == SC_G0R) && s - 1 >= s0) {
