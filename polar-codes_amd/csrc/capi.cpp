@@ -165,7 +165,7 @@ void compute_geometry(pcd_decoder* d)
     }
     d->sc_s0 = d->logN;
     d->sc_arena_cw_words = 0;
-    if (N >= 2048 && d->sc_virtual_top && !PAMD_ENV("PCD_SC_NO_ARENA") && !PAMD_ENV("PCD_SC_LCL")) {
+    if ((N >= 2048 || (N >= 512 && PAMD_ENV("PCD_SC_S0"))) && d->sc_virtual_top && !PAMD_ENV("PCD_SC_NO_ARENA") && !PAMD_ENV("PCD_SC_LCL")) {
         // long blocks: keep 16 lanes per codeword (four codewords per wave) and move the LLR stages from s0 up into a
         // per-codeword arena slice, s0 chosen so that a wave stays within 10 KB of LDS (16 waves per CU)
         unsigned s0 = d->logN - 1;
@@ -702,6 +702,7 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
         Q.cycles = nullptr;  // (the query is about the production kernel, whatever this call is)
         HIP_TRY(pamd::launch_sc(Q, d->sc_lcl, i8, 1, d->sc_wpb, lds, st, &occ));
         sc_bpc = std::max(1, std::min(occ, (int)lds_blocks_per_cu(lds)));
+        if (const char* e = PAMD_ENV("PCD_SC_BLOCKS_PER_CU")) sc_bpc = std::max(1, std::min(64, std::atoi(e)));  // experiments
         if (PAMD_ENV("PCD_VERBOSE"))
             std::fprintf(stderr, "[pcd] sc: %u codewords/wave, lds=%zu B/workgroup, occupancy=%d blocks/CU\n", cw_per_wave, lds, occ);
     }
