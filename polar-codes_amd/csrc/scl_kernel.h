@@ -1002,7 +1002,7 @@ constexpr uint64_t merge_keepmin_mask(int dist, int dbit)
                  "v_cndmask_b32_dpp %1, %1, %1, vcc " DPPSTR " row_mask:0xf bank_mask:0xf bound_ctrl:1"    \
                  : "+v"(k), "+v"(x), "=&v"(pk)                                                            \
                  : "i"(KEEPMIN)                                                                           \
-                 : "vcc")
+                 : "vcc", "scc")  /* (s_xor_b32 writes SCC) */
 template <int DIST, uint32_t KEEPMIN>
 __device__ __forceinline__ void merge_cmpex(uint32_t& k, uint32_t& x)
 {
@@ -1028,6 +1028,13 @@ __device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t
 {
     static_assert(CTX::LP == 4 && CTX::CW == 2 && CTX::LCW == 8, "8 path groups of 4 lanes per codeword");
     constexpr uint32_t INFK = 0xFFFFFFFFu;
+    if constexpr (CTX::CH) {
+        // int8 decoder: metrics are integers (|m| < 2^18 up to N = 2048), so equal metrics are the rule, not the exception.
+        // The key becomes (-m) << 6 | position: all keys differ and equal metrics order by ascending position, which is the
+        // order simplePartialSortDescending picks them in as long as none of them has been moved by a swap (see below).
+        k0 = k0 == INFK ? INFK : ((((uint32_t)bitsf(k0 ^ 0x80000000u)) << 6) | x0);
+        if constexpr (CPP == 8) k1 = k1 == INFK ? INFK : ((((uint32_t)bitsf(k1 ^ 0x80000000u)) << 6) | x1);
+    }
     uint32_t k = k0, x = x0, pk;
     if constexpr (CPP == 8) {  // a_i against b_(7-i): the other quad's second register, mirrored; keep the smaller
         asm volatile("s_nop 1\n\t"
@@ -1061,26 +1068,65 @@ __device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t
         k = ta ? sk[0] : (tb ? sk[1] : k);
     }
     merge_sort8<-1>(k, x);
-    // exact ties among the winners: ranks r | r + 1 are quad neighbours (rotation by one lane; its wrap-around pair and
-    // the pairs of the second comparison that are not neighbours compare two ranks of the same list, so an equality
-    // there is a tie as well), ranks 3 | 4 sit in lanes 3 | 7 (rotation of the row by four lanes) ...
-    const uint32_t nx = dpp_u32<0x39>(k), n4 = dpp_u32<0x124>(k);
-    const bool tie = k != INFK && (k == nx || k == n4);
-    // ... and at the cut: exactly newP candidates of each codeword may be at or below the key of rank newP - 1
-    const uint32_t rl = newP - 1u, tl = rl < 4u ? rl : 11u - rl;
-    const uint32_t t0 = readlane_u32(k, (int)tl), t1 = readlane_u32(k, (int)(32u + tl));
-    uint32_t n0 = (uint32_t)__popc((uint32_t)ballot64(k0 <= t0)), n1 = (uint32_t)__popc((uint32_t)(ballot64(k0 <= t1) >> 32));
-    if constexpr (CPP == 8) {
-        n0 += (uint32_t)__popc((uint32_t)ballot64(k1 <= t0));
-        n1 += (uint32_t)__popc((uint32_t)(ballot64(k1 <= t1) >> 32));
-    }
-    if (ballot64(tie) != 0 || n0 != newP || n1 != newP) return false;
     // new path pl inherits the candidate of rank pl
     const uint32_t pl = (uint32_t)c.pl;
     const uint32_t src = ((uint32_t)c.lane & ~7u) | (pl < 4u ? pl : 11u - pl);
-    nval = bitsf((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)k));
-    nidx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)x);
-    return true;
+    const uint32_t nx = dpp_u32<0x39>(k), n4 = dpp_u32<0x124>(k);
+    const uint32_t rl = newP - 1u, tl = rl < 4u ? rl : 11u - rl;
+    if constexpr (CTX::CH) {
+        const uint32_t t0 = readlane_u32(k, (int)tl), t1 = readlane_u32(k, (int)(32u + tl));
+        // Equal metrics are exact in position order unless a swap of the selection sort has moved one of them: round i
+        // moves the element at position i to the winner's old place when it is not the winner itself, so only the elements
+        // that START at the positions below lim = min(size - 1, newP) ever move, such an element has moved by the time it
+        // is picked iff its rank is larger than its start position p, and the place it moved to is where the winner of
+        // round p (= the element of rank p) came from.  With that effective position in place of the start position the
+        // ranks must still ascend inside every run of equal metrics; a second move (the new place is again below lim, or
+        // the winner had moved itself), an order that does not hold, or a run that crosses the cut and contains a moved
+        // picked element goes to the literal emulation.
+        const uint32_t size = c.P * (uint32_t)CPP, lim = (size - 1u < newP) ? size - 1u : newP;
+        const uint32_t j8 = (uint32_t)c.lane & 7u, r = j8 < 4u ? j8 : 11u - j8;
+        const uint32_t pos = k & 63u, mk = k >> 6;
+        const bool moved = k != INFK && pos < lim && r > pos;
+        const uint32_t wl = ((uint32_t)c.lane & ~7u) | (moved ? (pos < 4u ? pos : 11u - pos) : j8);
+        const uint32_t wk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wl << 2), (int)(k | (moved ? 0x80000000u : 0u)));
+        // (0xFFFFFFFF: moved twice -- no effective position is derived, any tie of this element falls back)
+        const uint32_t eff = moved ? (((wk >> 31) != 0u || (wk & 63u) < lim) ? INFK : (wk & 63u)) : pos;
+        const uint32_t ex = dpp_u32<0x39>(eff), e4 = dpp_u32<0x124>(eff);
+        const bool tq = k != INFK && mk == (nx >> 6), t4 = k != INFK && mk == (n4 >> 6);
+        const bool bad = (tq && j8 < 3u && (eff >= ex || ex == INFK)) || (tq && j8 >= 4u && j8 < 7u && (ex >= eff || eff == INFK)) ||
+                         (t4 && j8 == 3u && (eff >= e4 || e4 == INFK));
+        const uint32_t tm0 = t0 >> 6, tm1 = t1 >> 6, tm = ((uint32_t)c.lane & 32u) ? tm1 : tm0;
+        uint32_t n0 = (uint32_t)__popc((uint32_t)ballot64((k0 >> 6) <= tm0)), n1 = (uint32_t)__popc((uint32_t)(ballot64((k0 >> 6) <= tm1) >> 32));
+        if constexpr (CPP == 8) {
+            n0 += (uint32_t)__popc((uint32_t)ballot64((k1 >> 6) <= tm0));
+            n1 += (uint32_t)__popc((uint32_t)(ballot64((k1 >> 6) <= tm1) >> 32));
+        }
+        // a run of equal metrics that crosses the cut: exact unless one of its PICKED members has moved (an element that
+        // is not picked in position order stays unpicked when it moves further back, and nobody else's place changes)
+        const uint64_t mrun = ballot64(r < newP && mk == tm && moved);
+        const bool cut0 = n0 != newP && (uint32_t)mrun != 0u, cut1 = n1 != newP && (uint32_t)(mrun >> 32) != 0u;
+        if (ballot64(bad) != 0 || cut0 || cut1) return false;
+        const uint32_t rk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)k);
+        nval = 0.0f - (float)(rk >> 6);
+        nidx = rk & 63u;
+        return true;
+    } else {
+        // exact ties among the winners: ranks r | r + 1 are quad neighbours (rotation by one lane; its wrap-around pair and
+        // the pairs of the second comparison that are not neighbours compare two ranks of the same list, so an equality
+        // there is a tie as well), ranks 3 | 4 sit in lanes 3 | 7 (rotation of the row by four lanes) ...
+        const bool tie = k != INFK && (k == nx || k == n4);
+        // ... and at the cut: exactly newP candidates of each codeword may be at or below the key of rank newP - 1
+        const uint32_t t0 = readlane_u32(k, (int)tl), t1 = readlane_u32(k, (int)(32u + tl));
+        uint32_t n0 = (uint32_t)__popc((uint32_t)ballot64(k0 <= t0)), n1 = (uint32_t)__popc((uint32_t)(ballot64(k0 <= t1) >> 32));
+        if constexpr (CPP == 8) {
+            n0 += (uint32_t)__popc((uint32_t)ballot64(k1 <= t0));
+            n1 += (uint32_t)__popc((uint32_t)(ballot64(k1 <= t1) >> 32));
+        }
+        if (ballot64(tie) != 0 || n0 != newP || n1 != newP) return false;
+        nval = bitsf((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)k));
+        nidx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)x);
+        return true;
+    }
 }
 
 template <typename CTX, int LPL, int CPP>

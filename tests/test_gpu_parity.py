@@ -525,6 +525,28 @@ def test_char_decoders_vs_oracle_random(built_library, N, L):
         assert np.array_equal(res[0], e_out) and np.array_equal(res[1].astype(np.uint8), e_ok), (N, L, K, "nsys")
 
 
+@pytest.mark.parametrize("N,L", [(256, 4), (1024, 8), (2048, 8)])
+def test_char_list_decoder_equal_metrics_everywhere(built_library, N, L):
+    """int8 rows of tiny magnitude: nearly every candidate selection has equal metrics among the winners and across the
+    cut.  The merge selection orders them by position and only falls back to the literal emulation of
+    simplePartialSortDescending (arrayfuncs.h:161-183) when a swap has moved one of them (scl_kernel.h, select_merge):
+    bytes, verdicts and all L metrics must equal the oracle's.  tools/char_stress_vs_oracle.py is the long form."""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    rng = np.random.default_rng(N + L)
+    for rate, amp in ((0.25, 1), (0.5, 1), (0.5, 3), (0.75, 2), (0.5, 12)):
+        K = int(N * rate) // 8 * 8
+        frozen = np.asarray(frozen_bits(N, K, 0.0, "BB"), dtype=np.uint32)
+        rows = rng.integers(-amp, amp + 1, (96, N)).astype(np.int8)
+        d = pypolar_amd.PolarDecoder(N, L, frozen, "char")
+        d.setErrorDetection(8, "crc")
+        out, ok, met = d.decode_batch(rows, return_metrics=True)
+        e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, 8, rows.astype(np.float32), True, "char")
+        assert np.array_equal(out, e_out), (N, L, K, amp)
+        assert np.array_equal(np.asarray(ok, np.uint8), e_ok), (N, L, K, amp)
+        assert np.array_equal(met, e_met), (N, L, K, amp)
+
+
 def test_char_decoder_float_rows_are_converted_like_the_reference(built_library):
     """CharContainer::insertLlr(const float*) bitcontainer.cpp:505-516 (N >= 8): round to nearest EVEN, saturate"""
     import pypolar_amd
