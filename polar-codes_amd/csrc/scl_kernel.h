@@ -1115,6 +1115,9 @@ __device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t
         // the pairs of the second comparison that are not neighbours compare two ranks of the same list, so an equality
         // there is a tie as well), ranks 3 | 4 sit in lanes 3 | 7 (rotation of the row by four lanes) ...
         const bool tie = k != INFK && (k == nx || k == n4);
+        // (the winners are fetched first: the LDS round trip overlaps the scalar chain of the checks)
+        const uint32_t rk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)k);
+        const uint32_t rx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)x);
         // ... and at the cut: exactly newP candidates of each codeword may be at or below the key of rank newP - 1
         const uint32_t t0 = readlane_u32(k, (int)tl), t1 = readlane_u32(k, (int)(32u + tl));
         uint32_t n0 = (uint32_t)__popc((uint32_t)ballot64(k0 <= t0)), n1 = (uint32_t)__popc((uint32_t)(ballot64(k0 <= t1) >> 32));
@@ -1123,8 +1126,8 @@ __device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t
             n1 += (uint32_t)__popc((uint32_t)(ballot64(k1 <= t1) >> 32));
         }
         if (ballot64(tie) != 0 || n0 != newP || n1 != newP) return false;
-        nval = bitsf((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)k));
-        nidx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)x);
+        nval = bitsf(rk);
+        nidx = rx;
         return true;
     }
 }
