@@ -178,6 +178,37 @@ PAMD_GROUP_REDUCE(uint32_t, group_or_u32, partner_u32, v | o)
 PAMD_GROUP_REDUCE(uint32_t, group_max_u32, partner_u32, o > v ? o : v)
 PAMD_GROUP_REDUCE(uint32_t, group_min_u32, partner_u32, o < v ? o : v)
 
+// all-reduce minimum / maximum over G = 32 or 64 lanes without the LDS: DPP inside the 16-lane rows, then the gfx950 row /
+// half swaps (v_permlane16_swap, v_permlane32_swap with both operands = v: the two results are "my side" and "the other
+// side" in some order, so their minimum / maximum needs no lane predicate)
+template <int G>
+__device__ __forceinline__ uint32_t group_min_u32x(uint32_t v)
+{
+    v = group_min_u32<(G < 16 ? G : 16)>(v);
+    if constexpr (G > 16) {
+        const auto s = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        v = s[0] < s[1] ? s[0] : s[1];
+    }
+    if constexpr (G > 32) {
+        const auto s = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        v = s[0] < s[1] ? s[0] : s[1];
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_max_u32x(uint32_t v)
+{
+    v = group_max_u32<(G < 16 ? G : 16)>(v);
+    if constexpr (G > 16) {
+        const auto s = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        v = s[0] > s[1] ? s[0] : s[1];
+    }
+    if constexpr (G > 32) {
+        const auto s = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        v = s[0] > s[1] ? s[0] : s[1];
+    }
+    return v;
+}
 // wave-wide maximum of a u32 as a wave-uniform value: DPP inside the 16-lane rows, then 4 readlanes
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {

@@ -379,167 +379,6 @@ __device__ __forceinline__ void find_weak(const CTX& c, const SRC& x, uint32_t n
     }
 }
 
-// ---- candidate selection: simplePartialSortDescending(idx, metrics, P', size) arrayfuncs.h:161-183 ----
-// Candidate position c = path * CPP + q is held by lane path*LP + q/CPL, register q%CPL.
-// Literal emulation: iteration i finds the first position >= i holding the maximum and swaps it
-// with position i.  On return every lane knows, for ITS OWN new path index p, the winning
-// candidate's metric (nval) and original position (nidx).
-// tg0 = first group of the codeword being sorted (several codewords per wave take turns; lanes of the others idle):
-// on return only the lanes of that codeword hold a result.
-template <typename CTX, int LPL, int CPP>
-__device__ __forceinline__ void select_paths(const CTX& c, float (&val_in)[(CPP >> LPL) ? (CPP >> LPL) : 1],
-                                             uint32_t newP, float& nval, uint32_t& nidx, int tg0 = 0)
-{
-    constexpr int LP = CTX::LP;
-    constexpr int CPL = (CPP >> LPL) ? (CPP >> LPL) : 1;
-    const uint32_t size = c.P * CPP;
-    const bool mine = c.g0 == tg0;
-    const uint32_t lane0 = (uint32_t)tg0 << LPL;
-    uint32_t idx[CPL], pos[CPL];
-    float val[CPL];
-    bool valid[CPL];
-#pragma unroll
-    for (int r = 0; r < CPL; ++r) {
-        const uint32_t q = (uint32_t)c.j * CPL + r;
-        valid[r] = mine && (q < (uint32_t)CPP) && ((uint32_t)c.pl < c.P);
-        pos[r] = (uint32_t)c.pl * CPP + q;
-        idx[r] = pos[r];
-        val[r] = val_in[r];
-    }
-    const uint32_t lim = (size - 1 < newP) ? size - 1 : newP;
-    for (uint32_t i = 0; i < lim; ++i) {
-        // lane-local first maximum among eligible positions (>= i)
-        float lv = 0.0f;
-        int lr = -1;
-#pragma unroll
-        for (int r = 0; r < CPL; ++r) {
-            const bool el = valid[r] && pos[r] >= i;
-            if (el && (lr < 0 || val[r] > lv)) {
-                lv = val[r];
-                lr = r;
-            }
-        }
-        const bool has = lr >= 0;
-        // wave maximum
-        float m = has ? lv : -__builtin_inff();
-#pragma unroll
-        for (int k = 1; k < 64; k <<= 1) {
-            const float o = shflx_f32(m, k);
-            m = o > m ? o : m;
-        }
-        const uint64_t bal = ballot64(has && lv == m);
-        const int wl = __ffsll((long long)bal) - 1;  // lowest lane = lowest position
-        // the element currently at position i
-        const uint32_t li = lane0 + (i / CPP) * LP + ((i % CPP) / CPL), ri = (i % CPP) % CPL;
-        float vi = val[0];
-        uint32_t xi = idx[0];
-#pragma unroll
-        for (int r = 1; r < CPL; ++r)
-            if ((uint32_t)r == ri) {
-                vi = val[r];
-                xi = idx[r];
-            }
-        vi = shfl_f32(vi, (int)li);
-        xi = shfl_u32(xi, (int)li);
-        // the winner
-        uint32_t xw = idx[0];
-#pragma unroll
-        for (int r = 1; r < CPL; ++r)
-            if (r == lr) xw = idx[r];
-        const int lrw = __shfl(lr, wl, 64);
-        xw = shfl_u32(xw, wl);
-        // swap: winner's slot receives (vi, xi); position i receives (m, xw)
-        if (c.lane == wl) {
-#pragma unroll
-            for (int r = 0; r < CPL; ++r)
-                if (r == lrw) {
-                    val[r] = vi;
-                    idx[r] = xi;
-                }
-        }
-        if ((uint32_t)c.lane == li) {
-#pragma unroll
-            for (int r = 0; r < CPL; ++r)
-                if ((uint32_t)r == ri) {
-                    val[r] = m;
-                    idx[r] = xw;
-                }
-        }
-    }
-    // new path pl takes the candidate now sitting at position pl
-    const uint32_t np = (uint32_t)c.pl;
-    const uint32_t ln = lane0 + (np / CPP) * LP + ((np % CPP) / CPL), rn = (np % CPP) % CPL;
-    // fetch register rn of lane ln (rn varies per lane -> select after shuffling every register)
-    float v = shfl_f32(val[0], (int)ln);
-    uint32_t x = shfl_u32(idx[0], (int)ln);
-#pragma unroll
-    for (int r = 1; r < CPL; ++r) {
-        const float vr = shfl_f32(val[r], (int)ln);
-        const uint32_t xr = shfl_u32(idx[r], (int)ln);
-        if ((uint32_t)r == rn) {
-            v = vr;
-            x = xr;
-        }
-    }
-    if (mine) {
-        nval = v;
-        nidx = x;
-    }
-}
-
-// Same selection for the common case of at most one candidate per lane (CPP <= LP): everything that is
-// wave-uniform (maximum, winner lane, the lane holding position i) lives in SGPRs via DPP + v_readlane, and the
-// winner of iteration i IS what new path i inherits, so no permute is needed afterwards.
-template <typename CTX, int LPL, int CPP>
-__device__ __forceinline__ void select_paths_1(const CTX& c, float val, uint32_t newP, float& nval,
-                                               uint32_t& nidx, int tg0 = 0)
-{
-    constexpr int LP = CTX::LP;
-    static_assert(CPP <= LP, "one candidate per lane");
-    constexpr int CS = CPP == 8 ? 3 : (CPP == 4 ? 2 : 1);
-    const uint32_t size = c.P * CPP;
-    const bool mine = c.g0 == tg0;
-    const int lane0 = tg0 << LPL;
-    const bool valid = mine && ((uint32_t)c.j < (uint32_t)CPP) && ((uint32_t)c.pl < c.P);
-    const uint32_t pos = ((uint32_t)c.pl << CS) + (uint32_t)c.j;
-    uint32_t key = valid ? okey(val) : 0u;
-    uint32_t idx = pos;
-    uint32_t rkey = 0, ridx = 0;
-    const uint32_t lim = (size - 1 < newP) ? size - 1 : newP;
-    for (uint32_t i = 0; i < lim; ++i) {
-        const bool el = valid && pos >= i;
-        const uint32_t m = wave_max_u32(el ? key : 0u);
-        const uint64_t bal = ballot64(el && key == m);
-        const int wl = __ffsll((long long)bal) - 1;                  // lowest lane = lowest position
-        const int li = lane0 + (int)(((i >> CS) << LPL) + (i & (CPP - 1)));   // lane holding position i
-        const uint32_t ki = readlane_u32(key, li), xi = readlane_u32(idx, li), xw = readlane_u32(idx, wl);
-        if (c.lane == wl) {
-            key = ki;
-            idx = xi;
-        }
-        if (c.lane == li) {
-            key = m;
-            idx = xw;
-        }
-        if ((uint32_t)c.pl == i) {
-            rkey = m;
-            ridx = xw;
-        }
-    }
-    if (lim < newP) {  // every candidate survives: the last position keeps what is left there
-        const int ll = lane0 + (int)(((lim >> CS) << LPL) + (lim & (CPP - 1)));
-        const uint32_t kl = readlane_u32(key, ll), xl = readlane_u32(idx, ll);
-        if ((uint32_t)c.pl == lim) {
-            rkey = kl;
-            ridx = xl;
-        }
-    }
-    if (mine) {
-        nval = unkey(rkey);
-        nidx = ridx;
-    }
-}
-
 // ---- LP == 8: block of n = 2^S <= 8 LLRs, one per lane (lane j holds |x_j| bits, INFB beyond n) ----------
 // findWeakLlrs emulated literally with "array position = lane": iteration i finds the first minimum among
 // lanes >= i and swaps it with lane i, all with DPP reductions / broadcasts inside the 8-lane path group.
@@ -692,7 +531,7 @@ __device__ __forceinline__ void weak_small4(const CTX& c, uint32_t a0, uint32_t 
 // newP largest in descending order, so candidate c becomes new path  rank(c) = #{d : metric_d > metric_c}.
 // The rank is counted against every candidate slot with fully unrolled v_readlane / v_cmp / v_addc triples
 // (constant lane numbers, no scalar loop bookkeeping).  Candidates with equal metrics get equal ranks and
-// collide in the scatter below; that is detected and handed to the literal emulation (select_paths_1), which
+// collide in the scatter below; that is detected and handed to the literal emulation (select_literal_cw), which
 // reproduces the reference's swap-order tie behaviour.
 template <typename CTX, int CPP>
 __device__ __forceinline__ bool select_ranked8(const CTX& c, float val, uint32_t newP, float& nval,
@@ -893,72 +732,85 @@ __device__ __forceinline__ bool select_threshold(const CTX& c, const float (&val
     return true;
 }
 
-// ---- literal selection for several codewords per wave ---------------------------------------------------------
-// The same emulation of simplePartialSortDescending as select_paths / select_paths_1, but for all codewords of the wave
-// at once: the wave-wide reductions become reductions over the lanes of a codeword (DPP inside the 16-lane rows), so
-// tie-heavy input (quantised LLRs) does not pay one pass per codeword.
+// ---- candidate selection, literal: simplePartialSortDescending(idx, metrics, P', size) arrayfuncs.h:161-183 ----------
+// Candidate position c = path * CPP + q starts in lane path * LP + q / CPL, register q % CPL.  All codewords of the wave
+// run at once (reductions over the lanes of a codeword).  On return every lane knows, for ITS OWN new path index, the
+// winning candidate's metric (nval) and original position (nidx).  This is the fallback of the rank / merge selections
+// when metrics are equal, and THE selection of the int8 decoders, where they always are.
 template <typename CTX, int LPL, int CPP>
 __device__ __forceinline__ void select_literal_cw(const CTX& c, const float (&val)[(CPP >> LPL) ? (CPP >> LPL) : 1],
                                                   uint32_t newP, float& nval, uint32_t& nidx)
 {
-    constexpr int LP = CTX::LP;
+    // Every candidate stays in its lane and carries its CURRENT position in the reference's array; a round of the
+    // selection sort (arrayfuncs.h:161-183) is then one reduction and two local updates: the winner is the lowest current
+    // position among the maxima (strict `>`: first occurrence), it leaves for its rank, and whoever sits at position i
+    // takes over the winner's old place (the swap).  Winners drop (value, original index) into the LDS scratch at their
+    // rank; the new paths read them back at the end.  No cross-lane fetch inside the loop.
     constexpr int CPL = (CPP >> LPL) ? (CPP >> LPL) : 1;
     constexpr int G = 64 / CTX::CW;  // lanes per codeword
     constexpr uint32_t INF = 0xFFFFFFFFu;
-    const uint32_t lane0 = (uint32_t)c.g0 << LPL;
     const uint32_t size = c.P * CPP;
     const uint32_t lim = (size - 1 < newP) ? size - 1 : newP;
-    uint32_t key[CPL], idx[CPL], pos[CPL];
+    uint32_t key[CPL], cur[CPL];  // cur = INF: no candidate, or already picked
 #pragma unroll
     for (int r = 0; r < CPL; ++r) {
         const uint32_t q = (uint32_t)c.j * CPL + r;
         const bool valid = (q < (uint32_t)CPP) && ((uint32_t)c.pl < c.P);
-        pos[r] = valid ? (uint32_t)c.pl * CPP + q : INF;  // (an invalid slot is never eligible and never position i)
-        idx[r] = pos[r];
-        key[r] = valid ? okey(val[r]) : 0u;
+        cur[r] = valid ? (uint32_t)c.pl * CPP + q : INF;
+        if constexpr (CTX::CH)
+            key[r] = (uint32_t)(0.0f - val[r]);  // int8 decoder: -metric, an integer <= 127 N (smaller = better)
+        else
+            key[r] = valid ? okey(val[r]) : 0u;
     }
-    // lane / register that hold position x of this lane's codeword
-    auto lane_of = [&](uint32_t x) { return lane0 + (x / CPP) * LP + ((x % CPP) / CPL); };
-    auto pick = [&](const uint32_t (&a)[CPL], uint32_t rsel) {
-        uint32_t v = a[0];
-#pragma unroll
-        for (int r = 1; r < CPL; ++r) v = (rsel == (uint32_t)r) ? a[r] : v;
-        return v;
-    };
-    uint32_t rkey = 0, ridx = 0;
+    typedef uint32_t __attribute__((address_space(3))) lds_u32;
+    lds_u32* out = (lds_u32*)(uintptr_t)c.scratch + (uint32_t)c.g0 * 2u;  // 2 words per rank, LCW ranks per codeword
     for (uint32_t i = 0; i < lim; ++i) {
-        uint32_t lk = 0, lp = INF;  // first maximum among this lane's eligible positions
+        uint32_t wp;
+        if constexpr (CTX::CH) {  // one reduction: (-metric) << 8 | position  (<= 32 x 8 positions, |metric| < 2^22)
+            uint32_t lk = INF;
+#pragma unroll
+            for (int r = 0; r < CPL; ++r) {
+                const uint32_t kk = (key[r] << 8) | (cur[r] & 255u);
+                lk = (cur[r] != INF && kk < lk) ? kk : lk;
+            }
+            wp = group_min_u32x<G>(lk) & 255u;
+        } else {
+            uint32_t lk = 0, lp = INF;
+#pragma unroll
+            for (int r = 0; r < CPL; ++r) {
+                const bool take = cur[r] != INF && (key[r] > lk || (key[r] == lk && cur[r] < lp));
+                lk = take ? key[r] : lk;
+                lp = take ? cur[r] : lp;
+            }
+            const uint32_t M = group_max_u32x<G>(lk);
+            wp = group_min_u32x<G>((lk == M) ? lp : INF);
+        }
 #pragma unroll
         for (int r = 0; r < CPL; ++r) {
-            const bool take = pos[r] != INF && pos[r] >= i && key[r] > lk;
-            lk = take ? key[r] : lk;
-            lp = take ? pos[r] : lp;
+            const bool win = cur[r] == wp;
+            if (win) {
+                out[2u * i] = key[r];
+                out[2u * i + 1u] = (uint32_t)c.pl * CPP + (uint32_t)c.j * CPL + (uint32_t)r;
+            }
+            cur[r] = win ? INF : (cur[r] == i ? wp : cur[r]);
         }
-        const uint32_t M = group_max_u32<G>(lk);
-        const uint32_t wp = group_min_u32<G>((lk == M) ? lp : INF);  // winner: lowest position holding the maximum
-        const uint32_t ri = (i % CPP) % CPL, rw = (wp % CPP) % CPL;
-        const uint32_t ki = shfl_u32(pick(key, ri), (int)lane_of(i)), xi = shfl_u32(pick(idx, ri), (int)lane_of(i));
-        const uint32_t xw = shfl_u32(pick(idx, rw), (int)lane_of(wp));
+    }
+    if (lim < newP) {  // every candidate survives: the one that is left sits at position lim and stays there
 #pragma unroll
-        for (int r = 0; r < CPL; ++r) {
-            const bool at_w = pos[r] == wp, at_i = pos[r] == i;
-            key[r] = at_i ? M : (at_w ? ki : key[r]);
-            idx[r] = at_i ? xw : (at_w ? xi : idx[r]);
-        }
-        if ((uint32_t)c.pl == i) {
-            rkey = M;
-            ridx = xw;
-        }
+        for (int r = 0; r < CPL; ++r)
+            if (cur[r] != INF) {
+                out[2u * lim] = key[r];
+                out[2u * lim + 1u] = (uint32_t)c.pl * CPP + (uint32_t)c.j * CPL + (uint32_t)r;
+            }
     }
-    if (lim < newP) {  // every candidate survives: the last position keeps what is left there
-        const uint32_t rl = (lim % CPP) % CPL;
-        const uint32_t kl = shfl_u32(pick(key, rl), (int)lane_of(lim)), xl = shfl_u32(pick(idx, rl), (int)lane_of(lim));
-        if ((uint32_t)c.pl == lim) {
-            rkey = kl;
-            ridx = xl;
-        }
-    }
-    nval = unkey(rkey);
+    WAVE_SYNC();
+    const uint32_t me = (uint32_t)c.pl < newP ? (uint32_t)c.pl : 0u;
+    const uint32_t rkey = out[2u * me], ridx = out[2u * me + 1u];
+    WAVE_SYNC();  // (the scratch is reused by the next selection)
+    if constexpr (CTX::CH)
+        nval = 0.0f - (float)rkey;
+    else
+        nval = unkey(rkey);
     nidx = ridx;
 }
 
@@ -1028,13 +880,6 @@ __device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t
 {
     static_assert(CTX::LP == 4 && CTX::CW == 2 && CTX::LCW == 8, "8 path groups of 4 lanes per codeword");
     constexpr uint32_t INFK = 0xFFFFFFFFu;
-    if constexpr (CTX::CH) {
-        // int8 decoder: metrics are integers (|m| < 2^18 up to N = 2048), so equal metrics are the rule, not the exception.
-        // The key becomes (-m) << 6 | position: all keys differ and equal metrics order by ascending position, which is the
-        // order simplePartialSortDescending picks them in as long as none of them has been moved by a swap (see below).
-        k0 = k0 == INFK ? INFK : ((((uint32_t)bitsf(k0 ^ 0x80000000u)) << 6) | x0);
-        if constexpr (CPP == 8) k1 = k1 == INFK ? INFK : ((((uint32_t)bitsf(k1 ^ 0x80000000u)) << 6) | x1);
-    }
     uint32_t k = k0, x = x0, pk;
     if constexpr (CPP == 8) {  // a_i against b_(7-i): the other quad's second register, mirrored; keep the smaller
         asm volatile("s_nop 1\n\t"
@@ -1073,44 +918,7 @@ __device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t
     const uint32_t src = ((uint32_t)c.lane & ~7u) | (pl < 4u ? pl : 11u - pl);
     const uint32_t nx = dpp_u32<0x39>(k), n4 = dpp_u32<0x124>(k);
     const uint32_t rl = newP - 1u, tl = rl < 4u ? rl : 11u - rl;
-    if constexpr (CTX::CH) {
-        const uint32_t t0 = readlane_u32(k, (int)tl), t1 = readlane_u32(k, (int)(32u + tl));
-        // Equal metrics are exact in position order unless a swap of the selection sort has moved one of them: round i
-        // moves the element at position i to the winner's old place when it is not the winner itself, so only the elements
-        // that START at the positions below lim = min(size - 1, newP) ever move, such an element has moved by the time it
-        // is picked iff its rank is larger than its start position p, and the place it moved to is where the winner of
-        // round p (= the element of rank p) came from.  With that effective position in place of the start position the
-        // ranks must still ascend inside every run of equal metrics; a second move (the new place is again below lim, or
-        // the winner had moved itself), an order that does not hold, or a run that crosses the cut and contains a moved
-        // picked element goes to the literal emulation.
-        const uint32_t size = c.P * (uint32_t)CPP, lim = (size - 1u < newP) ? size - 1u : newP;
-        const uint32_t j8 = (uint32_t)c.lane & 7u, r = j8 < 4u ? j8 : 11u - j8;
-        const uint32_t pos = k & 63u, mk = k >> 6;
-        const bool moved = k != INFK && pos < lim && r > pos;
-        const uint32_t wl = ((uint32_t)c.lane & ~7u) | (moved ? (pos < 4u ? pos : 11u - pos) : j8);
-        const uint32_t wk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wl << 2), (int)(k | (moved ? 0x80000000u : 0u)));
-        // (0xFFFFFFFF: moved twice -- no effective position is derived, any tie of this element falls back)
-        const uint32_t eff = moved ? (((wk >> 31) != 0u || (wk & 63u) < lim) ? INFK : (wk & 63u)) : pos;
-        const uint32_t ex = dpp_u32<0x39>(eff), e4 = dpp_u32<0x124>(eff);
-        const bool tq = k != INFK && mk == (nx >> 6), t4 = k != INFK && mk == (n4 >> 6);
-        const bool bad = (tq && j8 < 3u && (eff >= ex || ex == INFK)) || (tq && j8 >= 4u && j8 < 7u && (ex >= eff || eff == INFK)) ||
-                         (t4 && j8 == 3u && (eff >= e4 || e4 == INFK));
-        const uint32_t tm0 = t0 >> 6, tm1 = t1 >> 6, tm = ((uint32_t)c.lane & 32u) ? tm1 : tm0;
-        uint32_t n0 = (uint32_t)__popc((uint32_t)ballot64((k0 >> 6) <= tm0)), n1 = (uint32_t)__popc((uint32_t)(ballot64((k0 >> 6) <= tm1) >> 32));
-        if constexpr (CPP == 8) {
-            n0 += (uint32_t)__popc((uint32_t)ballot64((k1 >> 6) <= tm0));
-            n1 += (uint32_t)__popc((uint32_t)(ballot64((k1 >> 6) <= tm1) >> 32));
-        }
-        // a run of equal metrics that crosses the cut: exact unless one of its PICKED members has moved (an element that
-        // is not picked in position order stays unpicked when it moves further back, and nobody else's place changes)
-        const uint64_t mrun = ballot64(r < newP && mk == tm && moved);
-        const bool cut0 = n0 != newP && (uint32_t)mrun != 0u, cut1 = n1 != newP && (uint32_t)(mrun >> 32) != 0u;
-        if (ballot64(bad) != 0 || cut0 || cut1) return false;
-        const uint32_t rk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)k);
-        nval = 0.0f - (float)(rk >> 6);
-        nidx = rk & 63u;
-        return true;
-    } else {
+    {
         // exact ties among the winners: ranks r | r + 1 are quad neighbours (rotation by one lane; its wrap-around pair and
         // the pairs of the second comparison that are not neighbours compare two ranks of the same list, so an equality
         // there is a tie as well), ranks 3 | 4 sit in lanes 3 | 7 (rotation of the row by four lanes) ...
@@ -1143,7 +951,9 @@ __device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP 
     }
     nval = 0.0f;
     nidx = 0;
-    if constexpr (LPL == 3) {
+    if constexpr (CTX::CH) {
+        // int8 decoder: equal metrics are the rule, the rank-based selections would fall back almost every time
+    } else if constexpr (LPL == 3) {
         if (select_ranked8<CTX, CPP>(c, val[0], newP, nval, nidx)) return;
     } else if (c.P * CPP > newP) {
         // (when every candidate survives, the reference leaves the last position unsorted: literal code below)
@@ -1155,13 +965,7 @@ __device__ __forceinline__ void select_dispatch(const CTX& c, float (&val)[(CPP 
         }
     }
     // literal emulation of the reference's swap order
-    if constexpr (CTX::CW > 1) {
-        select_literal_cw<CTX, LPL, CPP>(c, val, newP, nval, nidx);
-    } else if constexpr (CPP <= (1 << LPL)) {
-        select_paths_1<CTX, LPL, CPP>(c, val[0], newP, nval, nidx, 0);
-    } else {
-        select_paths<CTX, LPL, CPP>(c, val, newP, nval, nidx, 0);
-    }
+    select_literal_cw<CTX, LPL, CPP>(c, val, newP, nval, nidx);
 }
 
 // write the n leaf bits of every (new) path: sign(x_src[i]) ^ flips, packed, into area(side)[stage]
@@ -1609,7 +1413,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? PAMD_WAVES_
                     };
                     if constexpr (kMerge) {
                         bool done = false;
-                        if (c.P * 8 > newP && !(c.ablate & 1u)) {
+                        if (!CH && c.P * 8 > newP && !(c.ablate & 1u)) {
                             // the path's candidates best first: c0 c1 c2 {c3, c4} c5 c6 c7 -- element i in register
                             // i / 4 of lane i % 4 (select_merge); branch-free per-lane selects
                             const uint32_t j = (uint32_t)c.j;
@@ -1657,7 +1461,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? PAMD_WAVES_
                     };
                     if constexpr (kMerge) {
                         bool done = false;
-                        if (c.P * 4 > newP && !(c.ablate & 1u)) {  // m >= m - v0 >= m - v1 >= (m - v0) - v1: lane j holds candidate j
+                        if (!CH && c.P * 4 > newP && !(c.ablate & 1u)) {  // m >= m - v0 >= m - v1 >= (m - v0) - v1: lane j holds candidate j
                             const uint32_t j = (uint32_t)c.j;
                             const float d0 = m - v0;
                             const float e0 = j == 0 ? m : (j == 1 ? d0 : (j == 2 ? m - v1 : d0 - v1));
@@ -2066,11 +1870,11 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? PAMD_WAVES_
                     val[r] = (q == 0) ? c.metric + z : c.metric - o;
                 }
                 const uint32_t newP = (c.P * 2 < c.L) ? c.P * 2 : c.L;
-                float nval;
-                uint32_t nidx;
+                float nval = 0.0f;
+                uint32_t nidx = 0;
                 bool done = false;
                 if constexpr (kMerge) {
-                    if (c.P * 2 > newP && !(c.ablate & 1u)) {  // the better of the two in lane 0, the other in lane 1
+                    if (!CH && c.P * 2 > newP && !(c.ablate & 1u)) {  // the better of the two in lane 0, the other in lane 1
                         const float ca = c.metric + z, cb = c.metric - o;
                         const bool sw = fbits(cb) < fbits(ca);
                         const bool first = c.j == 0;

@@ -525,12 +525,12 @@ def test_char_decoders_vs_oracle_random(built_library, N, L):
         assert np.array_equal(res[0], e_out) and np.array_equal(res[1].astype(np.uint8), e_ok), (N, L, K, "nsys")
 
 
-@pytest.mark.parametrize("N,L", [(256, 4), (1024, 8), (2048, 8)])
+@pytest.mark.parametrize("N,L", [(256, 4), (1024, 8), (2048, 8), (512, 16), (256, 32), (1024, 2)])
 def test_char_list_decoder_equal_metrics_everywhere(built_library, N, L):
     """int8 rows of tiny magnitude: nearly every candidate selection has equal metrics among the winners and across the
-    cut.  The merge selection orders them by position and only falls back to the literal emulation of
-    simplePartialSortDescending (arrayfuncs.h:161-183) when a swap has moved one of them (scl_kernel.h, select_merge):
-    bytes, verdicts and all L metrics must equal the oracle's.  tools/char_stress_vs_oracle.py is the long form."""
+    cut, so the order simplePartialSortDescending (arrayfuncs.h:161-183) leaves them in -- including the swaps that move
+    candidates around -- decides which paths survive and where (scl_kernel.h, select_literal_cw): bytes, verdicts and all
+    L metrics must equal the oracle's.  tools/char_stress_vs_oracle.py is the long form."""
     import pypolar_amd
     from pypolar_amd.construction import frozen_bits
     rng = np.random.default_rng(N + L)

@@ -17,7 +17,7 @@ for N in (64, 256, 1024, 2048):
     for rate in (0.25, 0.5, 0.75):
         K = int(N * rate) // 8 * 8
         frozen = np.asarray(frozen_bits(N, K, 0.0, "BB"), dtype=np.uint32)
-        for L in (2, 4, 8):
+        for L in ((2, 4, 8, 16, 32) if N <= 1024 else (2, 4, 8)):
             for crc in ((0, "crc"), (8, "crc")):
                 for amp in (1, 3, 12, 127):   # magnitudes 0 ... amp: the smaller, the more equal metrics
                     llr = rng.integers(-amp, amp + 1, (B, N)).astype(np.int8)
