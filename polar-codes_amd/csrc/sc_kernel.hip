@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
 {
     constexpr int LC = 1 << LCL;
     constexpr int CW = 64 >> LCL;  // codewords per wave
-    extern __shared__ uint32_t smem[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const uint32_t wpb = blockDim.x >> 6;
@@ -644,6 +644,54 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
                 // instead of living in LDS -- left half: f(x_i, x_{i+N/2}); right half: g(.., root-left bit i) where
                 // the root's left output still sits untouched in bits[0, N/2)
                 const uint32_t hN = N >> 1;
+                const bool fgop = op == SC_F || op == SC_G || op == SC_G0R;
+                if (LCL == 4 && fgop && h >= 4u * LC) {
+                    // the root's grandchild block, four consecutive LLRs per lane and trip: four 16-byte channel loads (one
+                    // 4-byte load each for int8 rows), one 16-byte store, the steering bits four at a time
+                    auto ch4 = [&](uint32_t j) -> float4 {
+                        if constexpr (I8) {
+                            const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const int8_t*>(chan) + j);
+                            return make_float4((float)(int8_t)(w & 0xFFu), (float)(int8_t)((w >> 8) & 0xFFu),
+                                               (float)(int8_t)((w >> 16) & 0xFFu), (float)(int8_t)(w >> 24));
+                        } else {
+                            return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(chan) + j);
+                        }
+                    };
+                    auto f4 = [](const float4& a, const float4& b) {
+                        return make_float4(polar_fx<CH>(a.x, b.x), polar_fx<CH>(a.y, b.y), polar_fx<CH>(a.z, b.z), polar_fx<CH>(a.w, b.w));
+                    };
+                    auto a4 = [](const float4& a, const float4& b) {
+                        return make_float4(addx<CH>(a.x, b.x), addx<CH>(a.y, b.y), addx<CH>(a.z, b.z), addx<CH>(a.w, b.w));
+                    };
+                    auto g4 = [](const float4& a, const float4& b, uint32_t u) {
+                        return make_float4(polar_gx<CH>(a.x, b.x, u & 1u), polar_gx<CH>(a.y, b.y, (u >> 1) & 1u),
+                                           polar_gx<CH>(a.z, b.z, (u >> 2) & 1u), polar_gx<CH>(a.w, b.w, (u >> 3) & 1u));
+                    };
+                    auto bits4 = [&](uint32_t j) { return (bits[j >> 5] >> (j & 31u)) & 0xFu; };
+                    auto trips = [&](auto x4) {
+                        for (uint32_t i0 = 0; i0 < h; i0 += 4u * LC) {
+                            const uint32_t i = i0 + 4u * (uint32_t)l;
+                            const float4 a = x4(i), b = x4(h + i);
+                            float4 r;
+                            if (op == SC_F)
+                                r = f4(a, b);
+                            else if (op == SC_G0R)
+                                r = a4(a, b);
+                            else
+                                r = g4(a, b, bits4(off + i));
+                            if (ARENA && s - 1 >= s0)
+                                *reinterpret_cast<float4*>(ar + h + i) = r;
+                            else
+                                *reinterpret_cast<float4*>(llr + h + i) = r;
+                        }
+                    };
+                    if (off == 0)
+                        trips([&](uint32_t j) { return f4(ch4(j), ch4(hN + j)); });
+                    else if (P.prog_root_g0r)
+                        trips([&](uint32_t j) { return a4(ch4(j), ch4(hN + j)); });
+                    else
+                        trips([&](uint32_t j) { return g4(ch4(j), ch4(hN + j), bits4(j)); });
+                } else
                 if (off == 0)
                     run([&](uint32_t i) { return polar_fx<CH>(ch(i), ch(hN + i)); });
                 else if (P.prog_root_g0r)
