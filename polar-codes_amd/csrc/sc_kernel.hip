@@ -220,8 +220,15 @@ __device__ __forceinline__ float reduce_add8(const float a[8])
 // N = 1024 on; it costs registers (86 -> 115 VGPRs, 4 instead of 5 waves per SIMD), which shorter blocks -- whose LDS
 // footprint would allow the fifth wave -- pay with 15 %, so the host picks by block length.
 // CH: int8 arithmetic (FastSscFipChar): saturating f / g on int8-valued floats and the SCC_* leaves
+// Blocks up to N = 512 (the plain variant): the LDS slice is small, resident waves are bounded by registers, and each
+// instruction does little work -- so this variant is compiled for 8 waves per SIMD (<= 64 VGPRs) and keeps lane-derived
+// values hoisted (no per-instruction re-derivation, see the interpreter loop).  Measured N = 64 / 128 / 256 / 512:
+// 1.65 / 1.05 / 0.63 / 0.35 G cw/s with the re-derivation -> 1.78 / 1.17 / 0.77 / 0.43 G cw/s.
+#ifndef PAMD_SC_SMALL_WAVES
+#define PAMD_SC_SMALL_WAVES 8
+#endif
 template <int LCL, bool I8, bool DIAG = false, bool ARENA = false, bool B2 = false, bool CH = false>
-__global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
+__global__ __launch_bounds__(256, (!B2 && !ARENA && !CH && !DIAG && LCL <= 4) ? PAMD_SC_SMALL_WAVES : 1) void sc_decode_kernel(DecodeParams P)
 {
     constexpr int LC = 1 << LCL;
     constexpr int CW = 64 >> LCL;  // codewords per wave
@@ -261,10 +268,13 @@ __global__ __launch_bounds__(256) void sc_decode_kernel(DecodeParams P)
         for (uint32_t pc = 0; pc < P.prog_len; ++pc) {
             // the lane number is made opaque once per instruction: lane predicates (64-bit SGPR masks) and other values
             // derived from it are then re-derived per instruction instead of being hoisted out of the interpreter loop
-            // (the kernel sits at the SGPR limit: hoisted masks were spilled to VGPR lanes)
-            asm volatile("" : "+v"(lane_v));
-            g.l = lane_v & (LC - 1);
-            g.lbase = lane_v & ~(LC - 1);
+            // (the kernel sits at the SGPR limit: hoisted masks were spilled to VGPR lanes).  Not for the short-block
+            // variant, which does too little per instruction to pay for it.
+            if constexpr (B2 || ARENA || CH) {
+                asm volatile("" : "+v"(lane_v));
+                g.l = lane_v & (LC - 1);
+                g.lbase = lane_v & ~(LC - 1);
+            }
             const int l = g.l;
             const uint64_t iw = iw_next;
             const uint32_t op = (uint32_t)(iw & 0xFF);
