@@ -157,7 +157,11 @@ void compute_geometry(pcd_decoder* d)
     // root's children are inner nodes or leaves reading through the same accessor (always possible; N >= 16).
     d->sc_virtual_top = (N >= 16 && !PAMD_ENV("PCD_SC_NO_VIRTUAL")) ? 1u : 0u;
     d->sc_wave_words = ((d->sc_virtual_top ? N / 2 : N) + bitw + 3) & ~3u;
-    d->sc_lcl = N <= 2048 ? 4 : 6;  // 16 lanes per codeword while four codewords still leave >= 9 waves per CU
+    // 16 lanes per codeword while four codewords still leave >= 9 waves per CU; 8 lanes (eight codewords per wave share
+    // every wave-uniform cost, and the leaves of <= 8 LLRs use all their lanes) up to N = 256 -- measured N = 64 / 128 / 256:
+    // 1.80 / 1.17 / 0.77 -> 3.30 / 1.90 / 0.96 G cw/s, but N = 512: 0.43 -> 0.34 (the LDS slices of eight codewords)
+    d->sc_lcl = N <= 256 ? 3 : (N <= 2048 ? 4 : 6);
+    if (d->dectype == 0 && d->sc_lcl == 3) d->sc_lcl = 4;  // (the int8 reductions need the 32 byte lanes on 16 or 64 lanes)
     if (const char* e = PAMD_ENV("PCD_SC_LCL")) {  // experiments
         const int v = std::atoi(e);
         d->sc_lcl = (v == 3 || v == 6) ? v : 4;
