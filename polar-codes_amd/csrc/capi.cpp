@@ -201,10 +201,13 @@ void compute_geometry(pcd_decoder* d)
         // the skeleton of the small ops are shared.  L <= 2: 8 lanes per path x 4 codewords; L <= 4: 8 x 2;
         // L <= 8: 4 lanes per path x 2 codewords up to N = 2048 (measured at cfg 3: 12.0 -> 15.4 M cw/s against 8 lanes
         // x 1; from N = 4096 on the wide F / G passes dominate and 8 lanes x 1 codeword is 5-10 % faster).
-        d->cwl = lprime == 2 ? 2u : (lprime == 4 ? 1u : (lprime == 8 && d->logN <= 11 ? 1u : 0u));
+        // (4 lanes per path for every L <= 8 up to N = 2048 -- L <= 2: 8 codewords per wave, L <= 4: 4, L <= 8: 2; measured against
+        //  8 lanes per path x 4 / 2 codewords: L = 2 x 1.6 (N = 2048) ... x 2.8 (N = 64), L = 4 x 1.4 ... x 1.65; from N = 4096 on
+        //  the 8-lane forms are 5-40 % faster again)
+        d->cwl = lprime == 2 ? (d->logN <= 11 ? 3u : 2u) : (lprime == 4 ? (d->logN <= 11 ? 2u : 1u) : (lprime == 8 && d->logN <= 11 ? 1u : 0u));
         if (const char* e = PAMD_ENV("PCD_CWL")) {  // experiments: 0 = one codeword per wave; 1 at L <= 8: 4 lanes per path
             const unsigned v = (unsigned)std::atoi(e);
-            d->cwl = (lprime == 2 && v <= 2) || (lprime <= 8 && v <= 1) ? v : 0u;
+            d->cwl = (lprime == 2 && v <= 3) || (lprime == 4 && v <= 2) || (lprime <= 8 && v <= 1) ? v : 0u;
             if (lprime == 2 && v == 1) d->cwl = 0;  // (8 lanes x 2 paths x 2 codewords has no kernel)
         }
         const unsigned lmax = lprime << d->cwl;  // path groups (= path buffers) per wave

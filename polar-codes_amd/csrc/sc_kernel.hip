@@ -922,6 +922,8 @@ hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, un
     case 2 * 4 + 1: return launch_scl_inst_2_1(P, i8, diag, g, b, lds, st, occupancy);  // L <= 8: 4 lanes per path, 2 codewords
     case 3 * 4 + 1: return launch_scl_inst_3_1(P, i8, diag, g, b, lds, st, occupancy);  // L <= 4: 8 lanes per path, 2 codewords
     case 3 * 4 + 2: return launch_scl_inst_3_2(P, i8, diag, g, b, lds, st, occupancy);  // L <= 2: 8 lanes per path, 4 codewords
+    case 2 * 4 + 2: return launch_scl_inst_2_2(P, i8, diag, g, b, lds, st, occupancy);  // L <= 4: 4 lanes per path, 4 codewords
+    case 2 * 4 + 3: return launch_scl_inst_2_3(P, i8, diag, g, b, lds, st, occupancy);  // L <= 2: 4 lanes per path, 8 codewords
     default: return hipErrorInvalidValue;
     }
 }

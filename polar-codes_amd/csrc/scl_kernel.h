@@ -1153,8 +1153,9 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? PAMD_WAVES_
                     t = 0;
                     return ql;
                 } else {
-                    t = (ql >= c.P) ? 1u : 0u;
-                    if constexpr (CW > 2) t += ((ql >= 2u * c.P) ? 1u : 0u) + ((ql >= 3u * c.P) ? 1u : 0u);
+                    t = 0;
+#pragma unroll
+                    for (uint32_t m = 1; m < (uint32_t)CW; ++m) t += (ql >= m * c.P) ? 1u : 0u;
                     return t * (uint32_t)LCW + (ql - t * c.P);
                 }
             };

@@ -13,5 +13,7 @@ hipError_t launch_scl_inst_5_0(const DecodeParams& P, bool i8, bool diag, dim3 g
 hipError_t launch_scl_inst_2_1(const DecodeParams& P, bool i8, bool diag, dim3 grid, dim3 block, size_t lds, hipStream_t st, int* occ);
 hipError_t launch_scl_inst_3_1(const DecodeParams& P, bool i8, bool diag, dim3 grid, dim3 block, size_t lds, hipStream_t st, int* occ);
 hipError_t launch_scl_inst_3_2(const DecodeParams& P, bool i8, bool diag, dim3 grid, dim3 block, size_t lds, hipStream_t st, int* occ);
+hipError_t launch_scl_inst_2_2(const DecodeParams& P, bool i8, bool diag, dim3 grid, dim3 block, size_t lds, hipStream_t st, int* occ);
+hipError_t launch_scl_inst_2_3(const DecodeParams& P, bool i8, bool diag, dim3 grid, dim3 block, size_t lds, hipStream_t st, int* occ);
 
 }  // namespace pamd
