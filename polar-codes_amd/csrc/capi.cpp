@@ -202,8 +202,9 @@ void compute_geometry(pcd_decoder* d)
         // L <= 8: 4 lanes per path x 2 codewords up to N = 2048 (measured at cfg 3: 12.0 -> 15.4 M cw/s against 8 lanes
         // x 1; from N = 4096 on the wide F / G passes dominate and 8 lanes x 1 codeword is 5-10 % faster).
         // (4 lanes per path for every L <= 8 up to N = 2048 -- L <= 2: 8 codewords per wave, L <= 4: 4, L <= 8: 2; measured against
-        //  8 lanes per path x 4 / 2 codewords: L = 2 x 1.6 (N = 2048) ... x 2.8 (N = 64), L = 4 x 1.4 ... x 1.65; from N = 4096 on
-        //  the 8-lane forms are 5-40 % faster again)
+        //  8 lanes per path x 4 / 2 codewords (profiles/r02_perf_sweep.txt): L = 2 +33 % at N = 128, +6 % at 512, +10 % at 2048,
+        //  level at 1024; L = 4 +41 % / +19 % / +10 % / +5 % at N = 128 / 512 / 1024 / 2048; from N = 4096 on the 8-lane forms
+        //  are 5-40 % faster again)
         d->cwl = lprime == 2 ? (d->logN <= 11 ? 3u : 2u) : (lprime == 4 ? (d->logN <= 11 ? 2u : 1u) : (lprime == 8 && d->logN <= 11 ? 1u : 0u));
         if (const char* e = PAMD_ENV("PCD_CWL")) {  // experiments: 0 = one codeword per wave; 1 at L <= 8: 4 lanes per path
             const unsigned v = (unsigned)std::atoi(e);
