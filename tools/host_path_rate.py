@@ -26,6 +26,21 @@ for name, arr in (("pageable numpy", llr),):
     print("per call ms:", [round(t * 1e3, 1) for t in ts])
     dt = min(ts)
     print(f"{name}: {B / dt / 1e6:.2f} M cw/s  ({B * N * 4 / dt / 1e9:.1f} GB/s of LLRs over PCIe incl. the kernel)")
+# int8 rows (decode_vector(const char*) / pcd_decode_i8): a quarter of the bytes over PCIe
+for dectype in ("float", "char"):
+    d8 = pypolar_amd.PolarDecoder(N, L, frozen_bits(N, K, 0.0, "BB"), dectype)
+    d8.setErrorDetection(24, "crcnr")
+    B8 = 1 << 19
+    rows = np.random.default_rng(1).integers(-30, 56, (B8, N), dtype=np.int8)  # (any rows: the rate does not depend on them)
+    d8.decode_batch(rows[:4096])
+    d8.decode_batch(rows)
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        d8.decode_batch(rows)
+        ts.append(time.perf_counter() - t0)
+    dt = min(ts)
+    print(f"int8 rows, pageable numpy, \"{dectype}\" decoder: {B8 / dt / 1e6:.2f} M cw/s  ({B8 * N / dt / 1e9:.1f} GB/s of LLRs)")
 try:
     import torch
     pin = torch.from_numpy(llr).pin_memory()
