@@ -1798,7 +1798,14 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? PAMD_WAVES_
 #pragma unroll
                         for (int a = 0; a < NACC; ++a) {
                             const uint32_t v = (uint32_t)c.j + (uint32_t)a * LP;
-                            for (uint32_t i = v; i < n; i += 8) acc[a] = acc[a] + min0(x[i]);
+                            if (n >= 32) {  // four loads in flight per accumulator (arena blocks: one global latency per 4 adds)
+                                for (uint32_t i = v; i < n; i += 32) {
+                                    const float x0 = x[i], x1 = x[i + 8], x2 = x[i + 16], x3 = x[i + 24];
+                                    acc[a] = (((acc[a] + min0(x0)) + min0(x1)) + min0(x2)) + min0(x3);
+                                }
+                            } else {
+                                for (uint32_t i = v; i < n; i += 8) acc[a] = acc[a] + min0(x[i]);
+                            }
                             if (v >= n) acc[a] = acc[a] + 0.0f;
                         }
                     };
