@@ -319,3 +319,22 @@ def test_sc_builder_refuses_the_sets_the_reference_refuses(built_library):
         d8 = pypolar_amd.PolarDecoder(N, 8, F, "float")
         assert d8.program_stats(True) == ob.tree_stats(N, F, True)[1:]
     assert n_ok >= 40 and n_bad >= 200
+
+
+@pytest.mark.parametrize("N,L,cw,groups", [
+    (128, 1, 8, 1), (256, 1, 8, 1), (512, 1, 4, 1), (1024, 1, 4, 1), (4096, 1, 4, 1),        # SC: 8 lanes per codeword up to 256
+    (1024, 2, 8, 16), (1024, 4, 4, 16), (1024, 8, 2, 16), (2048, 3, 4, 16),                    # 4 lanes per path up to N = 2048
+    (4096, 2, 4, 8), (4096, 4, 2, 8), (4096, 8, 1, 8), (1024, 16, 1, 16), (4096, 32, 1, 32)])  # 8 lanes / one codeword above
+def test_launch_geometry_choices(built_library, N, L, cw, groups):
+    """codewords per wave and path groups per wave the host picks (capi.cpp, compute_geometry): the measured choices of
+    DESIGN.md section 3 -- a change here is a performance change and should come with a sweep (tools/perf_sweep.py)"""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    d = pypolar_amd.PolarDecoder(N, L, frozen_bits(N, N // 2, 0.0, "BB"), "float")
+    info = d.launch_info(L > 1)
+    assert info["codewords_per_workgroup"] == cw, info
+    assert info["path_groups"] == groups, info
+    # the int8 SC decoder keeps 16 lanes per codeword (its reductions run over the 32 byte lanes of a 16-lane group)
+    if L == 1 and N <= 256:
+        d8 = pypolar_amd.PolarDecoder(N, 1, frozen_bits(N, N // 2, 0.0, "BB"), "char")
+        assert d8.launch_info(False)["codewords_per_workgroup"] == 4
