@@ -878,7 +878,8 @@ template <typename CTX, int CPP>
 __device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t x0, uint32_t k1, uint32_t x1,
                                              uint32_t newP, float& nval, uint32_t& nidx)
 {
-    static_assert(CTX::LP == 4 && CTX::CW == 2 && CTX::LCW == 8, "8 path groups of 4 lanes per codeword");
+    static_assert(CTX::LP == 4 && (CTX::LCW == 8 || CTX::LCW == 4 || CTX::LCW == 2), "8 / 4 / 2 path groups of 4 lanes per codeword");
+    constexpr int LCW = CTX::LCW;
     constexpr uint32_t INFK = 0xFFFFFFFFu;
     uint32_t k = k0, x = x0, pk;
     if constexpr (CPP == 8) {  // a_i against b_(7-i): the other quad's second register, mirrored; keep the smaller
@@ -891,7 +892,8 @@ __device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t
                      : "v"(k1), "v"(x1)
                      : "vcc");
     }
-    merge_sort8<3>(k, x);
+    merge_sort8<(LCW > 2 ? 3 : -1)>(k, x);
+    if constexpr (LCW > 2) {
     // the 8-lane neighbour group of the row (lane ^ 8) holds its list the other way round
     asm volatile("s_nop 1\n\t"
                  "v_mov_b32_dpp %2, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -901,8 +903,9 @@ __device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t
                  : "+v"(k), "+v"(x), "=&v"(pk)
                  :
                  : "vcc");
-    merge_sort8<4>(k, x);
-    {
+    merge_sort8<(LCW > 4 ? 4 : -1)>(k, x);
+    }
+    if constexpr (LCW > 4) {
         // lane ^ 16: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the second.
         // With both operands = k the results are {row 0, row 0, row 2, row 2} and {row 1, row 1, row 3, row 3}: in every
         // lane one of them is the partner's key and the other the lane's own, so no lane predicate is needed
@@ -911,14 +914,30 @@ __device__ __forceinline__ bool select_merge(const CTX& c, uint32_t k0, uint32_t
         const bool ta = sk[0] < k, tb = sk[1] < k;
         x = ta ? sx[0] : (tb ? sx[1] : x);
         k = ta ? sk[0] : (tb ? sk[1] : k);
+        merge_sort8<-1>(k, x);
     }
-    merge_sort8<-1>(k, x);
     // new path pl inherits the candidate of rank pl
     const uint32_t pl = (uint32_t)c.pl;
     const uint32_t src = ((uint32_t)c.lane & ~7u) | (pl < 4u ? pl : 11u - pl);
     const uint32_t nx = dpp_u32<0x39>(k), n4 = dpp_u32<0x124>(k);
     const uint32_t rl = newP - 1u, tl = rl < 4u ? rl : 11u - rl;
-    {
+    if constexpr (LCW < 8) {
+        // four or eight codewords per wave: the checks of the two-codeword form below, without per-codeword scalars -- the
+        // cut key comes from the lane's own 8-lane group (every group of a codeword holds the sorted winners), the count
+        // "candidates at or below it" is the population of the codeword's segment of one ballot
+        constexpr uint32_t G = 4u * (uint32_t)LCW;  // lanes per codeword
+        const bool tie = k != INFK && (k == nx || k == n4);
+        const uint32_t rk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)k);
+        const uint32_t rx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)x);
+        const uint32_t tv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)c.lane & ~7u) | tl) << 2), (int)k);
+        const uint32_t sh = (uint32_t)c.lane & ~(G - 1u);
+        uint32_t cnt = (uint32_t)__popc((uint32_t)(ballot64(k0 <= tv) >> sh) & ((1u << G) - 1u));
+        if constexpr (CPP == 8) cnt += (uint32_t)__popc((uint32_t)(ballot64(k1 <= tv) >> sh) & ((1u << G) - 1u));
+        if (ballot64(tie || cnt != newP) != 0) return false;
+        nval = bitsf(rk);
+        nidx = rx;
+        return true;
+    } else {
         // exact ties among the winners: ranks r | r + 1 are quad neighbours (rotation by one lane; its wrap-around pair and
         // the pairs of the second comparison that are not neighbours compare two ranks of the same list, so an equality
         // there is a tie as well), ranks 3 | 4 sit in lanes 3 | 7 (rotation of the row by four lanes) ...
@@ -1177,7 +1196,8 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? PAMD_WAVES_
             //   bits 0-1: input is 1 = F of the parent's LLRs, 2 = G, 3 = G after an all-frozen left sibling (whose
             //             F + RateZero step runs here too);  bits 2-4: COMBINEs that follow;  bit 5: side of the last
             constexpr bool kFuse = LPL == 2 || LPL == 3;  // (8 lanes per path: lane j holds LLR j, x1 is unused)
-            constexpr bool kMerge = LPL == 2 && CWL == 1;  // candidate selection by select_merge
+            constexpr bool kMerge = LPL == 2 && CWL >= 1;  // candidate selection by select_merge (4 lanes per path, 8 / 4 / 2 paths)
+            constexpr bool kTop8 = LPL == 2 && CWL == 1;   // the N = 1024 chunk-major ops (SCL_VTOP, SCL_VG2): 8 paths x 2 codewords
             const uint32_t fuse = kFuse ? ((uint32_t)(iw >> 24) & 0xFFu) : 0u;
             auto leaf_input4 = [&](float& x0, float& x1) {  // LLRs j and j + 4 of this lane's path
                 const bool in0 = (uint32_t)c.j < n, in1 = LP == 4 && n == 8;
@@ -1959,7 +1979,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? PAMD_WAVES_
                 c.set_field(s);
                 c.set_field(s - 1);
             } else if (ins.op == SCL_VG2) {
-                if constexpr (kMerge && !S64 && HB) {
+                if constexpr (kTop8 && !S64 && HB) {
                     // s = logN - 2 = 8: 128 outputs per path = 32 chunks: lane l serves codeword l / 32, chunk l % 32 and loops
                     // over the paths of its codeword.  Output chunk c needs the chunks c, c + 32 of the (never stored)
                     // stage-8 block, those need the chunks c, c + 32, c + 64, c + 96 of the stage-9 block, and those the
@@ -2047,7 +2067,7 @@ __global__ __launch_bounds__(256, ((LPL == 3 || CWL > 0) && !DIAG) ? PAMD_WAVES_
                     if (kf >= 1u) c.set_field(s - 1);
                 }
             } else if (ins.op == SCL_VTOP) {
-                if constexpr (kMerge && !S64 && HB) {
+                if constexpr (kTop8 && !S64 && HB) {
                     // Stage s = logN - 1 block of every live path from the channel row: h = 256 outputs per path = one
                     // 16-byte chunk per lane, so the four channel chunks a lane needs are loaded ONCE per codeword and
                     // serve all its paths (they differ only in the bits that steer the g's).  The F of the next stages
