@@ -640,6 +640,7 @@ __global__ __launch_bounds__(256, (!B2 && !ARENA && !CH && !DIAG && LCL <= 4) ? 
                 default: break;
                 }
             };
+            uint32_t fskip = 0;  // F steps of the left descent already done by the op itself (the fused top op)
             auto ch = [&](uint32_t i) -> float {
                 if constexpr (I8)
                     return (float)reinterpret_cast<const int8_t*>(chan)[i];
@@ -678,7 +679,50 @@ __global__ __launch_bounds__(256, (!B2 && !ARENA && !CH && !DIAG && LCL <= 4) ? 
                                            polar_gx<CH>(a.z, b.z, (u >> 2) & 1u), polar_gx<CH>(a.w, b.w, (u >> 3) & 1u));
                     };
                     auto bits4 = [&](uint32_t j) { return (bits[j >> 5] >> (j & 31u)) & 0xFu; };
+                    // N = 1024 (four trips): the first two F steps of the left descent that follows (side bits 0-2) run on the
+                    // results in registers: with four consecutive LLRs per lane and 64 per trip, the partner i + h / 2 (then
+                    // i + h / 4) of a chunk is the same lane's chunk two trips (then one trip) further on
+                    auto fused = [&](auto x4, auto T_) {
+                        constexpr int T = decltype(T_)::value;
+                        float4 r[T];
+#pragma unroll
+                        for (int t = 0; t < T; ++t) {
+                            const uint32_t i = 64u * (uint32_t)t + 4u * (uint32_t)l;
+                            const float4 a = x4(i), b = x4(h + i);
+                            if (op == SC_F)
+                                r[t] = f4(a, b);
+                            else if (op == SC_G0R)
+                                r[t] = a4(a, b);
+                            else
+                                r[t] = g4(a, b, bits4(off + i));
+                            *reinterpret_cast<float4*>(llr + h + i) = r[t];
+                        }
+                        const uint32_t nf = fzz & 7u;
+                        if (nf >= 1u) {
+                            float4 s7[T / 2];
+#pragma unroll
+                            for (int t = 0; t < T / 2; ++t) {
+                                s7[t] = f4(r[t], r[t + T / 2]);
+                                *reinterpret_cast<float4*>(llr + (h >> 1) + 64u * (uint32_t)t + 4u * (uint32_t)l) = s7[t];
+                            }
+                            fskip = 1;
+                            if constexpr (T >= 4) {
+                                if (nf >= 2u) {
+#pragma unroll
+                                    for (int t = 0; t < T / 4; ++t)
+                                        *reinterpret_cast<float4*>(llr + (h >> 2) + 64u * (uint32_t)t + 4u * (uint32_t)l) = f4(s7[t], s7[t + T / 4]);
+                                    fskip = 2;
+                                }
+                            }
+                        }
+                    };
                     auto trips = [&](auto x4) {
+                        if constexpr (B2 && !ARENA) {  // (N = 1024; the short-block variant has no registers to spare)
+                            if (h == 256u) {
+                                fused(x4, std::integral_constant<int, 4>{});
+                                return;
+                            }
+                        }
                         for (uint32_t i0 = 0; i0 < h; i0 += 4u * LC) {
                             const uint32_t i = i0 + 4u * (uint32_t)l;
                             const float4 a = x4(i), b = x4(h + i);
@@ -741,7 +785,7 @@ __global__ __launch_bounds__(256, (!B2 && !ARENA && !CH && !DIAG && LCL <= 4) ? 
                     });
                     fbase = gh;
                 }
-                for (uint32_t t = 0; t < (fzz & 7u); ++t) {  // F of the stages below (left descent)
+                for (uint32_t t = fskip; t < (fzz & 7u); ++t) {  // F of the stages below (left descent)
                     const uint32_t fn = fbase >> t, fh = fn >> 1;
                     WAVE_SYNC();
                     const float* X = llr + fn;
