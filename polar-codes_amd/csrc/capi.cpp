@@ -66,6 +66,10 @@ struct pcd_decoder {
     pamd::Detector det;
     pamd::Program sc_prog, scl_prog;
     bool has_sc = false, has_scl = false;
+    // lane-per-path list kernel (scl_lane_kernel.hip): N = 1024, 4 < L <= 8, float arithmetic, fp32 rows
+    pamd::Program lane_prog;
+    bool has_lane = false;
+    pamd::Ins* d_lane_prog = nullptr;
 
     // launch geometry
     unsigned sc_wave_words = 0, sc_wpb = 4;  // LDS words per codeword, waves per workgroup
@@ -640,6 +644,11 @@ int ensure_device(pcd_decoder* d, pamd::DeviceScope& scope)
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_scl_prog), b));
             HIP_TRY(hipMemcpy(d->d_scl_prog, d->scl_prog.ins.data(), b, hipMemcpyHostToDevice));
         }
+        if (d->has_lane) {
+            const size_t b = d->lane_prog.ins.size() * sizeof(pamd::Ins);
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_lane_prog), b));
+            HIP_TRY(hipMemcpy(d->d_lane_prog, d->lane_prog.ins.data(), b, hipMemcpyHostToDevice));
+        }
         // information-bit LUT (BitContainer::calculateLUT bitcontainer.cpp:68-84)
         std::vector<uint16_t> lut;
         lut.reserve(d->K);
@@ -726,8 +735,26 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     return PCD_OK;
 }
 
+// lane-per-path kernel: 8 codewords per single-wave workgroup, 4 workgroups per CU (40 KB of LDS and all 512 registers
+// of a SIMD lane each), one arena slice per workgroup
+int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
+{
+    P.prog = d->d_lane_prog;
+    P.prog_len = (uint32_t)d->lane_prog.ins.size() - 1u;
+    const unsigned need = (unsigned)((P.rows + 7u) / 8u);
+    unsigned per_cu = 4;
+    if (const char* e = PAMD_ENV("PCD_LANE_BLOCKS_PER_CU")) per_cu = (unsigned)std::max(1, std::min(4, std::atoi(e)));  // experiments
+    const unsigned grid = std::max(1u, std::min(need, (unsigned)d->num_cu * per_cu));
+    int rc = grow(d->d_arena, d->d_arena_cap, (size_t)grid * pamd::scl_lane_arena_words() * sizeof(uint32_t));
+    if (rc) return rc;
+    P.arena = d->d_arena;
+    HIP_TRY(pamd::launch_scl_lane(P, P.trace != nullptr, grid, st));
+    return PCD_OK;
+}
+
 int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
+    if (d->has_lane && !i8 && !P.cycles) return run_scl_lane(d, P, st);
     P.prog = d->d_scl_prog;
     if (!P.prog_len) P.prog_len = (uint32_t)d->scl_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->scl_wave_words;
@@ -1030,6 +1057,8 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
     if (d->L > 1) {
         pamd::compile_scl(d->N, d->frozen, d->scl_prog, chr);
         d->has_scl = true;
+        // the lane-per-path kernel takes the codes it has every op for (its program is lowered from the plain one)
+        if (!chr && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog);
     }
     compute_geometry(d);
     if ((size_t)d->sc_wave_words * 4 * (64u >> d->sc_lcl) > kMaxLds && d->has_sc) {
@@ -1063,6 +1092,7 @@ void pcd_destroy(pcd_decoder* d)
         (void)scope.enter(d->device);
         (void)hipFree(d->d_sc_prog);
         (void)hipFree(d->d_scl_prog);
+        if (d->d_lane_prog) (void)hipFree(d->d_lane_prog);
         (void)hipFree(d->d_lut);
         (void)hipFree(d->d_syn);
         (void)hipFree(d->d_count);
@@ -1154,6 +1184,13 @@ int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4])
     if (!d || !info) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (list) {
         if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SCL program");
+        if (d->has_lane) {  // lane-per-path kernel: 40 KB of LDS per wave of 8 codewords, 1 lane per path, 4 waves per CU
+            info[0] = 40960 / 8;
+            info[1] = 8;
+            info[2] = 1;
+            info[3] = 4;
+            return PCD_OK;
+        }
         info[0] = (d->scl_wave_words * 4) >> d->cwl;
         info[1] = d->scl_wpb << d->cwl;
         info[2] = 64u >> d->lpl;

@@ -46,6 +46,10 @@ hipError_t launch_sc(const DecodeParams& P, int lcl, bool i8, unsigned grid, uns
                      hipStream_t st, int* occupancy = nullptr);
 hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, unsigned waves_per_block,
                       size_t lds, hipStream_t st, int* occupancy = nullptr);
+// lane-per-path list kernel (scl_lane_kernel.hip): N = 1024, L <= 8, fp32 rows; P.prog = the LN_* program, P.arena = grid
+// slices of scl_lane_arena_words() 32-bit words
+hipError_t launch_scl_lane(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);
+unsigned scl_lane_arena_words();
 // CharContainer::insertLlr(const float*) (bitcontainer.cpp:449-516, N >= 8): round to nearest even, saturate to int8
 hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st);
 hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,

@@ -1,0 +1,84 @@
+// Host-side lowering of the plain list-decoder program to the program of the lane-per-path kernel
+// (scl_lane_kernel.hip): the root and its children are folded into LN_VT passes over the channel row, the G behind an
+// all-frozen left child becomes LN_G0, the root's COMBINE is left to the kernel's epilogue.
+#include "program.h"
+
+namespace pamd {
+
+bool lower_lane(unsigned logN, const Program& scl, Program& out)
+{
+    out = Program();
+    out.leaves = scl.leaves;
+    out.inner = scl.inner;
+    if (logN != 10) return false;
+    const std::vector<Ins>& v = scl.ins;
+    auto put = [&](Op op, unsigned stage, unsigned side, unsigned off) {
+        Ins i;
+        i.op = (uint8_t)op;
+        i.stage = (uint8_t)stage;
+        i.side = (uint8_t)side;
+        i.pad = 0;
+        i.off = off;
+        out.ins.push_back(i);
+    };
+    bool right_half = false;  // the root's G has been seen
+    for (size_t k = 0; k < v.size(); ++k) {
+        const Ins& x = v[k];
+        switch (x.op) {
+        case OP_END: break;
+        case SCL_F:
+        case SCL_G: {
+            const bool isg = x.op == SCL_G;
+            if (x.stage == logN) {  // root: must be followed by the F of its child (stage 9 is virtual)
+                if (isg) right_half = true;
+                if (k + 1 >= v.size() || v[k + 1].op != SCL_F || v[k + 1].stage != logN - 1) return false;
+                continue;  // folded into the LN_VT emitted for that F
+            }
+            if (x.stage == logN - 1) {
+                unsigned off = (right_half ? 1u : 0u) | (isg ? 2u : 0u);
+                if (k + 1 < v.size() && v[k + 1].op == SCL_F && v[k + 1].stage == logN - 2) {
+                    off |= 4u;
+                    ++k;
+                }
+                put(LN_VT, x.stage, x.side, off);
+                continue;
+            }
+            if (x.stage < 2) return false;
+            // G behind an all-frozen left sibling: ... F(s) R0(s-1) G(s)
+            if (isg && k >= 1 && v[k - 1].op == SCL_R0 && v[k - 1].stage + 1u == x.stage) {
+                put(LN_G0, x.stage, x.side, 0);
+                continue;
+            }
+            put(isg ? LN_G : LN_F, x.stage, x.side, 0);
+            break;
+        }
+        case SCL_COMBINE:
+            if (x.stage == logN) break;  // the kernel's epilogue assembles the code word
+            if (x.stage < 2) return false;
+            put(LN_C, x.stage, x.side, 0);
+            break;
+        case SCL_R0:
+            if (x.stage > 8 || x.stage < 1) return false;
+            put(LN_R0, x.stage, x.side, 0);
+            break;
+        case SCL_R1:
+            if (x.stage > 7 || x.stage < 1) return false;
+            put(LN_R1, x.stage, x.side, 0);
+            break;
+        case SCL_SPC:
+            if (x.stage > 7 || x.stage < 2) return false;
+            put(LN_SPC, x.stage, x.side, 0);
+            break;
+        case SCL_REP:
+            if (x.stage > 2 || x.stage < 1) return false;
+            put(LN_REP, x.stage, x.side, 0);
+            break;
+        default: return false;
+        }
+    }
+    put(OP_END, 0, 0, 0);
+    // the first op must be the left-left pass over the channel row
+    return !out.ins.empty() && out.ins[0].op == LN_VT;
+}
+
+}  // namespace pamd

@@ -74,6 +74,20 @@ enum Op : uint8_t {
     // stage.  `off`: bit 0 = the root child is the RIGHT one, bit 1 = the grandchild is a RIGHT child, bits 2-3 = fused F
     // levels below (0..1)
     SCL_VG2,
+    // ---- lane-per-path list kernel (scl_lane_kernel.hip): 8 paths x 8 codewords per wave, one lane per path -------------
+    // Lowered from the plain SCL program by lower_lane (lane_program.cpp).  `stage` = log2 of the block the op works on
+    // (the PARENT block for F / G / C), `side` as above.
+    LN_VT = 64,    // root + its child in one pass over the channel row: stage-8 block of this path (stage 9 is never stored).
+                   // off bit 0: the root's RIGHT child (g with the root's left bits), bit 1: G at stage 9 (else F),
+                   // bit 2: the F of stage 8 runs on the values in registers as well (stage 7 goes to LDS)
+    LN_F,          // llr[s-1] = f(llr[s])
+    LN_G,          // llr[s-1] = g(llr[s] of the path's slot owner, own left bits)
+    LN_G0,         // llr[s-1] = a + b: the left child was all-frozen (no fork since the F, left bits zero)
+    LN_C,          // bits[s] = [left ^ right | right]
+    LN_R0,
+    LN_R1,
+    LN_REP,
+    LN_SPC,
 };
 
 struct Ins {
@@ -96,6 +110,10 @@ struct Program {
 // throws; SclFip::createDecoder scl_fip_char.cpp:745-775: repetition leaves at every block length)
 std::string compile_sc(unsigned N, const std::vector<uint32_t>& frozen, Program& out, bool chr = false);
 std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program& out, bool chr = false);
+// Lowers a plain SCL program (compile_scl output: SCL_F / SCL_G / SCL_COMBINE + leaves) of a code with N = 1024 to the
+// program of the lane-per-path kernel.  Returns false when the tree needs an op that kernel does not have (a leaf above
+// stage 8, ...): the caller then keeps the path-group kernels.
+bool lower_lane(unsigned logN, const Program& scl, Program& out);
 
 // ---- error detection -------------------------------------------------------------------------
 // All supported detectors are linear over GF(2) with a zero initial value, so

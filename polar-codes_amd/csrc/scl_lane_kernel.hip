@@ -1,0 +1,1241 @@
+// Fast-SSCL list decoder, lane-per-path form: N = 1024, list size <= 8.
+//
+// Reference: SclAvxFloat  src/polarcode/decoding/scl_avx_float.cpp (PathList :19-171, nodes :229-621, extractBestPath
+// :711-750).  The path-group kernels of scl_kernel.h give every path 4 lanes and keep the tree in LDS / a global arena;
+// here ONE LANE IS ONE PATH: a wave decodes 8 codewords x 8 paths, and the decoding tree of a path lives in the
+// lane's own registers:
+//
+//   stage t <= 6 (block 2^t LLRs)   VGPRs v[128..253], hand-allocated: the compiler is confined to v0..v103
+//                                   (amdgpu_num_vgpr) and never sees them; the ops below are asm blocks on fixed
+//                                   register numbers (`v[%[d]+k]`, %[d] an immediate)
+//   stage 7                         LDS, [16-byte chunk][lane]  (32 KB per wave)
+//   stage 8                         per-wave arena in global memory, [16-byte chunk][lane]  (64 KB per wave)
+//   stage 9                         never stored: recomputed from the channel row (LN_VT)
+//   partial sums                    bit-packed: stages <= 7 in VGPRs v[104..127], stages 8-9 in the arena
+//
+// One wave per SIMD (4 single-wave workgroups per CU: 40 KB of LDS each), i.e. 32 codewords in flight per CU.
+// With one lane per path there is no cross-lane work inside f / g / the leaves at all; what crosses lanes is the
+// list management (candidate selection among the 8 lanes of a codeword: a merge network on packed keys with DPP
+// partners) and the lazy copy: the reference's DataPool is replaced by a slot word per path -- field t names the lane
+// whose registers / LDS column / arena column hold LLR[t] until the G of that stage has read them (ds_bpermute for the
+// register stages), and the holder of the left child's bits afterwards.  A fork moves the slot word, nothing else.
+//
+// Bit-exactness: f exact; g is one fp32 addition (v_fma_f32 with a factor of +-1.0: one rounding, same result); the
+// metric sums follow the reference's 8-accumulator order (avxconvenience.h:256-272); findWeakLlrs and
+// simplePartialSortDescending (arrayfuncs.h:161-231) are reproduced including their swap-order tie behaviour (the merge
+// selection falls back to a literal emulation whenever two keys that matter agree in their upper 26 bits).
+#include "device_common.h"
+
+#include <utility>
+
+namespace pamd {
+namespace lane {
+
+// ---- register map (per lane) ---------------------------------------------------------------------------------------
+constexpr int KV = 104;      // the compiler's VGPR budget: v0 .. v103
+constexpr int RBL0 = 104;    // left-child / root output bits of stage t <= 5: v[104 + t]
+constexpr int RBR0 = 110;    // right-child output bits of stage t <= 5: v[110 + t]
+constexpr int RBL6 = 116, RBR6 = 118;  // stage 6: 2 words each
+constexpr int RBL7 = 120, RBR7 = 124;  // stage 7: 4 words each
+__host__ __device__ constexpr int RS(int t) { return t == 1 ? 128 : t == 2 ? 130 : t == 3 ? 134 : t == 4 ? 142 : t == 5 ? 158 : 190; }
+__host__ __device__ constexpr int RB(int side, int t) { return t <= 5 ? (side ? RBR0 : RBL0) + t : t == 6 ? (side ? RBR6 : RBL6) : (side ? RBR7 : RBL7); }
+// arena of one wave (32-bit words): stage-8 LLRs [64 chunks][64 lanes][4], then bit words [w][lane], then a dump area
+constexpr uint32_t AR_S8 = 0;
+constexpr uint32_t AR_BL9 = 64 * 64 * 4;           // 16 words: output of the root's left child
+constexpr uint32_t AR_BR9 = AR_BL9 + 16 * 64;      // 16 words: output of the root's right child
+constexpr uint32_t AR_BL8 = AR_BR9 + 16 * 64;      // 8 words
+constexpr uint32_t AR_BR8 = AR_BL8 + 8 * 64;       // 8 words
+constexpr uint32_t AR_DUMP = AR_BR8 + 8 * 64;      // 16 chunks x 64 lanes x 4: stage 5 / 6 leaf input, read back chunk-wise
+constexpr uint32_t AR_WORDS = AR_DUMP + 16 * 64 * 4;
+// LDS of one wave (32-bit words)
+constexpr uint32_t LDS_S7 = 0;                     // [32 chunks][64 lanes][4 words]
+constexpr uint32_t LDS_SCR = 8192;                 // scratch: 2048 words
+constexpr uint32_t LDS_WORDS = 10240;
+constexpr uint32_t SCR_CM = LDS_SCR;               // candidate metrics [lane][8] floats
+constexpr uint32_t SCR_FORK = LDS_SCR + 512;       // fork record [lane][8] words: sign words 0-3, weak indices, parity
+constexpr uint32_t SCR_SEL = LDS_SCR + 1024;       // literal selection: ranks [codeword][8]
+
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---- accessors for the hand-allocated registers (volatile: the compiler does not know their contents change) -------
+template <int R>
+__device__ __forceinline__ uint32_t rdu()
+{
+    uint32_t x;
+    asm volatile("v_mov_b32 %0, v[%1]" : "=v"(x) : "n"(R));
+    return x;
+}
+template <int R>
+__device__ __forceinline__ float rdf()
+{
+    return bitsf(rdu<R>());
+}
+template <int R>
+__device__ __forceinline__ void wru(uint32_t x)
+{
+    asm volatile("v_mov_b32 v[%0], %1" ::"n"(R), "v"(x));
+}
+// register R of lane addr / 4
+template <int R>
+__device__ __forceinline__ uint32_t rd_lane(uint32_t addr)
+{
+    uint32_t x;
+    asm volatile("ds_bpermute_b32 %0, %1, v[%2]\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(addr), "n"(R));
+    return x;
+}
+
+// ---- f / g blocks on registers ----------------------------------------------------------------------------------------
+// text of f over 4 consecutive elements: v[D+k] = f(v[A+k], v[B+k]), D may equal A (the xor is taken first)
+#define LN_F4T(D_, A_, B_)                                       \
+    "v_xor_b32 %[t0], v[" A_ "], v[" B_ "]\n\t"                  \
+    "v_xor_b32 %[t1], v[" A_ "+1], v[" B_ "+1]\n\t"              \
+    "v_xor_b32 %[t2], v[" A_ "+2], v[" B_ "+2]\n\t"              \
+    "v_xor_b32 %[t3], v[" A_ "+3], v[" B_ "+3]\n\t"              \
+    "v_min_f32_e64 v[" D_ "], |v[" A_ "]|, |v[" B_ "]|\n\t"      \
+    "v_min_f32_e64 v[" D_ "+1], |v[" A_ "+1]|, |v[" B_ "+1]|\n\t" \
+    "v_min_f32_e64 v[" D_ "+2], |v[" A_ "+2]|, |v[" B_ "+2]|\n\t" \
+    "v_min_f32_e64 v[" D_ "+3], |v[" A_ "+3]|, |v[" B_ "+3]|\n\t" \
+    "v_bfi_b32 v[" D_ "], %[am], v[" D_ "], %[t0]\n\t"           \
+    "v_bfi_b32 v[" D_ "+1], %[am], v[" D_ "+1], %[t1]\n\t"       \
+    "v_bfi_b32 v[" D_ "+2], %[am], v[" D_ "+2], %[t2]\n\t"       \
+    "v_bfi_b32 v[" D_ "+3], %[am], v[" D_ "+3], %[t3]\n\t"
+// text of g over 4 consecutive elements whose inputs are in place: v[D+k] = g(v[D+k], v[B+k], bit E+k of %[w])
+#define LN_G4T(D_, B_, S0, S1, S2, S3)                            \
+    "v_lshlrev_b32 %[t0], " #S0 ", %[w]\n\t"                     \
+    "v_lshlrev_b32 %[t1], " #S1 ", %[w]\n\t"                     \
+    "v_lshlrev_b32 %[t2], " #S2 ", %[w]\n\t"                     \
+    "v_lshlrev_b32 %[t3], " #S3 ", %[w]\n\t"                     \
+    "v_and_or_b32 %[t0], %[t0], %[sm], 1.0\n\t"                  \
+    "v_and_or_b32 %[t1], %[t1], %[sm], 1.0\n\t"                  \
+    "v_and_or_b32 %[t2], %[t2], %[sm], 1.0\n\t"                  \
+    "v_and_or_b32 %[t3], %[t3], %[sm], 1.0\n\t"                  \
+    "v_fma_f32 v[" D_ "], v[" D_ "], %[t0], v[" B_ "]\n\t"       \
+    "v_fma_f32 v[" D_ "+1], v[" D_ "+1], %[t1], v[" B_ "+1]\n\t" \
+    "v_fma_f32 v[" D_ "+2], v[" D_ "+2], %[t2], v[" B_ "+2]\n\t" \
+    "v_fma_f32 v[" D_ "+3], v[" D_ "+3], %[t3], v[" B_ "+3]\n\t"
+
+template <int G, int D, int A, int B>
+__device__ __forceinline__ void f_block(uint32_t absmask)
+{
+    static_assert(G == 2 || G == 4, "block size");
+    uint32_t t0, t1, t2, t3;
+    if constexpr (G == 4) {
+        asm volatile(LN_F4T("%[d]", "%[a]", "%[b]")
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [d] "n"(D), [a] "n"(A), [b] "n"(B), [am] "s"(absmask));
+    } else {
+        asm volatile(
+            "v_xor_b32 %[t0], v[%[a]], v[%[b]]\n\t"
+            "v_xor_b32 %[t1], v[%[a]+1], v[%[b]+1]\n\t"
+            "v_min_f32_e64 v[%[d]], |v[%[a]]|, |v[%[b]]|\n\t"
+            "v_min_f32_e64 v[%[d]+1], |v[%[a]+1]|, |v[%[b]+1]|\n\t"
+            "v_bfi_b32 v[%[d]], %[am], v[%[d]], %[t0]\n\t"
+            "v_bfi_b32 v[%[d]+1], %[am], v[%[d]+1], %[t1]"
+            : [t0] "=&v"(t0), [t1] "=&v"(t1)
+            : [d] "n"(D), [a] "n"(A), [b] "n"(B), [am] "s"(absmask));
+    }
+}
+// llr[T-1] = f(llr[T]) on registers, T = 2 .. 6
+template <int T>
+__device__ __forceinline__ void f_reg(uint32_t absmask)
+{
+    constexpr int h = 1 << (T - 1), A = RS(T), D = RS(T - 1);
+    constexpr int G = h < 4 ? h : 4;
+    static_for<h / G>([&](auto J) {
+        constexpr int j = decltype(J)::value * G;
+        f_block<G, D + j, A + j, A + h + j>(absmask);
+    });
+}
+// llr[T-1] = a + b (all-frozen left child), T = 2 .. 6
+template <int T>
+__device__ __forceinline__ void g0_reg()
+{
+    constexpr int h = 1 << (T - 1), A = RS(T), D = RS(T - 1);
+    static_for<h>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        asm volatile("v_add_f32 v[%0], v[%1], v[%2]" ::"n"(D + i), "n"(A + i), "n"(A + h + i));
+    });
+}
+// g over G consecutive elements, inputs fetched from lane addr / 4 (ds_bpermute): a lands in v[D+k], b in a temporary.
+// u: the left child's bits, bit k = element k of this block
+template <int G, int D, int A, int B>
+__device__ __forceinline__ void g_block_lazy(uint32_t addr, uint32_t u, uint32_t signmask)
+{
+    static_assert(G == 2 || G == 4 || G == 8, "block size");
+    uint32_t b0, b1, b2, b3, b4, b5, b6, b7, s0, s1, s2, s3, s4, s5, s6, s7;
+#define LN_BPA(k) "ds_bpermute_b32 v[%[d]+" #k "], %[ad], v[%[a]+" #k "]\n\t"
+#define LN_BPB(k) "ds_bpermute_b32 %[b" #k "], %[ad], v[%[bb]+" #k "]\n\t"
+#define LN_SH(k, s) "v_lshlrev_b32 %[s" #k "], " #s ", %[u]\n\t"
+#define LN_AO(k) "v_and_or_b32 %[s" #k "], %[s" #k "], %[sm], 1.0\n\t"
+#define LN_FM(k) "v_fma_f32 v[%[d]+" #k "], v[%[d]+" #k "], %[s" #k "], %[b" #k "]\n\t"
+    if constexpr (G == 8) {
+        asm volatile(LN_BPA(0) LN_BPB(0) LN_BPA(1) LN_BPB(1) LN_BPA(2) LN_BPB(2) LN_BPA(3) LN_BPB(3)
+                     LN_BPA(4) LN_BPB(4) LN_BPA(5) LN_BPB(5) LN_BPA(6) LN_BPB(6) LN_BPA(7) LN_BPB(7)
+                     LN_SH(0, 31) LN_SH(1, 30) LN_SH(2, 29) LN_SH(3, 28) LN_SH(4, 27) LN_SH(5, 26) LN_SH(6, 25) LN_SH(7, 24)
+                     LN_AO(0) LN_AO(1) LN_AO(2) LN_AO(3) LN_AO(4) LN_AO(5) LN_AO(6) LN_AO(7)
+                     "s_waitcnt lgkmcnt(8)\n\t" LN_FM(0) LN_FM(1) LN_FM(2) LN_FM(3)
+                     "s_waitcnt lgkmcnt(0)\n\t" LN_FM(4) LN_FM(5) LN_FM(6) LN_FM(7)
+                     : [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [b4] "=&v"(b4), [b5] "=&v"(b5),
+                       [b6] "=&v"(b6), [b7] "=&v"(b7), [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [s3] "=&v"(s3),
+                       [s4] "=&v"(s4), [s5] "=&v"(s5), [s6] "=&v"(s6), [s7] "=&v"(s7)
+                     : [d] "n"(D), [a] "n"(A), [bb] "n"(B), [ad] "v"(addr), [u] "v"(u), [sm] "s"(signmask)
+                     : "memory");
+    } else if constexpr (G == 4) {
+        asm volatile(LN_BPA(0) LN_BPB(0) LN_BPA(1) LN_BPB(1) LN_BPA(2) LN_BPB(2) LN_BPA(3) LN_BPB(3)
+                     LN_SH(0, 31) LN_SH(1, 30) LN_SH(2, 29) LN_SH(3, 28) LN_AO(0) LN_AO(1) LN_AO(2) LN_AO(3)
+                     "s_waitcnt lgkmcnt(0)\n\t" LN_FM(0) LN_FM(1) LN_FM(2) LN_FM(3)
+                     : [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [s0] "=&v"(s0), [s1] "=&v"(s1),
+                       [s2] "=&v"(s2), [s3] "=&v"(s3)
+                     : [d] "n"(D), [a] "n"(A), [bb] "n"(B), [ad] "v"(addr), [u] "v"(u), [sm] "s"(signmask)
+                     : "memory");
+    } else {
+        asm volatile(LN_BPA(0) LN_BPB(0) LN_BPA(1) LN_BPB(1) LN_SH(0, 31) LN_SH(1, 30) LN_AO(0) LN_AO(1)
+                     "s_waitcnt lgkmcnt(0)\n\t" LN_FM(0) LN_FM(1)
+                     : [b0] "=&v"(b0), [b1] "=&v"(b1), [s0] "=&v"(s0), [s1] "=&v"(s1)
+                     : [d] "n"(D), [a] "n"(A), [bb] "n"(B), [ad] "v"(addr), [u] "v"(u), [sm] "s"(signmask)
+                     : "memory");
+    }
+#undef LN_BPA
+#undef LN_BPB
+#undef LN_SH
+#undef LN_AO
+#undef LN_FM
+}
+// llr[T-1] = g(llr[T] of lane addr / 4, own left bits), T = 2 .. 6
+template <int T>
+__device__ __forceinline__ void g_reg(uint32_t addr, uint32_t signmask)
+{
+    constexpr int h = 1 << (T - 1), A = RS(T), D = RS(T - 1);
+    constexpr int G = h < 8 ? h : 8;
+    const uint32_t u = rdu<RBL0 + (T - 1)>();
+    static_for<h / G>([&](auto J) {
+        constexpr int j = decltype(J)::value * G;
+        g_block_lazy<G, D + j, A + j, A + h + j>(addr, u >> j, signmask);
+    });
+}
+
+// ---- stage 7 (LDS column, 16-byte chunks 1 KB apart) -> stage 6 (registers) ----------------------------------------------
+// Round r loads the chunks 8r .. 8r+7 into v[D .. D+31] and their partners 16+8r .. into v[T .. T+31] (the registers of
+// stage 5, dead while stage 6 is being produced), then works on them in place as they arrive.
+#define LN_RD2(c) "ds_read_b128 v[%[d]+4*" #c ":%[d]+4*" #c "+3], %[ad] offset:%[oa]+1024*" #c "\n\t" \
+                  "ds_read_b128 v[%[t]+4*" #c ":%[t]+4*" #c "+3], %[ad] offset:%[ob]+1024*" #c "\n\t"
+template <int R>
+__device__ __forceinline__ void f7_round(uint32_t addr, uint32_t absmask)
+{
+    uint32_t t0, t1, t2, t3;
+    asm volatile(LN_RD2(0) LN_RD2(1) LN_RD2(2) LN_RD2(3) LN_RD2(4) LN_RD2(5) LN_RD2(6) LN_RD2(7)
+                 "s_waitcnt lgkmcnt(14)\n\t" LN_F4T("%[d]", "%[d]", "%[t]")
+                 "s_waitcnt lgkmcnt(12)\n\t" LN_F4T("%[d]+4", "%[d]+4", "%[t]+4")
+                 "s_waitcnt lgkmcnt(10)\n\t" LN_F4T("%[d]+8", "%[d]+8", "%[t]+8")
+                 "s_waitcnt lgkmcnt(8)\n\t" LN_F4T("%[d]+12", "%[d]+12", "%[t]+12")
+                 "s_waitcnt lgkmcnt(6)\n\t" LN_F4T("%[d]+16", "%[d]+16", "%[t]+16")
+                 "s_waitcnt lgkmcnt(4)\n\t" LN_F4T("%[d]+20", "%[d]+20", "%[t]+20")
+                 "s_waitcnt lgkmcnt(2)\n\t" LN_F4T("%[d]+24", "%[d]+24", "%[t]+24")
+                 "s_waitcnt lgkmcnt(0)\n\t" LN_F4T("%[d]+28", "%[d]+28", "%[t]+28")
+                 : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [d] "n"(RS(6) + 32 * R), [t] "n"(RS(5)), [ad] "v"(addr), [oa] "n"(4 * LDS_S7 + 8192 * R),
+                   [ob] "n"(4 * LDS_S7 + 16384 + 8192 * R), [am] "s"(absmask)
+                 : "memory");
+}
+// the same with g: w = the 32 left-child bits of the round's elements; ZERO: all-frozen left child (a + b)
+template <int R, bool ZERO>
+__device__ __forceinline__ void g7_round(uint32_t addr, uint32_t w, uint32_t signmask)
+{
+    uint32_t t0, t1, t2, t3;
+    if constexpr (ZERO) {
+#define LN_ADD4(o) "v_add_f32 v[%[d]+" #o "], v[%[d]+" #o "], v[%[t]+" #o "]\n\t" "v_add_f32 v[%[d]+" #o "+1], v[%[d]+" #o "+1], v[%[t]+" #o "+1]\n\t" \
+                   "v_add_f32 v[%[d]+" #o "+2], v[%[d]+" #o "+2], v[%[t]+" #o "+2]\n\t" "v_add_f32 v[%[d]+" #o "+3], v[%[d]+" #o "+3], v[%[t]+" #o "+3]\n\t"
+        asm volatile(LN_RD2(0) LN_RD2(1) LN_RD2(2) LN_RD2(3) LN_RD2(4) LN_RD2(5) LN_RD2(6) LN_RD2(7)
+                     "s_waitcnt lgkmcnt(14)\n\t" LN_ADD4(0) "s_waitcnt lgkmcnt(12)\n\t" LN_ADD4(4)
+                     "s_waitcnt lgkmcnt(10)\n\t" LN_ADD4(8) "s_waitcnt lgkmcnt(8)\n\t" LN_ADD4(12)
+                     "s_waitcnt lgkmcnt(6)\n\t" LN_ADD4(16) "s_waitcnt lgkmcnt(4)\n\t" LN_ADD4(20)
+                     "s_waitcnt lgkmcnt(2)\n\t" LN_ADD4(24) "s_waitcnt lgkmcnt(0)\n\t" LN_ADD4(28)
+                     :
+                     : [d] "n"(RS(6) + 32 * R), [t] "n"(RS(5)), [ad] "v"(addr), [oa] "n"(4 * LDS_S7 + 8192 * R),
+                       [ob] "n"(4 * LDS_S7 + 16384 + 8192 * R)
+                     : "memory");
+#undef LN_ADD4
+    } else {
+        asm volatile(LN_RD2(0) LN_RD2(1) LN_RD2(2) LN_RD2(3) LN_RD2(4) LN_RD2(5) LN_RD2(6) LN_RD2(7)
+                     "s_waitcnt lgkmcnt(14)\n\t" LN_G4T("%[d]", "%[t]", 31, 30, 29, 28)
+                     "s_waitcnt lgkmcnt(12)\n\t" LN_G4T("%[d]+4", "%[t]+4", 27, 26, 25, 24)
+                     "s_waitcnt lgkmcnt(10)\n\t" LN_G4T("%[d]+8", "%[t]+8", 23, 22, 21, 20)
+                     "s_waitcnt lgkmcnt(8)\n\t" LN_G4T("%[d]+12", "%[t]+12", 19, 18, 17, 16)
+                     "s_waitcnt lgkmcnt(6)\n\t" LN_G4T("%[d]+16", "%[t]+16", 15, 14, 13, 12)
+                     "s_waitcnt lgkmcnt(4)\n\t" LN_G4T("%[d]+20", "%[t]+20", 11, 10, 9, 8)
+                     "s_waitcnt lgkmcnt(2)\n\t" LN_G4T("%[d]+24", "%[t]+24", 7, 6, 5, 4)
+                     "s_waitcnt lgkmcnt(0)\n\t" LN_G4T("%[d]+28", "%[t]+28", 3, 2, 1, 0)
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [d] "n"(RS(6) + 32 * R), [t] "n"(RS(5)), [ad] "v"(addr), [oa] "n"(4 * LDS_S7 + 8192 * R),
+                       [ob] "n"(4 * LDS_S7 + 16384 + 8192 * R), [w] "v"(w), [sm] "s"(signmask)
+                     : "memory");
+    }
+}
+#undef LN_RD2
+
+// registers v[R .. R+4*NCH) -> the dump area of the arena (own column), 16-byte chunks
+template <int R, int NCH>
+__device__ __forceinline__ void dump_regs(uint32_t* col)
+{
+    static_for<NCH>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        uint32_t* const dst = col + c * 256;
+        asm volatile("global_store_dwordx4 %0, v[%1:%1+3], off" ::"v"(dst), "n"(R + 4 * c) : "memory");
+    });
+}
+
+// ---- small helpers ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 f4(float4 a, float4 b)
+{
+    return make_float4(polar_f(a.x, b.x), polar_f(a.y, b.y), polar_f(a.z, b.z), polar_f(a.w, b.w));
+}
+__device__ __forceinline__ float4 g4(float4 a, float4 b, uint32_t u)
+{
+    return make_float4(polar_g(a.x, b.x, u & 1u), polar_g(a.y, b.y, (u >> 1) & 1u), polar_g(a.z, b.z, (u >> 2) & 1u),
+                       polar_g(a.w, b.w, (u >> 3) & 1u));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// all-reduce over the 8 lanes of a codeword (DPP: lane ^ 1, lane ^ 2, then the mirrored lane of the other quad)
+__device__ __forceinline__ uint32_t cw_min(uint32_t v)
+{
+    v = umin(v, dpp_u32<0xB1>(v));
+    v = umin(v, dpp_u32<0x4E>(v));
+    return umin(v, dpp_u32<0x141>(v));
+}
+__device__ __forceinline__ uint32_t cw_add(uint32_t v)
+{
+    v += dpp_u32<0xB1>(v);
+    v += dpp_u32<0x4E>(v);
+    return v + dpp_u32<0x141>(v);
+}
+
+// per-lane state the compiler keeps (everything else lives in the hand-allocated registers)
+struct Path {
+    float metric;
+    uint32_t slot;   // 3-bit fields, stage t at bit 3 * (t - 2), t = 2 .. 10
+    uint32_t pl;     // position in the reference's path list; >= P: not a live path
+    uint32_t P;      // live paths per codeword (wave uniform)
+    uint32_t L;
+    int lane, q, g0;
+    uint32_t self4;  // lane * 4 (ds_bpermute address of the own lane)
+    uint32_t* lds;   // this wave's LDS
+    uint32_t* arena; // this wave's arena slice
+    __device__ __forceinline__ uint32_t owner(uint32_t t) const { return (uint32_t)g0 | ((slot >> (3u * (t - 2u))) & 7u); }
+    __device__ __forceinline__ void set_field(uint32_t t)
+    {
+        const uint32_t sh = 3u * (t - 2u);
+        slot = (slot & ~(7u << sh)) | ((uint32_t)q << sh);
+    }
+};
+
+// ---- findWeakLlrs (arrayfuncs.h:209-231) for one path --------------------------------------------------------------
+// The reference runs a swap-mutating selection: iteration i takes the first minimum among positions >= i and swaps it
+// with position i.  Only the elements that start at positions 0 .. cnt-1 can ever be moved (to the position of a
+// winner); everything else stays where it is until it is selected.  The first four elements ("heads") are kept with
+// their current position, of the rest ("tail") only the four smallest (value, position) can matter.  One form serves
+// cnt = 2 (RateOne) and cnt = 4 (SPC): tracking two heads that never move costs nothing.
+struct WeakScan {
+    static constexpr uint32_t INF = 0xFFFFFFFFu;
+    uint32_t hv[4], tv[4], tp[4];
+    uint32_t sg[4];  // hard decisions of the block, 32 per word
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hv[e] = tv[e] = tp[e] = INF;
+            sg[e] = 0;
+        }
+    }
+    // tail elements arrive with ascending positions: strict '<' keeps the earlier one first
+    __device__ __forceinline__ void tail(uint32_t a, uint32_t ap)
+    {
+        bool placed = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool lt = placed || (a < tv[k]);
+            const uint32_t sv = lt ? tv[k] : a, sp = lt ? tp[k] : ap;
+            tv[k] = lt ? a : tv[k];
+            tp[k] = lt ? ap : tp[k];
+            a = sv;
+            ap = sp;
+            placed = lt;
+        }
+    }
+    // n = block length, cnt = 2 or 4 (wave uniform); wv / wi: values and original indices at positions 0 .. cnt-1 afterwards
+    __device__ __forceinline__ void finish(uint32_t n, uint32_t cnt, uint32_t (&wv)[4], uint32_t (&wi)[4])
+    {
+        const uint32_t lim = (n - 1 < cnt) ? n - 1 : cnt;
+        uint32_t hp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hp[e] = ((uint32_t)e < n) ? (uint32_t)e : INF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wv[i] = hv[i];
+            wi[i] = (uint32_t)i;
+            if ((uint32_t)i < lim) {
+                const uint32_t tvmin = tv[0], tpmin = tp[0];
+                uint32_t bv = hv[0], bp = hp[0], be = 0;
+#pragma unroll
+                for (int e = 1; e < 4; ++e) {
+                    const bool lt = (hv[e] < bv) || (hv[e] == bv && hp[e] < bp);
+                    bv = lt ? hv[e] : bv;
+                    bp = lt ? hp[e] : bp;
+                    be = lt ? (uint32_t)e : be;
+                }
+                const bool tail_wins = (tvmin < bv) || (tvmin == bv && tpmin < bp);
+                const uint32_t wp = tail_wins ? tpmin : bp;
+                wv[i] = tail_wins ? tvmin : bv;
+                wi[i] = tail_wins ? wp : be;  // tail elements never move: original index = position
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool is_w = !tail_wins && be == (uint32_t)e;
+                    const bool at_i = hp[e] == (uint32_t)i;
+                    hp[e] = is_w ? INF : (at_i ? wp : hp[e]);
+                    hv[e] = is_w ? INF : hv[e];
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    tv[k] = tail_wins ? tv[k + 1] : tv[k];
+                    tp[k] = tail_wins ? tp[k + 1] : tp[k];
+                }
+                tv[3] = tail_wins ? INF : tv[3];
+                tp[3] = tail_wins ? INF : tp[3];
+            }
+        }
+        // positions >= lim keep whatever sits there: the head whose current position is i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if ((uint32_t)i >= lim && (uint32_t)i < n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (hp[e] == (uint32_t)i) {
+                        wv[i] = hv[e];
+                        wi[i] = (uint32_t)e;
+                    }
+            }
+        }
+    }
+};
+
+// ---- candidate selection: simplePartialSortDescending (arrayfuncs.h:161-183) over the P * C candidates of a codeword ----
+// Keys: the raw bits of a candidate metric read as unsigned order the candidates best-first (metrics are never
+// positive); the low 6 bits are replaced by (lane, candidate), so that min / max move the payload along and no two
+// keys are equal.  The order is exact unless two keys that matter agree in the upper 26 bits: those cases (and real
+// ties, whose order depends on the reference's swaps) go to the literal emulation below.
+template <int W>
+__device__ __forceinline__ void bitonic_clean(uint32_t (&k)[8])
+{
+#pragma unroll
+    for (int d = W / 2; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            if (!(i & d)) {
+                const uint32_t lo = umin(k[i], k[i + d]), hi = umax(k[i], k[i + d]);
+                k[i] = lo;
+                k[i + d] = hi;
+            }
+        }
+    }
+}
+// own list k[0 .. 8) and the partner lane's, both ascending -> the 8 smallest of both, ascending
+template <int CTRL>
+__device__ __forceinline__ void merge_level(uint32_t (&k)[8])
+{
+    uint32_t b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = dpp_u32<CTRL>(k[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = umin(k[i], b[7 - i]);
+    bitonic_clean<8>(k);
+}
+
+// Literal emulation of the selection sort on the exact metrics: every candidate carries its CURRENT position in the
+// reference's array (pl * C + c at the start); round i takes the largest value at positions >= i (first position on
+// ties), the candidate sitting at position i moves to the winner's old position.  Rank i of every codeword goes to the
+// scratch (word i of the codeword's row): (lane << 3) | c.
+__device__ __forceinline__ void select_literal(const Path& p, const float (&cm)[8], uint32_t C, uint32_t np)
+{
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+    const bool live = p.pl < p.P;
+    uint32_t pos[8], key[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bool v = live && (uint32_t)c < C;
+        pos[c] = v ? p.pl * C + (uint32_t)c : INF;
+        key[c] = v ? fbits(cm[c]) : INF;
+    }
+    uint32_t* row = p.lds + SCR_SEL + (uint32_t)(p.lane >> 3) * 8u;
+    for (uint32_t i = 0; i < np; ++i) {
+        uint32_t bk = INF;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bk = umin(bk, pos[c] != INF ? key[c] : INF);
+        const uint32_t gk = cw_min(bk);
+        uint32_t bp = INF;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bp = umin(bp, (pos[c] != INF && key[c] == gk) ? pos[c] : INF);
+        const uint32_t gp = cw_min(bp);
+        uint32_t mine = INF;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bool win = pos[c] == gp;
+            mine = win ? (((uint32_t)p.q << 3) | (uint32_t)c) : mine;
+            const bool at_i = pos[c] == i;
+            pos[c] = win ? INF : (at_i ? gp : pos[c]);
+        }
+        if (mine != INF) row[i] = mine;
+    }
+}
+
+// Chooses the np = min(L, P * C) best candidates of every codeword and re-seats the paths: on return this lane hosts
+// the path of rank p.pl (or none), taken from lane `src` (absolute), candidate `cand`; p.metric is the candidate's.
+// The candidates' exact metrics are in the scratch (row of the lane, C floats).
+__device__ __forceinline__ void select_fork(Path& p, uint32_t C, uint32_t& src, uint32_t& cand)
+{
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+    const bool live = p.pl < p.P;
+    const uint32_t np = (p.P * C < p.L) ? p.P * C : p.L;
+    float cm[8];
+    {
+        const float4* scm = reinterpret_cast<const float4*>(p.lds + SCR_CM + p.lane * 8);
+        const float4 a = scm[0], b = scm[1];
+        cm[0] = a.x; cm[1] = a.y; cm[2] = a.z; cm[3] = a.w;
+        cm[4] = b.x; cm[5] = b.y; cm[6] = b.z; cm[7] = b.w;
+    }
+    uint32_t k[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        k[c] = ((uint32_t)c < C && live) ? ((fbits(cm[c]) & ~63u) | ((uint32_t)p.q << 3) | (uint32_t)c) : INF;
+    // local order: R1 m >= m-v0 >= m-v1 >= (m-v0)-v1; SPC c0 c1 c2 {c3, c4} c5 c6 c7; REP: one compare
+    {
+        const uint32_t lo01 = umin(k[0], k[1]), hi01 = umax(k[0], k[1]);
+        k[0] = C == 2 ? lo01 : k[0];
+        k[1] = C == 2 ? hi01 : k[1];
+        const uint32_t lo34 = umin(k[3], k[4]), hi34 = umax(k[3], k[4]);
+        k[3] = lo34;  // (C < 8: k[4] is INF already)
+        k[4] = hi34;
+    }
+    uint32_t own[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) own[c] = k[c];
+    merge_level<0xB1>(k);
+    merge_level<0x4E>(k);
+    merge_level<0x141>(k);
+    // exactness check: neighbours among the np chosen, and nobody outside them at or below the last one
+    bool tie = false;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) tie = tie || ((uint32_t)(i + 1) < np && ((k[i] ^ k[i + 1]) < 64u));
+    uint32_t kcut = k[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) kcut = ((uint32_t)i < np) ? k[i] : kcut;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cnt += (own[c] != INF && (own[c] >> 6) <= (kcut >> 6)) ? 1u : 0u;
+    cnt = cw_add(cnt);
+    tie = tie || (cnt != np);
+    uint32_t sel[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sel[i] = k[i] & 63u;
+    if (ballot64(tie) != 0) {  // (wave uniform; rare on real-valued input)
+        select_literal(p, cm, C, np);
+        const uint32_t* row = p.lds + SCR_SEL + (uint32_t)(p.lane >> 3) * 8u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t e = row[i];
+            sel[i] = (tie && (uint32_t)i < np) ? (e & 63u) : sel[i];  // (tie is the same in all lanes of a codeword)
+        }
+    }
+    // seats: the first chosen candidate of a source lane stays in that lane, the others take the free lanes in order
+    uint32_t used = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) used |= ((uint32_t)i < np) ? (1u << (sel[i] >> 3)) : 0u;
+    const bool in_used = ((used >> p.q) & 1u) != 0;
+    const uint32_t fidx = (uint32_t)__builtin_popcount(~used & ((1u << p.q) - 1u) & 0xFFu);  // my number among the free lanes
+    uint32_t seen = 0, extra = 0, myj = INF;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t sq = sel[i] >> 3, bit = 1u << sq;
+        const bool valid = (uint32_t)i < np;
+        const bool first = !(seen & bit);
+        const bool take = valid && (first ? (in_used && sq == (uint32_t)p.q) : (!in_used && extra == fidx));
+        myj = take ? (uint32_t)i : myj;
+        extra += (valid && !first) ? 1u : 0u;
+        seen |= valid ? bit : 0u;
+    }
+    uint32_t mysel = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mysel = (myj == (uint32_t)i) ? sel[i] : mysel;
+    const bool seated = myj != INF;
+    src = seated ? ((uint32_t)p.g0 | (mysel >> 3)) : (uint32_t)p.lane;
+    cand = mysel & 7u;
+    // the path's state: metric from the scratch, slot word from the source lane
+    const float nm = reinterpret_cast<const float*>(p.lds + SCR_CM)[src * 8 + cand];
+    const uint32_t nslot = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)p.slot);
+    p.metric = seated ? nm : p.metric;
+    p.slot = nslot;
+    p.pl = seated ? myj : 15u;
+    p.P = np;
+}
+
+// ---- leaves ---------------------------------------------------------------------------------------------------------------
+// sum of v over the block in the reference's order: 8 strided accumulators (acc[j] += x[8k + j], k ascending), then
+// ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7   (avxconvenience.h:256-272; blocks of fewer than 8: the missing
+// lanes hold +0, which never changes a sum whose terms are not -0)
+template <int N>
+__device__ __forceinline__ float lanesum_regs(const float (&z)[N])
+{
+    if constexpr (N <= 8) {
+        float s = z[0];
+#pragma unroll
+        for (int i = 1; i < N; ++i) s = s + z[i];
+        return s;
+    } else {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = z[j];
+#pragma unroll
+        for (int i = 8; i < N; ++i) acc[i & 7] = acc[i & 7] + z[i];
+        return ((((((acc[0] + acc[1]) + acc[2]) + acc[3]) + acc[4]) + acc[5]) + acc[6]) + acc[7];
+    }
+}
+
+// the output bits of a leaf: stage T, side 0 = left child (or root), 1 = right child; NW words
+template <int T>
+__device__ __forceinline__ void put_bits(const Path& p, uint32_t side, const uint32_t (&w)[T <= 5 ? 1 : (1 << (T - 5))])
+{
+    constexpr int NW = T <= 5 ? 1 : (1 << (T - 5));
+    if constexpr (T <= 7) {
+        if (side) {
+            static_for<NW>([&](auto I) { wru<RB(1, T) + decltype(I)::value>(w[decltype(I)::value]); });
+        } else {
+            static_for<NW>([&](auto I) { wru<RB(0, T) + decltype(I)::value>(w[decltype(I)::value]); });
+        }
+    } else {
+        uint32_t* o = p.arena + (side ? AR_BR8 : AR_BL8) + p.lane;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) o[i * 64] = w[i];
+    }
+}
+
+// Input of a leaf at stage T as 16-byte chunks (T >= 5: rolled loops): the registers of stages 5 / 6 are dumped to the
+// arena first, stage 7 is read from the LDS column, stage 8 from the arena column.
+template <int T>
+struct ChunkSrc {
+    const float4* base;  // chunk c at base[c * 64]
+    __device__ __forceinline__ ChunkSrc(const Path& p)
+    {
+        if constexpr (T == 7) base = reinterpret_cast<const float4*>(p.lds + LDS_S7) + p.lane;
+        else if constexpr (T == 8) base = reinterpret_cast<const float4*>(p.arena + AR_S8) + p.lane;
+        else base = reinterpret_cast<const float4*>(p.arena + AR_DUMP) + p.lane;
+    }
+    __device__ __forceinline__ float4 chunk(uint32_t c) const { return base[c * 64]; }
+};
+template <int T>
+__device__ __forceinline__ void stage_to_dump(const Path& p)
+{
+    if constexpr (T == 5 || T == 6) {
+        dump_regs<RS(T), (1 << T) / 4>(p.arena + AR_DUMP + p.lane * 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// RateZeroDecoder::decode scl_avx_float.cpp:316-337: metric += sum of min(llr, 0); bits = 0
+// (v_min_f32 may return -0 for min(-0, +0) where the reference's _mm256_min_ps returns +0: the partial sums start from a
+//  value that is not -0 in every case that reaches the metric -- a sum of such terms added to a metric that is never -0 --
+//  so the results are the same bit for bit)
+template <int R>
+__device__ __forceinline__ float min0_reg()
+{
+    float z;
+    asm volatile("v_min_f32 %0, 0, v[%1]" : "=v"(z) : "n"(R));
+    return z;
+}
+template <int T>
+__device__ __forceinline__ void leaf_r0(Path& p, uint32_t side)
+{
+    constexpr int n = 1 << T;
+    float sum;
+    if constexpr (T <= 3) {
+        sum = min0_reg<RS(T)>();
+        static_for<n - 1>([&](auto I) { sum = sum + min0_reg<RS(T) + 1 + decltype(I)::value>(); });
+    } else if constexpr (T <= 6) {
+        float acc[8];
+        static_for<8>([&](auto J) { acc[decltype(J)::value] = min0_reg<RS(T) + decltype(J)::value>(); });
+        static_for<n - 8>([&](auto I) {
+            constexpr int i = 8 + decltype(I)::value;
+            acc[i & 7] = acc[i & 7] + min0_reg<RS(T) + i>();
+        });
+        sum = ((((((acc[0] + acc[1]) + acc[2]) + acc[3]) + acc[4]) + acc[5]) + acc[6]) + acc[7];
+    } else {
+        const ChunkSrc<T> x(p);
+        float acc[8];
+        {
+            const float4 a = x.chunk(0), b = x.chunk(1);
+            acc[0] = min0(a.x); acc[1] = min0(a.y); acc[2] = min0(a.z); acc[3] = min0(a.w);
+            acc[4] = min0(b.x); acc[5] = min0(b.y); acc[6] = min0(b.z); acc[7] = min0(b.w);
+        }
+#pragma unroll 2
+        for (uint32_t c = 2; c < (uint32_t)n / 4; c += 2) {
+            const float4 a = x.chunk(c), b = x.chunk(c + 1);
+            acc[0] += min0(a.x); acc[1] += min0(a.y); acc[2] += min0(a.z); acc[3] += min0(a.w);
+            acc[4] += min0(b.x); acc[5] += min0(b.y); acc[6] += min0(b.z); acc[7] += min0(b.w);
+        }
+        sum = ((((((acc[0] + acc[1]) + acc[2]) + acc[3]) + acc[4]) + acc[5]) + acc[6]) + acc[7];
+    }
+    p.metric = p.metric + sum;
+    uint32_t w[T <= 5 ? 1 : (1 << (T - 5))];
+#pragma unroll
+    for (int i = 0; i < (T <= 5 ? 1 : (1 << (T - 5))); ++i) w[i] = 0;
+    put_bits<T>(p, side, w);
+}
+
+// RepetitionDecoder::decode scl_avx_float.cpp:428-481 (blocks of 2 and 4): the two candidate metrics -> scratch
+template <int T>
+__device__ __forceinline__ void leaf_rep(Path& p)
+{
+    constexpr int n = 1 << T;
+    float z[n], o[n];
+    static_for<n>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const float x = rdf<RS(T) + i>();
+        z[i] = min0(x);
+        o[i] = max0(x);
+    });
+    float* scm = reinterpret_cast<float*>(p.lds + SCR_CM + p.lane * 8);
+    scm[0] = p.metric + lanesum_regs<n>(z);
+    scm[1] = p.metric - lanesum_regs<n>(o);
+}
+
+// RateOneDecoder::decode :353-413 and SpcDecoder::decode :498-621, first half: hard decisions and the weak-LLR scan of
+// the block (what follows -- findWeakLlrs' iterations, candidates, selection, bits -- is shared: fork_tail)
+template <int T>
+__device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
+{
+    constexpr int n = 1 << T;
+    ws.init();
+    if constexpr (T <= 4) {
+        uint32_t s = 0;
+        static_for<n>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const uint32_t b = rdu<RS(T) + i>();
+            s |= (b >> 31) << i;
+            if constexpr (i < 4) ws.hv[i] = b & 0x7FFFFFFFu;
+            else ws.tail(b & 0x7FFFFFFFu, (uint32_t)i);
+        });
+        ws.sg[0] = s;
+    } else {
+        stage_to_dump<T>(p);
+        const ChunkSrc<T> x(p);
+        {
+            const float4 a = x.chunk(0);
+            const uint32_t e[4] = { fbits(a.x), fbits(a.y), fbits(a.z), fbits(a.w) };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ws.sg[0] |= (e[i] >> 31) << i;
+                ws.hv[i] = e[i] & 0x7FFFFFFFu;
+            }
+        }
+        static_for<(n + 31) / 32>([&](auto Wd) {
+            constexpr int wd = decltype(Wd)::value;
+            uint32_t s = ws.sg[wd];
+#pragma unroll 1
+            for (uint32_t c = (wd == 0 ? 1u : 0u); c < 8; ++c) {
+                const uint32_t ch = (uint32_t)wd * 8u + c;
+                const float4 a = x.chunk(ch);
+                const uint32_t e[4] = { fbits(a.x), fbits(a.y), fbits(a.z), fbits(a.w) };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s |= (e[i] >> 31) << (4u * c + (uint32_t)i);
+                    ws.tail(e[i] & 0x7FFFFFFFu, 4u * ch + (uint32_t)i);
+                }
+            }
+            ws.sg[wd] = s;
+        });
+    }
+}
+
+// Second half of the forking leaves, one instance for all of them.  kind: 1 RateOne, 2 SPC, 3 repetition; T = log2 of
+// the block length; ws: the scan of this lane's path (kinds 1, 2).
+__device__ __forceinline__ void fork_tail(Path& p, uint32_t kind, uint32_t T, uint32_t side, WeakScan& ws)
+{
+    const uint32_t n = 1u << T;
+    uint32_t* rec = p.lds + SCR_FORK + p.lane * 8;
+    if (kind != 3u) {
+        uint32_t wv[4], wi[4];
+        ws.finish(n, kind == 2u ? 4u : 2u, wv, wi);
+        const float m = p.metric;
+        float cm[8];
+        uint32_t par = 0;
+        if (kind == 2u) {
+            par = (uint32_t)__builtin_popcount(ws.sg[0] ^ ws.sg[1] ^ ws.sg[2] ^ ws.sg[3]) & 1u;
+            const float v0 = bitsf(wv[0]), v1 = bitsf(wv[1]), v2 = bitsf(wv[2]), v3 = bitsf(wv[3]);
+            const float t = m - v0;        // m' - pinv * v0 (par: m' = m - v0, pinv = 0; else m' = m, pinv = 1)
+            const float mp = par ? t : m;  // m'
+            cm[0] = mp;
+            cm[1] = t - v1;
+            cm[2] = t - v2;
+            cm[3] = t - v3;
+            cm[4] = (mp - v1) - v2;
+            cm[5] = (mp - v1) - v3;
+            cm[6] = (mp - v2) - v3;
+            cm[7] = ((t - v1) - v2) - v3;
+        } else {
+            const float v0 = bitsf(wv[0]), v1 = bitsf(wv[1]);
+            cm[0] = m;
+            cm[1] = m - v0;
+            cm[2] = m - v1;
+            cm[3] = (m - v0) - v1;
+            cm[4] = cm[5] = cm[6] = cm[7] = 0.0f;
+        }
+        float4* scm = reinterpret_cast<float4*>(p.lds + SCR_CM + p.lane * 8);
+        scm[0] = make_float4(cm[0], cm[1], cm[2], cm[3]);
+        scm[1] = make_float4(cm[4], cm[5], cm[6], cm[7]);
+        // fork record of this lane's path: the new hosts of its children read it
+        rec[0] = ws.sg[0];
+        rec[1] = ws.sg[1];
+        rec[2] = ws.sg[2];
+        rec[3] = ws.sg[3];
+        rec[4] = (wi[0] & 0xFFu) | ((wi[1] & 0xFFu) << 8) | ((wi[2] & 0xFFu) << 16) | ((wi[3] & 0xFFu) << 24);
+        rec[5] = par;
+    }
+    uint32_t src, cand;
+    select_fork(p, kind == 2u ? 8u : (kind == 1u ? 4u : 2u), src, cand);
+    uint32_t w[4];
+    if (kind == 3u) {
+        w[0] = cand ? ((1u << n) - 1u) : 0u;  // (n <= 4)
+        w[1] = w[2] = w[3] = 0;
+    } else {
+        const uint32_t* sr = p.lds + SCR_FORK + src * 8;
+        const uint32_t spk = sr[4], spar = sr[5];
+        // which of the weak positions the candidate flips (RateOne: 1 -> ix0, 2 -> ix1, 3 -> both; SPC :541-613)
+        uint32_t fl[4];
+        if (kind == 2u) {
+            fl[0] = ((spar ? 0x71u : 0x8Eu) >> cand) & 1u;
+            fl[1] = (0xB2u >> cand) & 1u;
+            fl[2] = (0xD4u >> cand) & 1u;
+            fl[3] = (0xE8u >> cand) & 1u;
+        } else {
+            fl[0] = cand & 1u;
+            fl[1] = (cand >> 1) & 1u;
+            fl[2] = fl[3] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = sr[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ix = (spk >> (8 * k)) & 0xFFu;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] ^= (fl[k] && (ix >> 5) == (uint32_t)i) ? (1u << (ix & 31u)) : 0u;
+        }
+    }
+    switch (T) {
+    case 7: { const uint32_t o[4] = { w[0], w[1], w[2], w[3] }; put_bits<7>(p, side, o); break; }
+    case 6: { const uint32_t o[2] = { w[0], w[1] }; put_bits<6>(p, side, o); break; }
+    case 5: { const uint32_t o[1] = { w[0] }; put_bits<5>(p, side, o); break; }
+    case 4: { const uint32_t o[1] = { w[0] }; put_bits<4>(p, side, o); break; }
+    case 3: { const uint32_t o[1] = { w[0] }; put_bits<3>(p, side, o); break; }
+    case 2: { const uint32_t o[1] = { w[0] }; put_bits<2>(p, side, o); break; }
+    default: { const uint32_t o[1] = { w[0] }; put_bits<1>(p, side, o); break; }
+    }
+}
+
+// ---- COMBINE: bits[T] = [left ^ right | right], left = the slot holder's, right = own -------------------------------------
+template <int T>
+__device__ __forceinline__ void op_combine(Path& p, uint32_t side)
+{
+    const uint32_t ho = p.owner(T) << 2;  // holder of the left child's bits
+    if constexpr (T <= 5) {
+        constexpr int h = 1 << (T - 1);
+        const uint32_t l = rd_lane<RBL0 + (T - 1)>(ho), r = rdu<RBR0 + (T - 1)>();
+        const uint32_t w[1] = { ((l ^ r) & ((1u << h) - 1u)) | (r << h) };
+        put_bits<T>(p, side, w);
+    } else if constexpr (T == 6) {
+        const uint32_t l = rd_lane<RBL0 + 5>(ho), r = rdu<RBR0 + 5>();
+        const uint32_t w[2] = { l ^ r, r };
+        put_bits<6>(p, side, w);
+    } else if constexpr (T == 7) {
+        const uint32_t l0 = rd_lane<RBL6>(ho), l1 = rd_lane<RBL6 + 1>(ho), r0 = rdu<RBR6>(), r1 = rdu<RBR6 + 1>();
+        const uint32_t w[4] = { l0 ^ r0, l1 ^ r1, r0, r1 };
+        put_bits<7>(p, side, w);
+    } else if constexpr (T == 8) {
+        const uint32_t l0 = rd_lane<RBL7>(ho), l1 = rd_lane<RBL7 + 1>(ho), l2 = rd_lane<RBL7 + 2>(ho), l3 = rd_lane<RBL7 + 3>(ho);
+        const uint32_t r0 = rdu<RBR7>(), r1 = rdu<RBR7 + 1>(), r2 = rdu<RBR7 + 2>(), r3 = rdu<RBR7 + 3>();
+        const uint32_t w[8] = { l0 ^ r0, l1 ^ r1, l2 ^ r2, l3 ^ r3, r0, r1, r2, r3 };
+        put_bits<8>(p, side, w);
+    } else {  // T == 9: 8 + 8 words from the arena -> 16 words to the arena
+        const uint32_t* lp = p.arena + AR_BL8 + p.owner(9);
+        const uint32_t* rp = p.arena + AR_BR8 + p.lane;
+        uint32_t* o = p.arena + (side ? AR_BR9 : AR_BL9) + p.lane;
+        uint32_t l[8], r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            l[i] = lp[i * 64];
+            r[i] = rp[i * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            o[i * 64] = l[i] ^ r[i];
+            o[(8 + i) * 64] = r[i];
+        }
+    }
+}
+
+// ---- the top of the tree -------------------------------------------------------------------------------------------------
+// LN_VT: the stage-8 block of this path from the channel row (stage 9 = f / g of the row is never stored), optionally
+// with the F of stage 8 on the values in registers.  Element e of stage 8 needs the row at e, e + 256, e + 512, e + 768.
+__device__ __forceinline__ void op_vt(Path& p, uint32_t off, const float* chan)
+{
+    const bool r9 = (off & 1u) != 0, isg = (off & 2u) != 0, f8 = (off & 4u) != 0;
+    if (r9 && !isg) p.set_field(10);  // the G of the root directly follows its left child: the bits are this lane's own
+    const uint32_t* bl9 = p.arena + AR_BL9 + p.owner(10);  // the root's left-child bits: with the slot holder
+    const uint32_t* bl8 = p.arena + AR_BL8 + p.lane;       // own (the G follows its left child directly)
+    float4* s8 = reinterpret_cast<float4*>(p.arena + AR_S8) + p.lane;
+    float4* s7 = reinterpret_cast<float4*>(p.lds + LDS_S7) + p.lane;
+    for (uint32_t jo = 0; jo < 4; ++jo) {
+        uint32_t wa = 0, wb = 0, wc = 0, wd = 0, ue = 0, uf = 0;
+        if (r9) {
+            wa = bl9[jo * 64];
+            wb = bl9[(8 + jo) * 64];
+            wc = bl9[(4 + jo) * 64];
+            wd = bl9[(12 + jo) * 64];
+        }
+        if (isg) {
+            ue = bl8[jo * 64];
+            uf = bl8[(4 + jo) * 64];
+        }
+#pragma unroll 2
+        for (uint32_t ji = 0; ji < 8; ++ji) {
+            const uint32_t j = jo * 8 + ji, sh = 4 * ji, e0 = 4 * j;
+            const float4 c0 = ldg4(chan + e0), c1 = ldg4(chan + e0 + 256), c2 = ldg4(chan + e0 + 512), c3 = ldg4(chan + e0 + 768);
+            const float4 d0 = ldg4(chan + e0 + 128), d1 = ldg4(chan + e0 + 384), d2 = ldg4(chan + e0 + 640), d3 = ldg4(chan + e0 + 896);
+            float4 a, b, c, d;
+            if (r9) {
+                a = g4(c0, c2, (wa >> sh) & 15u);
+                b = g4(c1, c3, (wb >> sh) & 15u);
+                c = g4(d0, d2, (wc >> sh) & 15u);
+                d = g4(d1, d3, (wd >> sh) & 15u);
+            } else {
+                a = f4(c0, c2);
+                b = f4(c1, c3);
+                c = f4(d0, d2);
+                d = f4(d1, d3);
+            }
+            float4 x, y;
+            if (isg) {
+                x = g4(a, b, (ue >> sh) & 15u);
+                y = g4(c, d, (uf >> sh) & 15u);
+            } else {
+                x = f4(a, b);
+                y = f4(c, d);
+            }
+            s8[j * 64] = x;
+            s8[(j + 32) * 64] = y;
+            if (f8) s7[j * 64] = f4(x, y);
+        }
+    }
+    if (isg) p.set_field(9);
+    p.set_field(8);
+    if (f8) p.set_field(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// stage 8 (arena column) -> stage 7 (LDS column): kind 0 = F, 1 = G (column of the slot owner), 2 = a + b
+__device__ __forceinline__ void op_fg8(Path& p, uint32_t kind)
+{
+    const uint32_t col = kind == 1u ? p.owner(8) : (uint32_t)p.lane;
+    const float4* s8 = reinterpret_cast<const float4*>(p.arena + AR_S8) + col;
+    float4* s7 = reinterpret_cast<float4*>(p.lds + LDS_S7) + p.lane;
+    const uint32_t w0 = rdu<RBL7>(), w1 = rdu<RBL7 + 1>(), w2 = rdu<RBL7 + 2>(), w3 = rdu<RBL7 + 3>();
+#pragma unroll 1
+    for (uint32_t jo = 0; jo < 4; ++jo) {
+        const uint32_t w = kind != 1u ? 0u : (jo == 0 ? w0 : (jo == 1 ? w1 : (jo == 2 ? w2 : w3)));
+#pragma unroll 2
+        for (uint32_t ji = 0; ji < 8; ++ji) {
+            const uint32_t j = jo * 8 + ji;
+            const float4 a = s8[j * 64], b = s8[(j + 32) * 64];
+            s7[j * 64] = kind == 0u ? f4(a, b) : g4(a, b, (w >> (4 * ji)) & 15u);  // (a + b = g with zero bits)
+        }
+    }
+    if (kind != 0u) p.set_field(8);
+    p.set_field(7);
+}
+
+// stage 7 (LDS column) -> stage 6 (registers)
+template <int KIND>
+__device__ __forceinline__ void op_fg7(Path& p, uint32_t absmask, uint32_t signmask)
+{
+    const uint32_t col = KIND == 1 ? p.owner(7) : (uint32_t)p.lane;
+    const uint32_t addr = (uint32_t)(uintptr_t)p.lds + col * 16u;
+    if constexpr (KIND == 0) {
+        f7_round<0>(addr, absmask);
+        f7_round<1>(addr, absmask);
+    } else if constexpr (KIND == 1) {
+        const uint32_t w0 = rdu<RBL6>(), w1 = rdu<RBL6 + 1>();
+        g7_round<0, false>(addr, w0, signmask);
+        g7_round<1, false>(addr, w1, signmask);
+    } else {  // a + b = g with zero bits
+        g7_round<0, false>(addr, 0, signmask);
+        g7_round<1, false>(addr, 0, signmask);
+    }
+    if (KIND != 0) p.set_field(7);
+    p.set_field(6);
+}
+
+template <int KIND, int T>
+__device__ __forceinline__ void op_fg_reg(Path& p, uint32_t absmask, uint32_t signmask)
+{
+    if constexpr (KIND == 0) f_reg<T>(absmask);
+    else if constexpr (KIND == 1) g_reg<T>(p.owner(T) << 2, signmask);
+    else g0_reg<T>();
+    if (KIND != 0) p.set_field(T);
+    p.set_field(T - 1);
+}
+
+}  // namespace lane
+
+// =====================================================================================================================
+//  kernel
+// =====================================================================================================================
+template <bool DIAG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(lane::KV)))
+void scl_lane_kernel(const DecodeParams P)
+{
+    using namespace lane;
+    // (dynamic: with a static 40 KB the compiler derives one wave per SIMD from the LDS size and then ignores the VGPR cap)
+    extern __shared__ uint32_t lds[];
+    asm volatile("" ::: "v255", "a0");  // (sizes the register file: the hand-allocated registers reach up to v253; a0: see KV)
+    const int lane = (int)threadIdx.x;
+    const uint32_t nrows = P.rows_dev ? *P.rows_dev : P.rows;
+    const uint32_t ngroups = (nrows + 7u) >> 3;
+    const uint32_t absmask = 0x7FFFFFFFu, signmask = 0x80000000u;
+    const_u64_ptr prog = (const_u64_ptr)(const void*)P.prog;
+    const uint32_t N = P.N;
+
+    Path p;
+    p.lane = lane;
+    p.q = lane & 7;
+    p.g0 = lane & ~7;
+    p.self4 = (uint32_t)lane << 2;
+    p.lds = lds;
+    p.arena = reinterpret_cast<uint32_t*>(P.arena) + (size_t)blockIdx.x * AR_WORDS;
+    p.L = P.L;
+
+    for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const uint32_t ci = grp * 8u + ((uint32_t)lane >> 3);
+        const bool live = ci < nrows;
+        const uint32_t cj = live ? ci : grp * 8u;
+        const uint32_t row = P.rowidx ? P.rowidx[cj] : cj;
+        const float* chan = reinterpret_cast<const float*>(P.llr) + (size_t)row * N;
+        p.metric = 0.0f;
+        p.pl = p.q == 0 ? 0u : 15u;
+        p.P = 1;
+        p.slot = (uint32_t)p.q * 0x01249249u;  // every field = own lane
+        uint32_t trace_n = 0;
+
+        for (uint32_t pc = 0;; ++pc) {
+            const uint64_t raw = prog[pc];
+            const uint32_t op = (uint32_t)raw & 0xFFu, st = ((uint32_t)raw >> 8) & 0xFFu, side = ((uint32_t)raw >> 16) & 0xFFu;
+            const uint32_t off = (uint32_t)(raw >> 32);
+            if (op == OP_END) break;
+            bool is_leaf = false;
+            uint32_t fkind = 0;  // forking leaf: 1 RateOne, 2 SPC, 3 repetition
+            WeakScan ws;
+            switch (op) {
+            case LN_VT: op_vt(p, off, chan); break;
+            case LN_F:
+                switch (st) {
+                case 8: op_fg8(p, 0); break;
+                case 7: op_fg7<0>(p, absmask, signmask); break;
+                case 6: op_fg_reg<0, 6>(p, absmask, signmask); break;
+                case 5: op_fg_reg<0, 5>(p, absmask, signmask); break;
+                case 4: op_fg_reg<0, 4>(p, absmask, signmask); break;
+                case 3: op_fg_reg<0, 3>(p, absmask, signmask); break;
+                default: op_fg_reg<0, 2>(p, absmask, signmask); break;
+                }
+                break;
+            case LN_G:
+                switch (st) {
+                case 8: op_fg8(p, 1); break;
+                case 7: op_fg7<1>(p, absmask, signmask); break;
+                case 6: op_fg_reg<1, 6>(p, absmask, signmask); break;
+                case 5: op_fg_reg<1, 5>(p, absmask, signmask); break;
+                case 4: op_fg_reg<1, 4>(p, absmask, signmask); break;
+                case 3: op_fg_reg<1, 3>(p, absmask, signmask); break;
+                default: op_fg_reg<1, 2>(p, absmask, signmask); break;
+                }
+                break;
+            case LN_G0:
+                switch (st) {
+                case 8: op_fg8(p, 2); break;
+                case 7: op_fg7<2>(p, absmask, signmask); break;
+                case 6: op_fg_reg<2, 6>(p, absmask, signmask); break;
+                case 5: op_fg_reg<2, 5>(p, absmask, signmask); break;
+                case 4: op_fg_reg<2, 4>(p, absmask, signmask); break;
+                case 3: op_fg_reg<2, 3>(p, absmask, signmask); break;
+                default: op_fg_reg<2, 2>(p, absmask, signmask); break;
+                }
+                break;
+            case LN_C:
+                switch (st) {
+                case 9: op_combine<9>(p, side); break;
+                case 8: op_combine<8>(p, side); break;
+                case 7: op_combine<7>(p, side); break;
+                case 6: op_combine<6>(p, side); break;
+                case 5: op_combine<5>(p, side); break;
+                case 4: op_combine<4>(p, side); break;
+                case 3: op_combine<3>(p, side); break;
+                default: op_combine<2>(p, side); break;
+                }
+                if (st >= 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                break;
+            case LN_R0:
+                is_leaf = true;
+                switch (st) {
+                case 8: leaf_r0<8>(p, side); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 7: leaf_r0<7>(p, side); break;
+                case 6: leaf_r0<6>(p, side); break;
+                case 5: leaf_r0<5>(p, side); break;
+                case 4: leaf_r0<4>(p, side); break;
+                case 3: leaf_r0<3>(p, side); break;
+                case 2: leaf_r0<2>(p, side); break;
+                default: leaf_r0<1>(p, side); break;
+                }
+                break;
+            case LN_REP:
+                is_leaf = true;
+                fkind = 3;
+                if (st == 2) leaf_rep<2>(p);
+                else leaf_rep<1>(p);
+                break;
+            case LN_R1:
+            case LN_SPC:
+                is_leaf = true;
+                fkind = op == LN_SPC ? 2u : 1u;
+                switch (st) {
+                case 7: leaf_scan<7>(p, ws); break;
+                case 6: leaf_scan<6>(p, ws); break;
+                case 5: leaf_scan<5>(p, ws); break;
+                case 4: leaf_scan<4>(p, ws); break;
+                case 3: leaf_scan<3>(p, ws); break;
+                case 2: leaf_scan<2>(p, ws); break;
+                default: leaf_scan<1>(p, ws); break;
+                }
+                break;
+            default: break;
+            }
+            if (fkind) fork_tail(p, fkind, st, side, ws);
+            if (DIAG && P.trace && grp == 0 && is_leaf) {
+                if (trace_n < P.trace_cap && lane < 8) {
+                    float* t = P.trace + (size_t)trace_n * (1 + P.L);
+                    if (lane == 0) t[0] = (float)p.P;
+                    if ((uint32_t)lane >= p.P && (uint32_t)lane < P.L) t[1 + lane] = 0.0f;
+                    if (p.pl < p.P) t[1 + p.pl] = p.metric;
+                }
+                ++trace_n;
+            }
+        }
+
+        // ---- SclAvxFloat::extractBestPath :711-750 -----------------------------------------------------------------
+        // code word of this path: [left ^ right | right] of the root's children (16 + 16 words from the arena)
+        uint32_t xw[32];
+        {
+            const uint32_t* lp = p.arena + AR_BL9 + p.owner(10);
+            const uint32_t* rp = p.arena + AR_BR9 + p.lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t l = lp[i * 64], r = rp[i * 64];
+                xw[i] = l ^ r;
+                xw[16 + i] = r;
+            }
+        }
+        if (!P.systematic) {  // re-encode (:731-746): u = x G, butterflies inside the words, then between them
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                uint32_t v = xw[i];
+                v ^= (v >> 1) & 0x55555555u;
+                v ^= (v >> 2) & 0x33333333u;
+                v ^= (v >> 4) & 0x0F0F0F0Fu;
+                v ^= (v >> 8) & 0x00FF00FFu;
+                v ^= (v >> 16) & 0x0000FFFFu;
+                xw[i] = v;
+            }
+#pragma unroll
+            for (int hw = 1; hw < 32; hw <<= 1) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (!(i & hw)) xw[i] ^= xw[i + hw];
+            }
+        }
+        uint32_t* xl = lds + LDS_S7;  // (stage 7 is dead now) word w of lane l at [w * 64 + l]
+#pragma unroll
+        for (int i = 0; i < 32; ++i) xl[i * 64 + lane] = xw[i];
+        // detector verdict of every path (syndrome XOR over its set information bits)
+        const bool alive = p.pl < p.P;
+        uint32_t syn = 0;
+        if (P.det_on) {
+#pragma unroll 4
+            for (uint32_t t = 0; t < P.K; ++t) {
+                const uint32_t pos = P.lut[t], sy = P.syn[t];
+                const uint32_t w = xl[(pos >> 5) * 64 + lane];
+                syn ^= ((w >> (pos & 31u)) & 1u) ? sy : 0u;
+            }
+        }
+        const uint32_t wpl = cw_min((alive && syn == 0) ? p.pl : 99u);  // first passing path in list order
+        const uint32_t okflag = wpl != 99u ? 1u : 0u;
+        const uint32_t want = okflag ? wpl : 0u;
+        const uint32_t wl = cw_min((alive && p.pl == want) ? (uint32_t)lane : 99u);  // its lane
+        // information bits of the winner: the 8 lanes of a codeword pack 8 bytes each
+        if (live) {
+            uint8_t* orow = P.out + (size_t)row * P.nb;
+            const uint32_t* wx = xl + wl;
+            for (uint32_t b0 = (uint32_t)p.q * 8u; b0 < P.nb; b0 += 64u) {
+                for (uint32_t bb = 0; bb < 8 && b0 + bb < P.nb; ++bb) {
+                    uint32_t byte = 0;
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; ++i) {
+                        const uint32_t t = (b0 + bb) * 8u + i;
+                        if (t < P.K) {
+                            const uint32_t pos = P.lut[t];
+                            byte |= ((wx[(pos >> 5) * 64] >> (pos & 31u)) & 1u) << (7u - i);
+                        }
+                    }
+                    orow[b0 + bb] = (uint8_t)byte;
+                }
+            }
+            if (p.q == 0 && P.ok) P.ok[row] = (uint8_t)okflag;
+            if (P.metrics) {
+                if ((uint32_t)p.q >= p.P && (uint32_t)p.q < P.L) P.metrics[(size_t)row * P.L + p.q] = 0.0f;
+                if (alive) P.metrics[(size_t)row * P.L + p.pl] = p.metric;
+            }
+        }
+        WAVE_SYNC();
+    }
+}
+
+hipError_t launch_scl_lane(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
+{
+#ifdef PAMD_DIAG
+    if (diag) {
+        hipLaunchKernelGGL(scl_lane_kernel<true>, dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+        return hipGetLastError();
+    }
+#else
+    if (diag) return hipErrorInvalidValue;
+#endif
+    hipLaunchKernelGGL(scl_lane_kernel<false>, dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+    return hipGetLastError();
+}
+unsigned scl_lane_arena_words() { return lane::AR_WORDS; }
+
+}  // namespace pamd
