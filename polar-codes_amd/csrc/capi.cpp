@@ -70,6 +70,8 @@ struct pcd_decoder {
     pamd::Program lane_prog;
     bool has_lane = false;
     pamd::Ins* d_lane_prog = nullptr;
+    uint32_t* d_ext = nullptr;        // extraction masks per 32 code bits (deposit_table)
+    uint32_t* d_syn_bytes = nullptr;  // nb x 256 syndrome words per output byte value
 
     // launch geometry
     unsigned sc_wave_words = 0, sc_wpb = 4;  // LDS words per codeword, waves per workgroup
@@ -648,6 +650,10 @@ int ensure_device(pcd_decoder* d, pamd::DeviceScope& scope)
             const size_t b = d->lane_prog.ins.size() * sizeof(pamd::Ins);
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_lane_prog), b));
             HIP_TRY(hipMemcpy(d->d_lane_prog, d->lane_prog.ins.data(), b, hipMemcpyHostToDevice));
+            const std::vector<pamd::DepositWord> ext = pamd::deposit_table(d->N, d->frozen);
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_ext), ext.size() * sizeof(pamd::DepositWord)));
+            HIP_TRY(hipMemcpy(d->d_ext, ext.data(), ext.size() * sizeof(pamd::DepositWord), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_syn_bytes), (size_t)std::max(1u, d->nb) * 256 * 4));
         }
         // information-bit LUT (BitContainer::calculateLUT bitcontainer.cpp:68-84)
         std::vector<uint16_t> lut;
@@ -670,6 +676,18 @@ int ensure_device(pcd_decoder* d, pamd::DeviceScope& scope)
     if (d->det_dirty) {
         const std::vector<uint32_t> syn = d->det.syndrome_table(d->K);
         if (!syn.empty()) HIP_TRY(hipMemcpy(d->d_syn, syn.data(), syn.size() * 4, hipMemcpyHostToDevice));
+        if (d->has_lane && d->nb) {
+            // the same syndrome per (output byte, byte value): information bit 8 j + i is bit 7 - i of byte j
+            std::vector<uint32_t> tb((size_t)d->nb * 256, 0u);
+            for (unsigned j = 0; j < d->nb; ++j)
+                for (unsigned v = 1; v < 256; ++v) {
+                    uint32_t x = 0;
+                    for (unsigned i = 0; i < 8; ++i)
+                        if (((v >> (7 - i)) & 1u) && 8 * j + i < d->K) x ^= syn[8 * j + i];
+                    tb[(size_t)j * 256 + v] = x;
+                }
+            HIP_TRY(hipMemcpy(d->d_syn_bytes, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
+        }
         d->det_dirty = false;
     }
     return PCD_OK;
@@ -740,6 +758,8 @@ int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
 {
     P.prog = d->d_lane_prog;
+    P.ext = d->d_ext;
+    P.syn_bytes = d->d_syn_bytes;
     P.prog_len = (uint32_t)d->lane_prog.ins.size() - 1u;
     const unsigned need = (unsigned)((P.rows + 7u) / 8u);
     unsigned per_cu = 4;
@@ -748,13 +768,13 @@ int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
     int rc = grow(d->d_arena, d->d_arena_cap, (size_t)grid * pamd::scl_lane_arena_words() * sizeof(uint32_t));
     if (rc) return rc;
     P.arena = d->d_arena;
-    HIP_TRY(pamd::launch_scl_lane(P, P.trace != nullptr, grid, st));
+    HIP_TRY(pamd::launch_scl_lane(P, P.trace != nullptr || P.cycles != nullptr || P.ablate != 0, grid, st));
     return PCD_OK;
 }
 
 int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
-    if (d->has_lane && !i8 && !P.cycles) return run_scl_lane(d, P, st);
+    if (d->has_lane && !i8) return run_scl_lane(d, P, st);
     P.prog = d->d_scl_prog;
     if (!P.prog_len) P.prog_len = (uint32_t)d->scl_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->scl_wave_words;
@@ -1093,6 +1113,8 @@ void pcd_destroy(pcd_decoder* d)
         (void)hipFree(d->d_sc_prog);
         (void)hipFree(d->d_scl_prog);
         if (d->d_lane_prog) (void)hipFree(d->d_lane_prog);
+        if (d->d_ext) (void)hipFree(d->d_ext);
+        if (d->d_syn_bytes) (void)hipFree(d->d_syn_bytes);
         (void)hipFree(d->d_lut);
         (void)hipFree(d->d_syn);
         (void)hipFree(d->d_count);
@@ -1266,7 +1288,8 @@ int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t*
     pamd::DeviceScope scope;
     int rc = ensure_device(d, scope);
     if (rc) return rc;
-    const unsigned n = (unsigned)d->scl_prog.ins.size();
+    const pamd::Program& prog = d->has_lane ? d->lane_prog : d->scl_prog;  // (the program the kernel of this decoder runs)
+    const unsigned n = (unsigned)prog.ins.size();
     *count = n;
     uint32_t* dcyc = nullptr;
     if ((rc = grow(d->d_in, d->d_in_cap, (size_t)d->N * 4))) return rc;
@@ -1285,15 +1308,15 @@ int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t*
         if (const char* dump = PAMD_ENV("PCD_SUBPROFILE")) {  // leaf phase stamps (diagnostics)
             if (FILE* f = std::fopen(dump, "w")) {
                 for (unsigned i = 0; i + 1 < n; ++i)
-                    std::fprintf(f, "%u %u %u %u %u %u %u\n", (unsigned)d->scl_prog.ins[i].op, (unsigned)d->scl_prog.ins[i].stage,
+                    std::fprintf(f, "%u %u %u %u %u %u %u\n", (unsigned)prog.ins[i].op, (unsigned)prog.ins[i].stage,
                                  h[i], h[(n - 1) + 4 * i], h[(n - 1) + 4 * i + 1], h[(n - 1) + 4 * i + 2], h[(n - 1) + 4 * i + 3]);
                 std::fclose(f);
             }
         }
         for (unsigned i = 0; i < n && i < cap; ++i) {
             cycles[i] = h[i];
-            if (ops) ops[i] = d->scl_prog.ins[i].op;
-            if (stages) stages[i] = d->scl_prog.ins[i].stage;
+            if (ops) ops[i] = prog.ins[i].op;
+            if (stages) stages[i] = prog.ins[i].stage;
         }
     }
     (void)hipFree(dcyc);

@@ -16,6 +16,8 @@ struct DecodeParams {
     const Ins* prog;         // decode program (device)
     const uint16_t* lut;     // K code-bit positions of the information bits, ascending
     const uint32_t* syn;     // K detector syndrome words
+    const uint32_t* ext;     // lane kernel: DepositWord per 32 code bits (mask of the information positions, move masks, offset)
+    const uint32_t* syn_bytes;  // lane kernel: nb x 256 syndrome words, one per (output byte, byte value)
     uint8_t* out;            // rows x nb
     uint8_t* ok;             // rows (nullable)
     float* metrics;          // rows x L (nullable)

@@ -78,7 +78,50 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out)
     }
     put(OP_END, 0, 0, 0);
     // the first op must be the left-left pass over the channel row
-    return !out.ins.empty() && out.ins[0].op == LN_VT;
+    if (out.ins.empty() || out.ins[0].op != LN_VT) return false;
+    // fuse what lies between two leaves into LN_WALK: [C ... C] [G | G0] [F ... F]
+    std::vector<Ins> w;
+    const std::vector<Ins>& o = out.ins;
+    for (size_t k = 0; k < o.size();) {
+        if (o[k].op != LN_C && o[k].op != LN_G && o[k].op != LN_G0 && o[k].op != LN_F) {
+            w.push_back(o[k++]);
+            continue;
+        }
+        unsigned c0 = 0, c1 = 0, gs = 0, gk = 0, f1 = 0, f0 = 0, side = 0;
+        if (o[k].op == LN_C) {
+            c0 = c1 = o[k].stage;
+            side = o[k].side;
+            ++k;
+            while (o[k].op == LN_C && o[k].stage == c1 + 1 && side == 1) {  // (the node below was this one's right child)
+                c1 = o[k].stage;
+                side = o[k].side;
+                ++k;
+            }
+        }
+        if (o[k].op == LN_G || o[k].op == LN_G0) {
+            gs = o[k].stage;
+            gk = o[k].op == LN_G ? 1u : 2u;
+            ++k;
+        }
+        if (o[k].op == LN_F && (gs == 0 || o[k].stage + 1u == gs)) {
+            f1 = f0 = o[k].stage;
+            ++k;
+            while (o[k].op == LN_F && o[k].stage + 1u == f0) {
+                f0 = o[k].stage;
+                ++k;
+            }
+        }
+        Ins i;
+        i.op = (uint8_t)LN_WALK;
+        i.stage = 0;
+        i.side = (uint8_t)side;
+        i.pad = 0;
+        i.off = c0 | (c1 << 4) | (gs << 8) | (gk << 12) | (f1 << 16) | (f0 << 20);
+        w.push_back(i);
+    }
+    w.push_back(w.back());  // a spare word behind OP_END: the kernel fetches one instruction ahead
+    out.ins.swap(w);
+    return true;
 }
 
 }  // namespace pamd

@@ -88,6 +88,10 @@ enum Op : uint8_t {
     LN_R1,
     LN_REP,
     LN_SPC,
+    // Everything between two leaves (or a leaf and an LN_VT) in one instruction: COMBINEs at stages c0 .. c1 up a right
+    // spine (the last one writes to `side`, the others are right children), then a G (kind 1) / G0 (kind 2) at stage gs,
+    // then Fs from stage f1 down to f0.  off: c0 | c1 << 4 | gs << 8 | kind << 12 | f1 << 16 | f0 << 20 (0 = absent)
+    LN_WALK,
 };
 
 struct Ins {

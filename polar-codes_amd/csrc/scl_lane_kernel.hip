@@ -24,6 +24,7 @@
 // metric sums follow the reference's 8-accumulator order (avxconvenience.h:256-272); findWeakLlrs and
 // simplePartialSortDescending (arrayfuncs.h:161-231) are reproduced including their swap-order tie behaviour (the merge
 // selection falls back to a literal emulation whenever two keys that matter agree in their upper 26 bits).
+#define PAMD_POLAR_F_MINF 1  // (device_common.h: the 3-instruction f)
 #include "device_common.h"
 
 #include <utility>
@@ -321,6 +322,19 @@ __device__ __forceinline__ uint32_t cw_add(uint32_t v)
     return v + dpp_u32<0x141>(v);
 }
 
+// diagnostics: cycle stamp k (0 .. 3) of the instruction being profiled (sub: nullptr in the production kernel)
+struct Stamps {
+    uint32_t* sub;
+    uint64_t t0;
+    __device__ __forceinline__ void mark(int k) const
+    {
+        if (sub) {
+            const uint64_t t = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) sub[k] = (uint32_t)(t - t0);
+        }
+    }
+};
+
 // per-lane state the compiler keeps (everything else lives in the hand-allocated registers)
 struct Path {
     float metric;
@@ -372,6 +386,55 @@ struct WeakScan {
             ap = sp;
             placed = lt;
         }
+    }
+    // The same result without the swap emulation, valid while the smallest values are pairwise different (then the
+    // selection is a plain sort): heads sorted with their indices, merged with the (sorted) tail minima.  Returns false
+    // when two of the values that matter are equal -- the caller then runs finish().  T = log2 of the block length.
+    __device__ __forceinline__ bool finish_fast(uint32_t (&wv)[4], uint32_t (&wi)[4], uint32_t T) const
+    {
+        uint32_t a[4] = { hv[0], hv[1], hv[2], hv[3] }, ai[4] = { 0u, 1u, 2u, 3u };
+        auto ce = [](uint32_t& x, uint32_t& xi, uint32_t& y, uint32_t& yi) {
+            const bool sw = y < x;
+            const uint32_t lo = sw ? y : x, li = sw ? yi : xi, hi = sw ? x : y, hj = sw ? xi : yi;
+            x = lo; xi = li; y = hi; yi = hj;
+        };
+        if (T <= 1u) {  // two elements
+            ce(a[0], ai[0], a[1], ai[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wv[i] = a[i];
+                wi[i] = ai[i];
+            }
+            return a[0] != a[1];
+        }
+        ce(a[0], ai[0], a[1], ai[1]);
+        ce(a[2], ai[2], a[3], ai[3]);
+        ce(a[0], ai[0], a[2], ai[2]);
+        ce(a[1], ai[1], a[3], ai[3]);
+        ce(a[1], ai[1], a[2], ai[2]);
+        if (T == 2u) {  // four elements: no tail
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wv[i] = a[i];
+                wi[i] = ai[i];
+            }
+            return umin(umin(a[0] ^ a[1], a[1] ^ a[2]), a[2] ^ a[3]) != 0u;
+        }
+        // the four smallest of {a[0..3]} U {tv[0..3]}: min(a[i], tv[3 - i]) is bitonic; the discarded maxima hold the fifth
+        uint32_t fifth = INF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool sw = tv[3 - i] < a[i];
+            fifth = umin(fifth, sw ? a[i] : tv[3 - i]);
+            wv[i] = sw ? tv[3 - i] : a[i];
+            wi[i] = sw ? tp[3 - i] : ai[i];
+        }
+        ce(wv[0], wi[0], wv[2], wi[2]);
+        ce(wv[1], wi[1], wv[3], wi[3]);
+        ce(wv[0], wi[0], wv[1], wi[1]);
+        ce(wv[2], wi[2], wv[3], wi[3]);
+        // (blocks of 8 and more: the five smallest are all real values)
+        return umin(umin(wv[0] ^ wv[1], wv[1] ^ wv[2]), umin(wv[2] ^ wv[3], wv[3] ^ fifth)) != 0u;
     }
     // n = block length, cnt = 2 or 4 (wave uniform); wv / wi: values and original indices at positions 0 .. cnt-1 afterwards
     __device__ __forceinline__ void finish(uint32_t n, uint32_t cnt, uint32_t (&wv)[4], uint32_t (&wi)[4])
@@ -434,151 +497,187 @@ struct WeakScan {
 // positive); the low 6 bits are replaced by (lane, candidate), so that min / max move the payload along and no two
 // keys are equal.  The order is exact unless two keys that matter agree in the upper 26 bits: those cases (and real
 // ties, whose order depends on the reference's swaps) go to the literal emulation below.
+// (One wave per SIMD issues one instruction of any kind every four cycles: the code below avoids lane-mask logic --
+//  v_cmp + s_and / s_or + v_cndmask -- wherever min / max / add-with-carry do the same.)
+__device__ __forceinline__ void cex(uint32_t& a, uint32_t& b)
+{
+    const uint32_t lo = umin(a, b), hi = umax(a, b);
+    a = lo;
+    b = hi;
+}
 template <int W>
 __device__ __forceinline__ void bitonic_clean(uint32_t (&k)[8])
 {
 #pragma unroll
     for (int d = W / 2; d >= 1; d >>= 1) {
 #pragma unroll
-        for (int i = 0; i < W; ++i) {
-            if (!(i & d)) {
-                const uint32_t lo = umin(k[i], k[i + d]), hi = umax(k[i], k[i + d]);
-                k[i] = lo;
-                k[i + d] = hi;
-            }
-        }
+        for (int i = 0; i < W; ++i)
+            if (!(i & d)) cex(k[i], k[i + d]);
     }
 }
-// own list k[0 .. 8) and the partner lane's, both ascending -> the 8 smallest of both, ascending
-template <int CTRL>
+// own list k[0 .. M) and the partner lane's (same length), both ascending -> the min(2M, 8) smallest of both, ascending
+template <int M, int CTRL>
 __device__ __forceinline__ void merge_level(uint32_t (&k)[8])
 {
-    uint32_t b[8];
+    if constexpr (M == 8) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) b[i] = dpp_u32<CTRL>(k[i]);
+        for (int i = 0; i < 8; ++i) k[i] = umin(k[i], dpp_u32<CTRL>(k[7 - i]));  // (partner's list reversed: bitonic)
+        // (k[i] of the partner at index 7 - i: both lanes compute the same multiset, mirrored -- still bitonic)
+        bitonic_clean<8>(k);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) k[i] = umin(k[i], b[7 - i]);
-    bitonic_clean<8>(k);
+        for (int i = 0; i < M; ++i) k[2 * M - 1 - i] = dpp_u32<CTRL>(k[i]);
+        bitonic_clean<2 * M>(k);
+    }
+}
+// number of the eight keys of k[] that are smaller than x
+__device__ __forceinline__ uint32_t rank_in(const uint32_t (&k)[8], uint32_t x)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r += (k[i] < x) ? 1u : 0u;
+    return r;
 }
 
 // Literal emulation of the selection sort on the exact metrics: every candidate carries its CURRENT position in the
 // reference's array (pl * C + c at the start); round i takes the largest value at positions >= i (first position on
-// ties), the candidate sitting at position i moves to the winner's old position.  Rank i of every codeword goes to the
-// scratch (word i of the codeword's row): (lane << 3) | c.
-__device__ __forceinline__ void select_literal(const Path& p, const float (&cm)[8], uint32_t C, uint32_t np)
+// ties), the candidate sitting at position i moves to the winner's old position.  Returns the winners as keys in rank
+// order in k[] (the same form the merge network delivers: low 6 bits = (lane, candidate), upper bits = rank, so that
+// they are ascending and pairwise different).
+template <int C>
+__device__ __forceinline__ void select_literal(const Path& p, const float (&cm)[C], uint32_t np, uint32_t (&k)[8])
 {
     constexpr uint32_t INF = 0xFFFFFFFFu;
     const bool live = p.pl < p.P;
-    uint32_t pos[8], key[8];
+    uint32_t pos[C], key[C];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const bool v = live && (uint32_t)c < C;
-        pos[c] = v ? p.pl * C + (uint32_t)c : INF;
-        key[c] = v ? fbits(cm[c]) : INF;
+    for (int c = 0; c < C; ++c) {
+        pos[c] = live ? p.pl * (uint32_t)C + (uint32_t)c : INF;
+        key[c] = live ? fbits(cm[c]) : INF;
     }
-    uint32_t* row = p.lds + SCR_SEL + (uint32_t)(p.lane >> 3) * 8u;
-    for (uint32_t i = 0; i < np; ++i) {
-        uint32_t bk = INF;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) bk = umin(bk, pos[c] != INF ? key[c] : INF);
-        const uint32_t gk = cw_min(bk);
-        uint32_t bp = INF;
+    for (int i = 0; i < 8; ++i) {
+        k[i] = INF;
+        if ((uint32_t)i < np) {
+            uint32_t bk = INF;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) bp = umin(bp, (pos[c] != INF && key[c] == gk) ? pos[c] : INF);
-        const uint32_t gp = cw_min(bp);
-        uint32_t mine = INF;
+            for (int c = 0; c < C; ++c) bk = umin(bk, pos[c] != INF ? key[c] : INF);
+            const uint32_t gk = cw_min(bk);
+            uint32_t bp = INF;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const bool win = pos[c] == gp;
-            mine = win ? (((uint32_t)p.q << 3) | (uint32_t)c) : mine;
-            const bool at_i = pos[c] == i;
-            pos[c] = win ? INF : (at_i ? gp : pos[c]);
+            for (int c = 0; c < C; ++c) bp = umin(bp, (pos[c] != INF && key[c] == gk) ? pos[c] : INF);
+            const uint32_t gp = cw_min(bp);
+            uint32_t mine = INF;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const bool win = pos[c] == gp;
+                mine = win ? (((uint32_t)i << 6) | ((uint32_t)p.q << 3) | (uint32_t)c) : mine;
+                const bool at_i = pos[c] == (uint32_t)i;
+                pos[c] = win ? INF : (at_i ? gp : pos[c]);
+            }
+            k[i] = cw_min(mine);
         }
-        if (mine != INF) row[i] = mine;
     }
 }
 
 // Chooses the np = min(L, P * C) best candidates of every codeword and re-seats the paths: on return this lane hosts
 // the path of rank p.pl (or none), taken from lane `src` (absolute), candidate `cand`; p.metric is the candidate's.
-// The candidates' exact metrics are in the scratch (row of the lane, C floats).
-__device__ __forceinline__ void select_fork(Path& p, uint32_t C, uint32_t& src, uint32_t& cand)
+// cm[]: this lane's candidate metrics, in an order whose keys ascend except where `fix` says otherwise (fix: SPC's
+// {c3, c4} pair and the two repetition candidates are put in order here).
+template <int C>
+__device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint32_t& src, uint32_t& cand, const Stamps& sm)
 {
     constexpr uint32_t INF = 0xFFFFFFFFu;
     const bool live = p.pl < p.P;
-    const uint32_t np = (p.P * C < p.L) ? p.P * C : p.L;
-    float cm[8];
+    const uint32_t np = (p.P * (uint32_t)C < p.L) ? p.P * (uint32_t)C : p.L;
+    // the candidates' exact metrics go to the scratch: the new host of a path reads the one it was given
     {
-        const float4* scm = reinterpret_cast<const float4*>(p.lds + SCR_CM + p.lane * 8);
-        const float4 a = scm[0], b = scm[1];
-        cm[0] = a.x; cm[1] = a.y; cm[2] = a.z; cm[3] = a.w;
-        cm[4] = b.x; cm[5] = b.y; cm[6] = b.z; cm[7] = b.w;
+        float* scm = reinterpret_cast<float*>(p.lds + SCR_CM + p.lane * 8);
+        if constexpr (C == 8) {
+            reinterpret_cast<float4*>(scm)[0] = make_float4(cm[0], cm[1], cm[2], cm[3]);
+            reinterpret_cast<float4*>(scm)[1] = make_float4(cm[4], cm[5], cm[6], cm[7]);
+        } else if constexpr (C == 4) {
+            reinterpret_cast<float4*>(scm)[0] = make_float4(cm[0], cm[1], cm[2], cm[3]);
+        } else {
+            reinterpret_cast<float2*>(scm)[0] = make_float2(cm[0], cm[1]);
+        }
     }
+    const uint32_t qc = live ? ((uint32_t)p.q << 3) : INF;  // (dead lanes: every key becomes INF)
     uint32_t k[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-        k[c] = ((uint32_t)c < C && live) ? ((fbits(cm[c]) & ~63u) | ((uint32_t)p.q << 3) | (uint32_t)c) : INF;
-    // local order: R1 m >= m-v0 >= m-v1 >= (m-v0)-v1; SPC c0 c1 c2 {c3, c4} c5 c6 c7; REP: one compare
-    {
-        const uint32_t lo01 = umin(k[0], k[1]), hi01 = umax(k[0], k[1]);
-        k[0] = C == 2 ? lo01 : k[0];
-        k[1] = C == 2 ? hi01 : k[1];
-        const uint32_t lo34 = umin(k[3], k[4]), hi34 = umax(k[3], k[4]);
-        k[3] = lo34;  // (C < 8: k[4] is INF already)
-        k[4] = hi34;
-    }
-    uint32_t own[8];
+    for (int c = 0; c < 8; ++c) k[c] = c < C ? ((fbits(cm[c < C ? c : 0]) & ~63u) | qc | (uint32_t)c) : INF;
+    if constexpr (C == 2) cex(k[0], k[1]);
+    if constexpr (C == 8) cex(k[3], k[4]);
+    uint32_t own[C];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) own[c] = k[c];
-    merge_level<0xB1>(k);
-    merge_level<0x4E>(k);
-    merge_level<0x141>(k);
-    // exactness check: neighbours among the np chosen, and nobody outside them at or below the last one
-    bool tie = false;
+    for (int c = 0; c < C; ++c) own[c] = k[c];
+    merge_level<C, 0xB1>(k);
+    merge_level<(2 * C < 8 ? 2 * C : 8), 0x4E>(k);
+    merge_level<(4 * C < 8 ? 4 * C : 8), 0x141>(k);
+    // exactness: neighbours among the np chosen differ above the payload bits, and nobody outside them is at or below
+    // the last one.  nme = number of this lane's candidates among the chosen.
+    uint32_t dmin = INF;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) tie = tie || ((uint32_t)(i + 1) < np && ((k[i] ^ k[i + 1]) < 64u));
+    for (int i = 0; i < 7; ++i) dmin = umin(dmin, ((uint32_t)(i + 1) < np) ? (k[i] ^ k[i + 1]) : INF);
     uint32_t kcut = k[0];
 #pragma unroll
     for (int i = 1; i < 8; ++i) kcut = ((uint32_t)i < np) ? k[i] : kcut;
-    uint32_t cnt = 0;
+    const uint32_t kc63 = kcut | 63u;  // (own <= kc63 <=> own >> 6 <= kcut >> 6; INF stays above every valid key)
+    uint32_t nme = 0;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) cnt += (own[c] != INF && (own[c] >> 6) <= (kcut >> 6)) ? 1u : 0u;
-    cnt = cw_add(cnt);
-    tie = tie || (cnt != np);
-    uint32_t sel[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sel[i] = k[i] & 63u;
+    for (int c = 0; c < C; ++c) nme += (own[c] <= kc63) ? 1u : 0u;
+    const bool tie = (dmin < 64u) || (cw_add(nme) != np);
     if (ballot64(tie) != 0) {  // (wave uniform; rare on real-valued input)
-        select_literal(p, cm, C, np);
-        const uint32_t* row = p.lds + SCR_SEL + (uint32_t)(p.lane >> 3) * 8u;
+        uint32_t ex[8];
+        select_literal<C>(p, cm, np, ex);
+        nme = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const uint32_t e = row[i];
-            sel[i] = (tie && (uint32_t)i < np) ? (e & 63u) : sel[i];  // (tie is the same in all lanes of a codeword)
+            k[i] = ex[i];
+            nme += ((uint32_t)i < np && ((ex[i] >> 3) & 7u) == (uint32_t)p.q) ? 1u : 0u;
         }
+        // own[] in rank order: the lane's winners first
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) own[c] = INF;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool mine = (uint32_t)i < np && ((ex[i] >> 3) & 7u) == (uint32_t)p.q;
+#pragma unroll
+            for (int c = 0; c < C; ++c) own[c] = (mine && cnt == (uint32_t)c) ? ex[i] : own[c];
+            cnt += mine ? 1u : 0u;
+        }
+        if (!live) nme = 0;
     }
-    // seats: the first chosen candidate of a source lane stays in that lane, the others take the free lanes in order
-    uint32_t used = 0;
+    sm.mark(2);
+    // Seats.  A lane whose path has candidates among the chosen keeps the best of them (own[0]); its further chosen
+    // candidates ("extras": own[1 .. nme)) go to the lanes whose path has none ("free": dead lanes included), matched in
+    // lane order through the scratch -- which lane hosts which path is invisible outside, only the rank (p.pl) matters.
+    const uint64_t freem = ballot64(nme == 0) >> p.g0;  // (bits 0 .. 7: the lanes of this codeword)
+    const uint32_t fidx = (uint32_t)__builtin_popcount((uint32_t)freem & ((1u << p.q) - 1u));  // my number among the free lanes
+    uint32_t mykey = nme ? own[0] : INF;
+    if (ballot64(nme > 1u) != 0) {  // (somebody forks)
+        const uint32_t ex = nme ? nme - 1u : 0u;
+        uint32_t sc = ex;  // inclusive prefix sum over the lanes of the codeword
+        const uint32_t t1 = dpp_u32<0x111>(sc);
+        sc += p.q >= 1 ? t1 : 0u;
+        const uint32_t t2 = dpp_u32<0x112>(sc);
+        sc += p.q >= 2 ? t2 : 0u;
+        const uint32_t t4 = dpp_u32<0x114>(sc);
+        sc += p.q >= 4 ? t4 : 0u;
+        uint32_t* tab = p.lds + SCR_SEL + (uint32_t)(p.lane >> 3) * 8u;
+        const uint32_t base = sc - ex;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) used |= ((uint32_t)i < np) ? (1u << (sel[i] >> 3)) : 0u;
-    const bool in_used = ((used >> p.q) & 1u) != 0;
-    const uint32_t fidx = (uint32_t)__builtin_popcount(~used & ((1u << p.q) - 1u) & 0xFFu);  // my number among the free lanes
-    uint32_t seen = 0, extra = 0, myj = INF;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t sq = sel[i] >> 3, bit = 1u << sq;
-        const bool valid = (uint32_t)i < np;
-        const bool first = !(seen & bit);
-        const bool take = valid && (first ? (in_used && sq == (uint32_t)p.q) : (!in_used && extra == fidx));
-        myj = take ? (uint32_t)i : myj;
-        extra += (valid && !first) ? 1u : 0u;
-        seen |= valid ? bit : 0u;
+        for (int e = 1; e < C; ++e)
+            if ((uint32_t)e < nme) tab[base + (uint32_t)e - 1u] = own[e];
+        const uint32_t got = tab[fidx < 8u ? fidx : 0u];
+        const uint32_t nextra = np - (8u - (uint32_t)__builtin_popcount((uint32_t)freem & 0xFFu));
+        mykey = (nme == 0 && fidx < nextra) ? got : mykey;
     }
-    uint32_t mysel = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) mysel = (myj == (uint32_t)i) ? sel[i] : mysel;
-    const bool seated = myj != INF;
-    src = seated ? ((uint32_t)p.g0 | (mysel >> 3)) : (uint32_t)p.lane;
-    cand = mysel & 7u;
+    const bool seated = mykey != INF;
+    const uint32_t myj = rank_in(k, mykey);
+    src = seated ? ((uint32_t)p.g0 | ((mykey >> 3) & 7u)) : (uint32_t)p.lane;
+    cand = mykey & 7u;
     // the path's state: metric from the scratch, slot word from the source lane
     const float nm = reinterpret_cast<const float*>(p.lds + SCR_CM)[src * 8 + cand];
     const uint32_t nslot = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)p.slot);
@@ -700,9 +799,9 @@ __device__ __forceinline__ void leaf_r0(Path& p, uint32_t side)
     put_bits<T>(p, side, w);
 }
 
-// RepetitionDecoder::decode scl_avx_float.cpp:428-481 (blocks of 2 and 4): the two candidate metrics -> scratch
+// RepetitionDecoder::decode scl_avx_float.cpp:428-481 (blocks of 2 and 4)
 template <int T>
-__device__ __forceinline__ void leaf_rep(Path& p)
+__device__ __forceinline__ void leaf_rep(Path& p, uint32_t side, const Stamps& sm)
 {
     constexpr int n = 1 << T;
     float z[n], o[n];
@@ -712,9 +811,15 @@ __device__ __forceinline__ void leaf_rep(Path& p)
         z[i] = min0(x);
         o[i] = max0(x);
     });
-    float* scm = reinterpret_cast<float*>(p.lds + SCR_CM + p.lane * 8);
-    scm[0] = p.metric + lanesum_regs<n>(z);
-    scm[1] = p.metric - lanesum_regs<n>(o);
+    float cm[2];
+    cm[0] = p.metric + lanesum_regs<n>(z);
+    cm[1] = p.metric - lanesum_regs<n>(o);
+    sm.mark(1);
+    uint32_t src, cand;
+    select_fork<2>(p, cm, src, cand, sm);
+    sm.mark(3);
+    const uint32_t w[1] = { cand ? ((1u << n) - 1u) : 0u };
+    put_bits<T>(p, side, w);
 }
 
 // RateOneDecoder::decode :353-413 and SpcDecoder::decode :498-621, first half: hard decisions and the weak-LLR scan of
@@ -765,88 +870,95 @@ __device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
     }
 }
 
-// Second half of the forking leaves, one instance for all of them.  kind: 1 RateOne, 2 SPC, 3 repetition; T = log2 of
-// the block length; ws: the scan of this lane's path (kinds 1, 2).
-__device__ __forceinline__ void fork_tail(Path& p, uint32_t kind, uint32_t T, uint32_t side, WeakScan& ws)
+// Second half of the forking leaves.  SPC: SpcDecoder (8 candidates), else RateOne (4); T = log2 of the block length;
+// ws: the scan of this lane's path.
+template <bool SPC>
+__device__ __forceinline__ void fork_tail(Path& p, uint32_t T, uint32_t side, WeakScan& ws, const Stamps& sm)
 {
     const uint32_t n = 1u << T;
-    uint32_t* rec = p.lds + SCR_FORK + p.lane * 8;
-    if (kind != 3u) {
-        uint32_t wv[4], wi[4];
-        ws.finish(n, kind == 2u ? 4u : 2u, wv, wi);
-        const float m = p.metric;
-        float cm[8];
-        uint32_t par = 0;
-        if (kind == 2u) {
-            par = (uint32_t)__builtin_popcount(ws.sg[0] ^ ws.sg[1] ^ ws.sg[2] ^ ws.sg[3]) & 1u;
-            const float v0 = bitsf(wv[0]), v1 = bitsf(wv[1]), v2 = bitsf(wv[2]), v3 = bitsf(wv[3]);
-            const float t = m - v0;        // m' - pinv * v0 (par: m' = m - v0, pinv = 0; else m' = m, pinv = 1)
-            const float mp = par ? t : m;  // m'
-            cm[0] = mp;
-            cm[1] = t - v1;
-            cm[2] = t - v2;
-            cm[3] = t - v3;
-            cm[4] = (mp - v1) - v2;
-            cm[5] = (mp - v1) - v3;
-            cm[6] = (mp - v2) - v3;
-            cm[7] = ((t - v1) - v2) - v3;
-        } else {
-            const float v0 = bitsf(wv[0]), v1 = bitsf(wv[1]);
-            cm[0] = m;
-            cm[1] = m - v0;
-            cm[2] = m - v1;
-            cm[3] = (m - v0) - v1;
-            cm[4] = cm[5] = cm[6] = cm[7] = 0.0f;
-        }
-        float4* scm = reinterpret_cast<float4*>(p.lds + SCR_CM + p.lane * 8);
-        scm[0] = make_float4(cm[0], cm[1], cm[2], cm[3]);
-        scm[1] = make_float4(cm[4], cm[5], cm[6], cm[7]);
-        // fork record of this lane's path: the new hosts of its children read it
-        rec[0] = ws.sg[0];
-        rec[1] = ws.sg[1];
-        rec[2] = ws.sg[2];
-        rec[3] = ws.sg[3];
-        rec[4] = (wi[0] & 0xFFu) | ((wi[1] & 0xFFu) << 8) | ((wi[2] & 0xFFu) << 16) | ((wi[3] & 0xFFu) << 24);
-        rec[5] = par;
-    }
-    uint32_t src, cand;
-    select_fork(p, kind == 2u ? 8u : (kind == 1u ? 4u : 2u), src, cand);
-    uint32_t w[4];
-    if (kind == 3u) {
-        w[0] = cand ? ((1u << n) - 1u) : 0u;  // (n <= 4)
-        w[1] = w[2] = w[3] = 0;
+    uint32_t wv[4], wi[4];
+    if (ballot64(!ws.finish_fast(wv, wi, T)) != 0) ws.finish(n, SPC ? 4u : 2u, wv, wi);  // (equal magnitudes somewhere in the wave)
+    const float m = p.metric;
+    constexpr int C = SPC ? 8 : 4;
+    float cm[C];
+    uint32_t par = 0;
+    if constexpr (SPC) {
+        par = (uint32_t)__builtin_popcount(ws.sg[0] ^ ws.sg[1] ^ ws.sg[2] ^ ws.sg[3]) & 1u;
+        const float v0 = bitsf(wv[0]), v1 = bitsf(wv[1]), v2 = bitsf(wv[2]), v3 = bitsf(wv[3]);
+        const float t = m - v0;        // m' - pinv * v0 (par: m' = m - v0, pinv = 0; else m' = m, pinv = 1)
+        const float mp = par ? t : m;  // m'
+        cm[0] = mp;
+        cm[1] = t - v1;
+        cm[2] = t - v2;
+        cm[3] = t - v3;
+        cm[4] = (mp - v1) - v2;
+        cm[5] = (mp - v1) - v3;
+        cm[6] = (mp - v2) - v3;
+        cm[7] = ((t - v1) - v2) - v3;
     } else {
-        const uint32_t* sr = p.lds + SCR_FORK + src * 8;
-        const uint32_t spk = sr[4], spar = sr[5];
-        // which of the weak positions the candidate flips (RateOne: 1 -> ix0, 2 -> ix1, 3 -> both; SPC :541-613)
-        uint32_t fl[4];
-        if (kind == 2u) {
-            fl[0] = ((spar ? 0x71u : 0x8Eu) >> cand) & 1u;
-            fl[1] = (0xB2u >> cand) & 1u;
-            fl[2] = (0xD4u >> cand) & 1u;
-            fl[3] = (0xE8u >> cand) & 1u;
-        } else {
-            fl[0] = cand & 1u;
-            fl[1] = (cand >> 1) & 1u;
-            fl[2] = fl[3] = 0;
+        const float v0 = bitsf(wv[0]), v1 = bitsf(wv[1]);
+        cm[0] = m;
+        cm[1] = m - v0;
+        cm[2] = m - v1;
+        cm[3] = (m - v0) - v1;
+    }
+    // fork record of this lane's path: the new hosts of its children read it
+    uint4* rec = reinterpret_cast<uint4*>(p.lds + SCR_FORK + p.lane * 8);
+    const uint32_t packed = (wi[0] & 0xFFu) | ((wi[1] & 0xFFu) << 8) | ((wi[2] & 0xFFu) << 16) | ((wi[3] & 0xFFu) << 24);
+    rec[0] = make_uint4(ws.sg[0], packed, par, ws.sg[1]);
+    if (T == 7u) rec[1] = make_uint4(ws.sg[2], ws.sg[3], 0u, 0u);
+    sm.mark(1);
+    uint32_t src, cand;
+    select_fork<C>(p, cm, src, cand, sm);
+    sm.mark(3);
+    const uint4* sr = reinterpret_cast<const uint4*>(p.lds + SCR_FORK + src * 8);
+    const uint4 s0 = sr[0];
+    const uint32_t spk = s0.y, spar = s0.z;
+    // which of the weak positions the candidate flips (RateOne: 1 -> ix0, 2 -> ix1, 3 -> both; SPC :541-613)
+    uint32_t fl[4];
+    if constexpr (SPC) {
+        fl[0] = ((spar ? 0x71u : 0x8Eu) >> cand) & 1u;
+        fl[1] = (0xB2u >> cand) & 1u;
+        fl[2] = (0xD4u >> cand) & 1u;
+        fl[3] = (0xE8u >> cand) & 1u;
+    } else {
+        fl[0] = cand & 1u;
+        fl[1] = (cand >> 1) & 1u;
+        fl[2] = fl[3] = 0;
+    }
+    constexpr int NF = SPC ? 4 : 2;
+    if (T <= 5u) {  // one word
+        uint32_t w0 = s0.x;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) w0 ^= fl[k] << ((spk >> (8 * k)) & 31u);
+        const uint32_t o[1] = { w0 };
+        switch (T) {
+        case 5: put_bits<5>(p, side, o); break;
+        case 4: put_bits<4>(p, side, o); break;
+        case 3: put_bits<3>(p, side, o); break;
+        case 2: put_bits<2>(p, side, o); break;
+        default: put_bits<1>(p, side, o); break;
+        }
+    } else {
+        uint32_t w[4] = { s0.x, s0.w, 0u, 0u };
+        if (T == 7u) {
+            const uint4 s1 = sr[1];
+            w[2] = s1.x;
+            w[3] = s1.y;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = sr[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NF; ++k) {
             const uint32_t ix = (spk >> (8 * k)) & 0xFFu;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] ^= (fl[k] && (ix >> 5) == (uint32_t)i) ? (1u << (ix & 31u)) : 0u;
+            for (int i = 0; i < 4; ++i) w[i] ^= ((ix >> 5) == (uint32_t)i) ? (fl[k] << (ix & 31u)) : 0u;
         }
-    }
-    switch (T) {
-    case 7: { const uint32_t o[4] = { w[0], w[1], w[2], w[3] }; put_bits<7>(p, side, o); break; }
-    case 6: { const uint32_t o[2] = { w[0], w[1] }; put_bits<6>(p, side, o); break; }
-    case 5: { const uint32_t o[1] = { w[0] }; put_bits<5>(p, side, o); break; }
-    case 4: { const uint32_t o[1] = { w[0] }; put_bits<4>(p, side, o); break; }
-    case 3: { const uint32_t o[1] = { w[0] }; put_bits<3>(p, side, o); break; }
-    case 2: { const uint32_t o[1] = { w[0] }; put_bits<2>(p, side, o); break; }
-    default: { const uint32_t o[1] = { w[0] }; put_bits<1>(p, side, o); break; }
+        if (T == 7u) {
+            const uint32_t o[4] = { w[0], w[1], w[2], w[3] };
+            put_bits<7>(p, side, o);
+        } else {
+            const uint32_t o[2] = { w[0], w[1] };
+            put_bits<6>(p, side, o);
+        }
     }
 }
 
@@ -894,78 +1006,232 @@ __device__ __forceinline__ void op_combine(Path& p, uint32_t side)
 // ---- the top of the tree -------------------------------------------------------------------------------------------------
 // LN_VT: the stage-8 block of this path from the channel row (stage 9 = f / g of the row is never stored), optionally
 // with the F of stage 8 on the values in registers.  Element e of stage 8 needs the row at e, e + 256, e + 512, e + 768.
-__device__ __forceinline__ void op_vt(Path& p, uint32_t off, const float* chan)
+// The registers of stages 1 .. 6 are dead while the top of the tree is being worked on: two sets of eight 16-byte
+// row chunks live there (v[128..159], v[160..191]); one step = chunks j (-> stage-8 chunk j) and j + 32 (-> chunk j + 32),
+// the loads of step j + 1 are issued before step j is computed.
+constexpr int VT_SET0 = 128, VT_SET1 = 160, VT_SET2 = 192, VT_SET3 = 224;  // (v254 / v255 are free as well)
+// set layout: +0 row[e], +4 row[e+256], +8 row[e+512], +12 row[e+768], +16 row[e+128], +20 row[e+384], +24 row[e+640], +28 row[e+896]
+template <int SET>
+__device__ __forceinline__ void vt_load(const float* rowp)
 {
-    const bool r9 = (off & 1u) != 0, isg = (off & 2u) != 0, f8 = (off & 4u) != 0;
-    if (r9 && !isg) p.set_field(10);  // the G of the root directly follows its left child: the bits are this lane's own
+    asm volatile(
+        "global_load_dwordx4 v[%[r]:%[r]+3], %[a], off\n\t"
+        "global_load_dwordx4 v[%[r]+4:%[r]+7], %[a], off offset:1024\n\t"
+        "global_load_dwordx4 v[%[r]+8:%[r]+11], %[a], off offset:2048\n\t"
+        "global_load_dwordx4 v[%[r]+12:%[r]+15], %[a], off offset:3072\n\t"
+        "global_load_dwordx4 v[%[r]+16:%[r]+19], %[a], off offset:512\n\t"
+        "global_load_dwordx4 v[%[r]+20:%[r]+23], %[a], off offset:1536\n\t"
+        "global_load_dwordx4 v[%[r]+24:%[r]+27], %[a], off offset:2560\n\t"
+        "global_load_dwordx4 v[%[r]+28:%[r]+31], %[a], off offset:3584"
+        :
+        : [r] "n"(SET), [a] "v"(rowp)
+        : "memory");
+}
+// one step on set SET.  wa..wd: the root's left-child bits for the four stage-9 chunks, ue / uf: the stage-9 node's
+// left-child bits for the two stage-8 chunks -- each word shifted so that the chunk's four bits are bits 0 .. 3.
+template <int SET, bool R9, bool ISG, bool F8>
+__device__ __forceinline__ void vt_step(uint32_t wa, uint32_t wb, uint32_t wc, uint32_t wd, uint32_t ue, uint32_t uf, uint32_t absmask,
+                                        uint32_t signmask, uint32_t s8off, const uint32_t* s8base, uint32_t s7addr)
+{
+    uint32_t t0, t1, t2, t3;
+#define LN_VG(D_, B_, W_)                                          \
+    "v_lshlrev_b32 %[t0], 31, " W_ "\n\t"                         \
+    "v_lshlrev_b32 %[t1], 30, " W_ "\n\t"                         \
+    "v_lshlrev_b32 %[t2], 29, " W_ "\n\t"                         \
+    "v_lshlrev_b32 %[t3], 28, " W_ "\n\t"                         \
+    "v_and_or_b32 %[t0], %[t0], %[sm], 1.0\n\t"                   \
+    "v_and_or_b32 %[t1], %[t1], %[sm], 1.0\n\t"                   \
+    "v_and_or_b32 %[t2], %[t2], %[sm], 1.0\n\t"                   \
+    "v_and_or_b32 %[t3], %[t3], %[sm], 1.0\n\t"                   \
+    "v_fma_f32 v[" D_ "], v[" D_ "], %[t0], v[" B_ "]\n\t"        \
+    "v_fma_f32 v[" D_ "+1], v[" D_ "+1], %[t1], v[" B_ "+1]\n\t"  \
+    "v_fma_f32 v[" D_ "+2], v[" D_ "+2], %[t2], v[" B_ "+2]\n\t"  \
+    "v_fma_f32 v[" D_ "+3], v[" D_ "+3], %[t3], v[" B_ "+3]\n\t"
+    // stage 9 (in place): a -> +0, b -> +4, c -> +16, d -> +20
+    if constexpr (R9) {
+        asm volatile("s_waitcnt vmcnt(24)\n\t" LN_VG("%[r]", "%[r]+8", "%[wa]") LN_VG("%[r]+4", "%[r]+12", "%[wb]")
+                     LN_VG("%[r]+16", "%[r]+24", "%[wc]") LN_VG("%[r]+20", "%[r]+28", "%[wd]")
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [r] "n"(SET), [wa] "v"(wa), [wb] "v"(wb), [wc] "v"(wc), [wd] "v"(wd), [sm] "s"(signmask)
+                     : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(24)\n\t" LN_F4T("%[r]", "%[r]", "%[r]+8") LN_F4T("%[r]+4", "%[r]+4", "%[r]+12")
+                     LN_F4T("%[r]+16", "%[r]+16", "%[r]+24") LN_F4T("%[r]+20", "%[r]+20", "%[r]+28")
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [r] "n"(SET), [am] "s"(absmask)
+                     : "memory");
+    }
+    // stage 8 (in place): x = op(a, b) -> +0, y = op(c, d) -> +16; stage 7: f(x, y) -> +4
+    if constexpr (ISG) {
+        asm volatile(LN_VG("%[r]", "%[r]+4", "%[ue]") LN_VG("%[r]+16", "%[r]+20", "%[uf]")
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [r] "n"(SET), [ue] "v"(ue), [uf] "v"(uf), [sm] "s"(signmask));
+    } else {
+        asm volatile(LN_F4T("%[r]", "%[r]", "%[r]+4") LN_F4T("%[r]+16", "%[r]+16", "%[r]+20")
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [r] "n"(SET), [am] "s"(absmask));
+    }
+    if constexpr (F8) {
+        asm volatile(LN_F4T("%[r]+4", "%[r]", "%[r]+16")
+                     "global_store_dwordx4 %[o], v[%[r]:%[r]+3], %[sb]\n\t"
+                     "global_store_dwordx4 %[o2], v[%[r]+16:%[r]+19], %[sb]\n\t"
+                     "ds_write_b128 %[la], v[%[r]+4:%[r]+7]"
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [r] "n"(SET), [am] "s"(absmask), [o] "v"(s8off), [o2] "v"(s8off + 32768u), [sb] "s"(s8base), [la] "v"(s7addr)
+                     : "memory");
+    } else {
+        asm volatile("s_nop 0\n\t"
+                     "global_store_dwordx4 %[o], v[%[r]:%[r]+3], %[sb]\n\t"
+                     "global_store_dwordx4 %[o2], v[%[r]+16:%[r]+19], %[sb]"
+                     :
+                     : [r] "n"(SET), [o] "v"(s8off), [o2] "v"(s8off + 32768u), [sb] "s"(s8base)
+                     : "memory");
+    }
+#undef LN_VG
+}
+// six words of partial sums for the eight steps of one group (jo): asm loads, so that the counted waits of the steps cover them
+template <bool R9, bool ISG>
+__device__ __forceinline__ void vt_words(const uint32_t* bl9, const uint32_t* bl8, uint32_t jo, uint32_t& wa, uint32_t& wb, uint32_t& wc,
+                                         uint32_t& wd, uint32_t& ue, uint32_t& uf)
+{
+    wa = wb = wc = wd = ue = uf = 0;
+    if constexpr (R9) {
+        const uint32_t* pa = bl9 + jo * 64;
+        asm volatile("global_load_dword %0, %4, off\n\t"
+                     "global_load_dword %1, %4, off offset:2048\n\t"
+                     "global_load_dword %2, %4, off offset:1024\n\t"
+                     "global_load_dword %3, %4, off offset:3072"
+                     : "=&v"(wa), "=&v"(wb), "=&v"(wc), "=&v"(wd)
+                     : "v"(pa)
+                     : "memory");
+    }
+    if constexpr (ISG) {
+        const uint32_t* pe = bl8 + jo * 64;
+        asm volatile("global_load_dword %0, %2, off\n\t"
+                     "global_load_dword %1, %2, off offset:1024"
+                     : "=&v"(ue), "=&v"(uf)
+                     : "v"(pe)
+                     : "memory");
+    }
+}
+template <bool R9, bool ISG, bool F8>
+__device__ __forceinline__ void op_vt_t(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
+{
+    if (R9 && !ISG) p.set_field(10);  // the G of the root directly follows its left child: the bits are this lane's own
     const uint32_t* bl9 = p.arena + AR_BL9 + p.owner(10);  // the root's left-child bits: with the slot holder
     const uint32_t* bl8 = p.arena + AR_BL8 + p.lane;       // own (the G follows its left child directly)
-    float4* s8 = reinterpret_cast<float4*>(p.arena + AR_S8) + p.lane;
-    float4* s7 = reinterpret_cast<float4*>(p.lds + LDS_S7) + p.lane;
-    for (uint32_t jo = 0; jo < 4; ++jo) {
-        uint32_t wa = 0, wb = 0, wc = 0, wd = 0, ue = 0, uf = 0;
-        if (r9) {
-            wa = bl9[jo * 64];
-            wb = bl9[(8 + jo) * 64];
-            wc = bl9[(4 + jo) * 64];
-            wd = bl9[(12 + jo) * 64];
-        }
-        if (isg) {
-            ue = bl8[jo * 64];
-            uf = bl8[(4 + jo) * 64];
-        }
-#pragma unroll 2
-        for (uint32_t ji = 0; ji < 8; ++ji) {
-            const uint32_t j = jo * 8 + ji, sh = 4 * ji, e0 = 4 * j;
-            const float4 c0 = ldg4(chan + e0), c1 = ldg4(chan + e0 + 256), c2 = ldg4(chan + e0 + 512), c3 = ldg4(chan + e0 + 768);
-            const float4 d0 = ldg4(chan + e0 + 128), d1 = ldg4(chan + e0 + 384), d2 = ldg4(chan + e0 + 640), d3 = ldg4(chan + e0 + 896);
-            float4 a, b, c, d;
-            if (r9) {
-                a = g4(c0, c2, (wa >> sh) & 15u);
-                b = g4(c1, c3, (wb >> sh) & 15u);
-                c = g4(d0, d2, (wc >> sh) & 15u);
-                d = g4(d1, d3, (wd >> sh) & 15u);
-            } else {
-                a = f4(c0, c2);
-                b = f4(c1, c3);
-                c = f4(d0, d2);
-                d = f4(d1, d3);
-            }
-            float4 x, y;
-            if (isg) {
-                x = g4(a, b, (ue >> sh) & 15u);
-                y = g4(c, d, (uf >> sh) & 15u);
-            } else {
-                x = f4(a, b);
-                y = f4(c, d);
-            }
-            s8[j * 64] = x;
-            s8[(j + 32) * 64] = y;
-            if (f8) s7[j * 64] = f4(x, y);
-        }
-    }
-    if (isg) p.set_field(9);
-    p.set_field(8);
-    if (f8) p.set_field(7);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// stage 8 (arena column) -> stage 7 (LDS column): kind 0 = F, 1 = G (column of the slot owner), 2 = a + b
-__device__ __forceinline__ void op_fg8(Path& p, uint32_t kind)
-{
-    const uint32_t col = kind == 1u ? p.owner(8) : (uint32_t)p.lane;
-    const float4* s8 = reinterpret_cast<const float4*>(p.arena + AR_S8) + col;
-    float4* s7 = reinterpret_cast<float4*>(p.lds + LDS_S7) + p.lane;
-    const uint32_t w0 = rdu<RBL7>(), w1 = rdu<RBL7 + 1>(), w2 = rdu<RBL7 + 2>(), w3 = rdu<RBL7 + 3>();
+    const uint32_t* s8base = p.arena + AR_S8;
+    uint32_t s8off = (uint32_t)p.lane * 16u;               // byte offset of chunk j of this lane's column (+ 32 KB: chunk j + 32)
+    uint32_t s7addr = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.lane * 16u;
+    const float* rowp = chan;
+    const float* const rowend = chan + 4 * 31;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing older in flight: the counted waits below see only this op's accesses)
+    uint32_t wa, wb, wc, wd, ue, uf;
+    vt_words<R9, ISG>(bl9, bl8, 0, wa, wb, wc, wd, ue, uf);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wa), "+v"(wb), "+v"(wc), "+v"(wd), "+v"(ue), "+v"(uf)::"memory");
+    vt_load<VT_SET0>(rowp);
+    vt_load<VT_SET1>(rowp + 4);
+    vt_load<VT_SET2>(rowp + 8);
+    rowp += 12;
 #pragma unroll 1
     for (uint32_t jo = 0; jo < 4; ++jo) {
-        const uint32_t w = kind != 1u ? 0u : (jo == 0 ? w0 : (jo == 1 ? w1 : (jo == 2 ? w2 : w3)));
-#pragma unroll 2
-        for (uint32_t ji = 0; ji < 8; ++ji) {
-            const uint32_t j = jo * 8 + ji;
-            const float4 a = s8[j * 64], b = s8[(j + 32) * 64];
-            s7[j * 64] = kind == 0u ? f4(a, b) : g4(a, b, (w >> (4 * ji)) & 15u);  // (a + b = g with zero bits)
+        // the words of the next group are requested now and are long there when it starts (every step waits for
+        // everything older than its own row chunks)
+        uint32_t na, nb, nc, nd, ne, nf;
+        vt_words<R9, ISG>(bl9, bl8, jo < 3u ? jo + 1u : 3u, na, nb, nc, nd, ne, nf);
+#pragma unroll 1
+        for (uint32_t ji = 0; ji < 8; ji += 4) {
+            vt_load<VT_SET3>(rowp < rowend ? rowp : rowend);
+            vt_step<VT_SET0, R9, ISG, F8>(wa, wb, wc, wd, ue, uf, absmask, signmask, s8off, s8base, s7addr);
+            vt_load<VT_SET0>(rowp + 4 < rowend ? rowp + 4 : rowend);
+            vt_step<VT_SET1, R9, ISG, F8>(wa >> 4, wb >> 4, wc >> 4, wd >> 4, ue >> 4, uf >> 4, absmask, signmask, s8off + 1024u, s8base,
+                                          s7addr + 1024u);
+            vt_load<VT_SET1>(rowp + 8 < rowend ? rowp + 8 : rowend);
+            vt_step<VT_SET2, R9, ISG, F8>(wa >> 8, wb >> 8, wc >> 8, wd >> 8, ue >> 8, uf >> 8, absmask, signmask, s8off + 2048u, s8base,
+                                          s7addr + 2048u);
+            vt_load<VT_SET2>(rowp + 12 < rowend ? rowp + 12 : rowend);
+            vt_step<VT_SET3, R9, ISG, F8>(wa >> 12, wb >> 12, wc >> 12, wd >> 12, ue >> 12, uf >> 12, absmask, signmask, s8off + 3072u,
+                                          s8base, s7addr + 3072u);
+            wa >>= 16; wb >>= 16; wc >>= 16; wd >>= 16; ue >>= 16; uf >>= 16;
+            rowp += 16;
+            s8off += 4096u;
+            s7addr += 4096u;
         }
+        asm volatile("" : "+v"(na), "+v"(nb), "+v"(nc), "+v"(nd), "+v"(ne), "+v"(nf));  // (nothing derived from them may be computed earlier)
+        wa = na; wb = nb; wc = nc; wd = nd; ue = ne; uf = nf;
+    }
+    if (ISG) p.set_field(9);
+    p.set_field(8);
+    if (F8) p.set_field(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void op_vt(Path& p, uint32_t off, const float* chan, uint32_t absmask, uint32_t signmask)
+{
+    // (bit 2 of off -- "the F of stage 8 follows" -- needs no variant of its own: stage 7 is dead whenever it is clear, so the
+    //  F is computed and stored regardless)
+    switch (off & 3u) {
+    case 0: op_vt_t<false, false, true>(p, chan, absmask, signmask); break;
+    case 1: op_vt_t<true, false, true>(p, chan, absmask, signmask); break;
+    case 2: op_vt_t<false, true, true>(p, chan, absmask, signmask); break;
+    default: op_vt_t<true, true, true>(p, chan, absmask, signmask); break;
+    }
+}
+
+// stage 8 (arena column) -> stage 7 (LDS column): kind 0 = F, 1 = G (column of the slot owner), 2 = a + b (= G with zero
+// bits).  Eight steps per batch: their sixteen 16-byte loads go out together into v[128 .. 191] (dead stages), the steps
+// work on them in place as they arrive and store to the LDS.
+#define LN_LD2(c) "global_load_dwordx4 v[%[d]+4*" #c ":%[d]+4*" #c "+3], %[oa], %[sb]\n\t" \
+                  "global_load_dwordx4 v[%[t]+4*" #c ":%[t]+4*" #c "+3], %[ob], %[sb]\n\t" \
+                  "v_add_u32 %[oa], 0x400, %[oa]\n\t" "v_add_u32 %[ob], 0x400, %[ob]\n\t"
+#define LN_ST(c) "s_nop 0\n\tds_write_b128 %[la], v[%[d]+4*" #c ":%[d]+4*" #c "+3] offset:1024*" #c "\n\t"
+template <bool ISF>
+__device__ __forceinline__ void fg8_batch(uint32_t& oa, uint32_t& ob, const uint32_t* s8base, uint32_t la, uint32_t w, uint32_t absmask,
+                                          uint32_t signmask)
+{
+    uint32_t t0, t1, t2, t3;
+    if constexpr (ISF) {
+        asm volatile(LN_LD2(0) LN_LD2(1) LN_LD2(2) LN_LD2(3) LN_LD2(4) LN_LD2(5) LN_LD2(6) LN_LD2(7)
+                     "s_waitcnt vmcnt(14)\n\t" LN_F4T("%[d]", "%[d]", "%[t]") LN_ST(0)
+                     "s_waitcnt vmcnt(12)\n\t" LN_F4T("%[d]+4", "%[d]+4", "%[t]+4") LN_ST(1)
+                     "s_waitcnt vmcnt(10)\n\t" LN_F4T("%[d]+8", "%[d]+8", "%[t]+8") LN_ST(2)
+                     "s_waitcnt vmcnt(8)\n\t" LN_F4T("%[d]+12", "%[d]+12", "%[t]+12") LN_ST(3)
+                     "s_waitcnt vmcnt(6)\n\t" LN_F4T("%[d]+16", "%[d]+16", "%[t]+16") LN_ST(4)
+                     "s_waitcnt vmcnt(4)\n\t" LN_F4T("%[d]+20", "%[d]+20", "%[t]+20") LN_ST(5)
+                     "s_waitcnt vmcnt(2)\n\t" LN_F4T("%[d]+24", "%[d]+24", "%[t]+24") LN_ST(6)
+                     "s_waitcnt vmcnt(0)\n\t" LN_F4T("%[d]+28", "%[d]+28", "%[t]+28") LN_ST(7)
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [oa] "+v"(oa), [ob] "+v"(ob)
+                     : [d] "n"(128), [t] "n"(160), [sb] "s"(s8base), [la] "v"(la), [am] "s"(absmask)
+                     : "memory");
+    } else {
+        asm volatile(LN_LD2(0) LN_LD2(1) LN_LD2(2) LN_LD2(3) LN_LD2(4) LN_LD2(5) LN_LD2(6) LN_LD2(7)
+                     "s_waitcnt vmcnt(14)\n\t" LN_G4T("%[d]", "%[t]", 31, 30, 29, 28) LN_ST(0)
+                     "s_waitcnt vmcnt(12)\n\t" LN_G4T("%[d]+4", "%[t]+4", 27, 26, 25, 24) LN_ST(1)
+                     "s_waitcnt vmcnt(10)\n\t" LN_G4T("%[d]+8", "%[t]+8", 23, 22, 21, 20) LN_ST(2)
+                     "s_waitcnt vmcnt(8)\n\t" LN_G4T("%[d]+12", "%[t]+12", 19, 18, 17, 16) LN_ST(3)
+                     "s_waitcnt vmcnt(6)\n\t" LN_G4T("%[d]+16", "%[t]+16", 15, 14, 13, 12) LN_ST(4)
+                     "s_waitcnt vmcnt(4)\n\t" LN_G4T("%[d]+20", "%[t]+20", 11, 10, 9, 8) LN_ST(5)
+                     "s_waitcnt vmcnt(2)\n\t" LN_G4T("%[d]+24", "%[t]+24", 7, 6, 5, 4) LN_ST(6)
+                     "s_waitcnt vmcnt(0)\n\t" LN_G4T("%[d]+28", "%[t]+28", 3, 2, 1, 0) LN_ST(7)
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [oa] "+v"(oa), [ob] "+v"(ob)
+                     : [d] "n"(128), [t] "n"(160), [sb] "s"(s8base), [la] "v"(la), [w] "v"(w), [sm] "s"(signmask)
+                     : "memory");
+    }
+}
+#undef LN_LD2
+#undef LN_ST
+__device__ __forceinline__ void op_fg8(Path& p, uint32_t kind, uint32_t absmask, uint32_t signmask)
+{
+    const uint32_t col = kind == 1u ? p.owner(8) : (uint32_t)p.lane;
+    const uint32_t* s8base = p.arena + AR_S8;
+    uint32_t oa = col * 16u, ob = col * 16u + 32768u;  // byte offsets of chunk j and chunk j + 32 of the column
+    const uint32_t la = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.lane * 16u;
+    const uint32_t w0 = rdu<RBL7>(), w1 = rdu<RBL7 + 1>(), w2 = rdu<RBL7 + 2>(), w3 = rdu<RBL7 + 3>();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (uint32_t b = 0; b < 4; ++b) {
+        const uint32_t w = kind != 1u ? 0u : (b == 0 ? w0 : (b == 1 ? w1 : (b == 2 ? w2 : w3)));
+        if (kind == 0u) fg8_batch<true>(oa, ob, s8base, la + b * 8192u, w, absmask, signmask);
+        else fg8_batch<false>(oa, ob, s8base, la + b * 8192u, w, absmask, signmask);
     }
     if (kind != 0u) p.set_field(8);
     p.set_field(7);
@@ -1043,64 +1309,80 @@ void scl_lane_kernel(const DecodeParams P)
         p.slot = (uint32_t)p.q * 0x01249249u;  // every field = own lane
         uint32_t trace_n = 0;
 
+        uint64_t nraw = prog[0];
         for (uint32_t pc = 0;; ++pc) {
-            const uint64_t raw = prog[pc];
+            const uint64_t raw = nraw;
+            nraw = prog[pc + 1];  // (fetched one instruction ahead; the host appends a spare word behind OP_END)
             const uint32_t op = (uint32_t)raw & 0xFFu, st = ((uint32_t)raw >> 8) & 0xFFu, side = ((uint32_t)raw >> 16) & 0xFFu;
             const uint32_t off = (uint32_t)(raw >> 32);
             if (op == OP_END) break;
+            uint64_t t_start = 0;
+            if (DIAG && P.cycles && grp == 0) t_start = __builtin_amdgcn_s_memtime();
+            Stamps sm{ nullptr, t_start };
+            if (DIAG && P.cycles && grp == 0) sm.sub = P.cycles + P.prog_len + 4 * pc;
             bool is_leaf = false;
             uint32_t fkind = 0;  // forking leaf: 1 RateOne, 2 SPC, 3 repetition
             WeakScan ws;
             switch (op) {
-            case LN_VT: op_vt(p, off, chan); break;
-            case LN_F:
-                switch (st) {
-                case 8: op_fg8(p, 0); break;
-                case 7: op_fg7<0>(p, absmask, signmask); break;
-                case 6: op_fg_reg<0, 6>(p, absmask, signmask); break;
-                case 5: op_fg_reg<0, 5>(p, absmask, signmask); break;
-                case 4: op_fg_reg<0, 4>(p, absmask, signmask); break;
-                case 3: op_fg_reg<0, 3>(p, absmask, signmask); break;
-                default: op_fg_reg<0, 2>(p, absmask, signmask); break;
-                }
+            case LN_VT:
+                if (!(DIAG && (P.ablate & 1u))) op_vt(p, off, chan, absmask, signmask);
                 break;
-            case LN_G:
-                switch (st) {
-                case 8: op_fg8(p, 1); break;
-                case 7: op_fg7<1>(p, absmask, signmask); break;
-                case 6: op_fg_reg<1, 6>(p, absmask, signmask); break;
-                case 5: op_fg_reg<1, 5>(p, absmask, signmask); break;
-                case 4: op_fg_reg<1, 4>(p, absmask, signmask); break;
-                case 3: op_fg_reg<1, 3>(p, absmask, signmask); break;
-                default: op_fg_reg<1, 2>(p, absmask, signmask); break;
-                }
-                break;
-            case LN_G0:
-                switch (st) {
-                case 8: op_fg8(p, 2); break;
-                case 7: op_fg7<2>(p, absmask, signmask); break;
-                case 6: op_fg_reg<2, 6>(p, absmask, signmask); break;
-                case 5: op_fg_reg<2, 5>(p, absmask, signmask); break;
-                case 4: op_fg_reg<2, 4>(p, absmask, signmask); break;
-                case 3: op_fg_reg<2, 3>(p, absmask, signmask); break;
-                default: op_fg_reg<2, 2>(p, absmask, signmask); break;
-                }
-                break;
-            case LN_C:
-                switch (st) {
+            case LN_WALK: {
+                if (DIAG && (P.ablate & 2u)) break;
+                // everything between two leaves in one dispatch: COMBINEs up the right spine (stages c0 .. c1, the last one
+                // with this instruction's side, the others are right children), the G of the node reached, Fs down to the next leaf
+                const uint32_t c0 = off & 15u, c1 = (off >> 4) & 15u, gs = (off >> 8) & 15u, gk = (off >> 12) & 3u;
+                const uint32_t f1 = (off >> 16) & 15u, f0 = (off >> 20) & 15u;
+                switch (c0) {
+                case 2: op_combine<2>(p, c1 == 2 ? side : 1u); if (c1 == 2) break; [[fallthrough]];
+                case 3: op_combine<3>(p, c1 == 3 ? side : 1u); if (c1 == 3) break; [[fallthrough]];
+                case 4: op_combine<4>(p, c1 == 4 ? side : 1u); if (c1 == 4) break; [[fallthrough]];
+                case 5: op_combine<5>(p, c1 == 5 ? side : 1u); if (c1 == 5) break; [[fallthrough]];
+                case 6: op_combine<6>(p, c1 == 6 ? side : 1u); if (c1 == 6) break; [[fallthrough]];
+                case 7: op_combine<7>(p, c1 == 7 ? side : 1u); if (c1 == 7) break; [[fallthrough]];
+                case 8: op_combine<8>(p, c1 == 8 ? side : 1u); if (c1 == 8) break; [[fallthrough]];
                 case 9: op_combine<9>(p, side); break;
-                case 8: op_combine<8>(p, side); break;
-                case 7: op_combine<7>(p, side); break;
-                case 6: op_combine<6>(p, side); break;
-                case 5: op_combine<5>(p, side); break;
-                case 4: op_combine<4>(p, side); break;
-                case 3: op_combine<3>(p, side); break;
-                default: op_combine<2>(p, side); break;
+                default: break;
                 }
-                if (st >= 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (c1 >= 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sm.mark(1);
+                if (gk == 1u) {
+                    switch (gs) {
+                    case 8: op_fg8(p, 1, absmask, signmask); break;
+                    case 7: op_fg7<1>(p, absmask, signmask); break;
+                    case 6: op_fg_reg<1, 6>(p, absmask, signmask); break;
+                    case 5: op_fg_reg<1, 5>(p, absmask, signmask); break;
+                    case 4: op_fg_reg<1, 4>(p, absmask, signmask); break;
+                    case 3: op_fg_reg<1, 3>(p, absmask, signmask); break;
+                    default: op_fg_reg<1, 2>(p, absmask, signmask); break;
+                    }
+                } else if (gk == 2u) {
+                    switch (gs) {
+                    case 8: op_fg8(p, 2, absmask, signmask); break;
+                    case 7: op_fg7<2>(p, absmask, signmask); break;
+                    case 6: op_fg_reg<2, 6>(p, absmask, signmask); break;
+                    case 5: op_fg_reg<2, 5>(p, absmask, signmask); break;
+                    case 4: op_fg_reg<2, 4>(p, absmask, signmask); break;
+                    case 3: op_fg_reg<2, 3>(p, absmask, signmask); break;
+                    default: op_fg_reg<2, 2>(p, absmask, signmask); break;
+                    }
+                }
+                sm.mark(2);
+                switch (f1) {
+                case 8: op_fg8(p, 0, absmask, signmask); if (f0 == 8) break; [[fallthrough]];
+                case 7: op_fg7<0>(p, absmask, signmask); if (f0 == 7) break; [[fallthrough]];
+                case 6: op_fg_reg<0, 6>(p, absmask, signmask); if (f0 == 6) break; [[fallthrough]];
+                case 5: op_fg_reg<0, 5>(p, absmask, signmask); if (f0 == 5) break; [[fallthrough]];
+                case 4: op_fg_reg<0, 4>(p, absmask, signmask); if (f0 == 4) break; [[fallthrough]];
+                case 3: op_fg_reg<0, 3>(p, absmask, signmask); if (f0 == 3) break; [[fallthrough]];
+                case 2: op_fg_reg<0, 2>(p, absmask, signmask); break;
+                default: break;
+                }
                 break;
+            }
             case LN_R0:
                 is_leaf = true;
+                if (DIAG && (P.ablate & 32u)) break;
                 switch (st) {
                 case 8: leaf_r0<8>(p, side); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
                 case 7: leaf_r0<7>(p, side); break;
@@ -1114,13 +1396,14 @@ void scl_lane_kernel(const DecodeParams P)
                 break;
             case LN_REP:
                 is_leaf = true;
-                fkind = 3;
-                if (st == 2) leaf_rep<2>(p);
-                else leaf_rep<1>(p);
+                if (DIAG && (P.ablate & 16u)) break;
+                if (st == 2) leaf_rep<2>(p, side, sm);
+                else leaf_rep<1>(p, side, sm);
                 break;
             case LN_R1:
             case LN_SPC:
                 is_leaf = true;
+                if (DIAG && (P.ablate & 8u)) break;
                 fkind = op == LN_SPC ? 2u : 1u;
                 switch (st) {
                 case 7: leaf_scan<7>(p, ws); break;
@@ -1134,7 +1417,14 @@ void scl_lane_kernel(const DecodeParams P)
                 break;
             default: break;
             }
-            if (fkind) fork_tail(p, fkind, st, side, ws);
+            sm.mark(0);
+            if (DIAG && (P.ablate & 4u)) fkind = 0;
+            if (fkind == 2u) fork_tail<true>(p, st, side, ws, sm);
+            else if (fkind == 1u) fork_tail<false>(p, st, side, ws, sm);
+            if (DIAG && P.cycles && grp == 0) {
+                const uint64_t t_end = __builtin_amdgcn_s_memtime();
+                if (lane == 0) P.cycles[pc] = (uint32_t)(t_end - t_start);
+            }
             if (DIAG && P.trace && grp == 0 && is_leaf) {
                 if (trace_n < P.trace_cap && lane < 8) {
                     float* t = P.trace + (size_t)trace_n * (1 + P.L);
@@ -1146,6 +1436,7 @@ void scl_lane_kernel(const DecodeParams P)
             }
         }
 
+        if (DIAG && (P.ablate & 64u)) continue;
         // ---- SclAvxFloat::extractBestPath :711-750 -----------------------------------------------------------------
         // code word of this path: [left ^ right | right] of the root's children (16 + 16 words from the arena)
         uint32_t xw[32];
@@ -1177,43 +1468,61 @@ void scl_lane_kernel(const DecodeParams P)
                     if (!(i & hw)) xw[i] ^= xw[i + hw];
             }
         }
-        uint32_t* xl = lds + LDS_S7;  // (stage 7 is dead now) word w of lane l at [w * 64 + l]
+        // information bits of this path, packed like the output (bit t of the information word = bit 7 - t % 8 of byte
+        // t / 8): per 32 code bits a log-step bit compress with host-made move masks (program.cpp, deposit_table), the
+        // pieces strung together in a 64-bit shift register; finished words go to the LDS (stage 7 is dead now) at
+        // [word * 64 + lane], byte-reversed bits first.
+        uint32_t* il = lds + LDS_S7;
+        {
+            const uint32_t* ext = P.ext;
+            uint64_t acc = 0;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) xl[i * 64 + lane] = xw[i];
-        // detector verdict of every path (syndrome XOR over its set information bits)
+            for (int w = 0; w < 32; ++w) {
+                const uint32_t mask = ext[8 * w], base = ext[8 * w + 1];
+                uint32_t x = xw[w] & mask;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const uint32_t t = x & ext[8 * w + 2 + i];
+                    x = (x ^ t) | (t >> (1u << i));
+                }
+                acc |= (uint64_t)x << (base & 31u);
+                const uint32_t end = base + (uint32_t)__builtin_popcount(mask);
+                if ((end >> 5) != (base >> 5)) {  // (wave uniform) a word is complete
+                    il[(base >> 5) * 64 + lane] = __builtin_bswap32(__brev((uint32_t)acc));
+                    acc >>= 32;
+                }
+            }
+            if (P.K & 31u) il[(P.K >> 5) * 64 + lane] = __builtin_bswap32(__brev((uint32_t)acc));
+        }
+        // detector verdict of every path: XOR of the syndrome words of its output bytes
         const bool alive = p.pl < p.P;
         uint32_t syn = 0;
         if (P.det_on) {
+            const uint32_t nwords = (P.nb + 3u) >> 2;
 #pragma unroll 4
-            for (uint32_t t = 0; t < P.K; ++t) {
-                const uint32_t pos = P.lut[t], sy = P.syn[t];
-                const uint32_t w = xl[(pos >> 5) * 64 + lane];
-                syn ^= ((w >> (pos & 31u)) & 1u) ? sy : 0u;
+            for (uint32_t j = 0; j < nwords; ++j) {
+                const uint32_t word = il[j * 64 + lane];
+                const uint32_t* tb = P.syn_bytes + j * 1024u;
+                syn ^= tb[word & 255u];
+                if (4 * j + 1 < P.nb) syn ^= tb[256 + ((word >> 8) & 255u)];
+                if (4 * j + 2 < P.nb) syn ^= tb[512 + ((word >> 16) & 255u)];
+                if (4 * j + 3 < P.nb) syn ^= tb[768 + (word >> 24)];
             }
         }
         const uint32_t wpl = cw_min((alive && syn == 0) ? p.pl : 99u);  // first passing path in list order
         const uint32_t okflag = wpl != 99u ? 1u : 0u;
         const uint32_t want = okflag ? wpl : 0u;
-        const uint32_t wl = cw_min((alive && p.pl == want) ? (uint32_t)lane : 99u);  // its lane
-        // information bits of the winner: the 8 lanes of a codeword pack 8 bytes each
         if (live) {
-            uint8_t* orow = P.out + (size_t)row * P.nb;
-            const uint32_t* wx = xl + wl;
-            for (uint32_t b0 = (uint32_t)p.q * 8u; b0 < P.nb; b0 += 64u) {
-                for (uint32_t bb = 0; bb < 8 && b0 + bb < P.nb; ++bb) {
-                    uint32_t byte = 0;
-#pragma unroll
-                    for (uint32_t i = 0; i < 8; ++i) {
-                        const uint32_t t = (b0 + bb) * 8u + i;
-                        if (t < P.K) {
-                            const uint32_t pos = P.lut[t];
-                            byte |= ((wx[(pos >> 5) * 64] >> (pos & 31u)) & 1u) << (7u - i);
-                        }
-                    }
-                    orow[b0 + bb] = (uint8_t)byte;
+            if (alive && p.pl == want) {  // the winner writes its information word
+                uint8_t* orow = P.out + (size_t)row * P.nb;
+                if ((P.nb & 3u) == 0) {
+                    uint32_t* o32 = reinterpret_cast<uint32_t*>(orow);
+                    for (uint32_t j = 0; j < (P.nb >> 2); ++j) o32[j] = il[j * 64 + lane];
+                } else {
+                    for (uint32_t b = 0; b < P.nb; ++b) orow[b] = (uint8_t)(il[(b >> 2) * 64 + lane] >> (8u * (b & 3u)));
                 }
+                if (P.ok) P.ok[row] = (uint8_t)okflag;
             }
-            if (p.q == 0 && P.ok) P.ok[row] = (uint8_t)okflag;
             if (P.metrics) {
                 if ((uint32_t)p.q >= p.P && (uint32_t)p.q < P.L) P.metrics[(size_t)row * P.L + p.q] = 0.0f;
                 if (alive) P.metrics[(size_t)row * P.L + p.pl] = p.metric;

@@ -1,0 +1,44 @@
+"""Cycle stamps of one wave of the lane-per-path list kernel on an otherwise idle GPU (diagnostic build): cycles per
+program instruction, summed per (op, stage)."""
+import os, sys
+from collections import defaultdict
+_R = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
+sys.path[:0] = [os.path.join(_R, 'polar-codes_amd'), os.path.join(_R, 'tests')]
+os.environ.setdefault('PYPOLAR_AMD_LIB', os.path.join(_R, 'polar-codes_amd', 'lib', 'libpolar_amd_diag.so'))
+import golden_io as gio
+import pypolar_amd
+names = {73: "WALK", 64: 'VT', 65: 'F', 66: 'G', 67: 'G0', 68: 'C', 69: 'R0', 70: 'R1', 71: 'REP', 72: 'SPC', 0: 'END'}
+fx = gio.load_named(sys.argv[1] if len(sys.argv) > 1 else "cfg3_n1024_k512_l8_crc24_awgn.bin")
+d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, "float")
+d.setErrorDetection(fx.crc_size, fx.crc_type)
+os.environ['PCD_SUBPROFILE'] = '/tmp/lane_sub.txt'
+ops, st, cyc = d.scl_profile(fx.llr[3])
+agg = defaultdict(lambda: [0, 0])
+for o, s, c in zip(ops, st, cyc):
+    k = (names.get(int(o), str(int(o))), int(s))
+    agg[k][0] += 1
+    agg[k][1] += int(c)
+tot = sum(v[1] for v in agg.values())
+print("total cycles in ops", tot, "instructions", len(ops))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"{k[0]:4s} {k[1]:2d}  n={v[0]:3d}  cycles={v[1]:8d}  avg={v[1] / v[0]:8.0f}  {100.0 * v[1] / tot:5.1f}%")
+
+# sub-stamps: leaves: 0 = scan done, 1 = weak search + candidates, 2 = merge + tie check, 3 = seats + state; walk: 1 = combines, 2 = G
+sub = defaultdict(lambda: [0, 0, 0, 0, 0, 0])
+for line in open('/tmp/lane_sub.txt'):
+    o, s_, c, a, b, c2, d2 = (int(x) for x in line.split())
+    k = names.get(o, str(o))
+    if k == 'WALK':
+        seg = [a if False else 0, b, c2 - b, c - c2, 0]
+        seg = [b, c2 - b, c - c2, 0, 0]
+    else:
+        if b == 0:
+            seg = [c, 0, 0, 0, 0]
+        else:
+            seg = [a, b - a, c2 - b, d2 - c2, c - d2]
+    sub[k][5] += 1
+    for i in range(5):
+        sub[k][i] += seg[i]
+print("segments (cycles summed over the pass): leaves = scan | weak+cands | merge+tie | seats+state | bits ; WALK = combines | G | F")
+for k, v in sub.items():
+    print(f"{k:5s} n={v[5]:3d} ", " ".join(f"{x:8d}" for x in v[:5]))
