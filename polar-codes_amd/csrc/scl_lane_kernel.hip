@@ -1319,7 +1319,7 @@ void scl_lane_kernel(const DecodeParams P)
             uint64_t t_start = 0;
             if (DIAG && P.cycles && grp == 0) t_start = __builtin_amdgcn_s_memtime();
             Stamps sm{ nullptr, t_start };
-            if (DIAG && P.cycles && grp == 0) sm.sub = P.cycles + P.prog_len + 4 * pc;
+            if (DIAG && P.cycles && grp == 0 && (P.ablate & 256u)) sm.sub = P.cycles + P.prog_len + 4 * pc;  // (PCD_ABLATE=256: phase stamps)
             bool is_leaf = false;
             uint32_t fkind = 0;  // forking leaf: 1 RateOne, 2 SPC, 3 repetition
             WeakScan ws;
@@ -1333,50 +1333,63 @@ void scl_lane_kernel(const DecodeParams P)
                 // with this instruction's side, the others are right children), the G of the node reached, Fs down to the next leaf
                 const uint32_t c0 = off & 15u, c1 = (off >> 4) & 15u, gs = (off >> 8) & 15u, gk = (off >> 12) & 3u;
                 const uint32_t f1 = (off >> 16) & 15u, f0 = (off >> 20) & 15u;
-                switch (c0) {
-                case 2: op_combine<2>(p, c1 == 2 ? side : 1u); if (c1 == 2) break; [[fallthrough]];
-                case 3: op_combine<3>(p, c1 == 3 ? side : 1u); if (c1 == 3) break; [[fallthrough]];
-                case 4: op_combine<4>(p, c1 == 4 ? side : 1u); if (c1 == 4) break; [[fallthrough]];
-                case 5: op_combine<5>(p, c1 == 5 ? side : 1u); if (c1 == 5) break; [[fallthrough]];
-                case 6: op_combine<6>(p, c1 == 6 ? side : 1u); if (c1 == 6) break; [[fallthrough]];
-                case 7: op_combine<7>(p, c1 == 7 ? side : 1u); if (c1 == 7) break; [[fallthrough]];
-                case 8: op_combine<8>(p, c1 == 8 ? side : 1u); if (c1 == 8) break; [[fallthrough]];
-                case 9: op_combine<9>(p, side); break;
-                default: break;
-                }
-                if (c1 >= 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                sm.mark(1);
-                if (gk == 1u) {
-                    switch (gs) {
-                    case 8: op_fg8(p, 1, absmask, signmask); break;
-                    case 7: op_fg7<1>(p, absmask, signmask); break;
-                    case 6: op_fg_reg<1, 6>(p, absmask, signmask); break;
-                    case 5: op_fg_reg<1, 5>(p, absmask, signmask); break;
-                    case 4: op_fg_reg<1, 4>(p, absmask, signmask); break;
-                    case 3: op_fg_reg<1, 3>(p, absmask, signmask); break;
-                    default: op_fg_reg<1, 2>(p, absmask, signmask); break;
+                // (plain loops over the stages with a flat switch each: fall-through switches make the compiler thread
+                //  flag variables through a structured control flow graph -- dozens of scalar instructions per step)
+                if (c0) {
+#pragma unroll 1
+                    for (uint32_t t = c0; t <= c1; ++t) {
+                        const uint32_t sd = t == c1 ? side : 1u;
+                        switch (t) {
+                        case 2: op_combine<2>(p, sd); break;
+                        case 3: op_combine<3>(p, sd); break;
+                        case 4: op_combine<4>(p, sd); break;
+                        case 5: op_combine<5>(p, sd); break;
+                        case 6: op_combine<6>(p, sd); break;
+                        case 7: op_combine<7>(p, sd); break;
+                        case 8: op_combine<8>(p, sd); break;
+                        default: op_combine<9>(p, sd); break;
+                        }
                     }
-                } else if (gk == 2u) {
-                    switch (gs) {
-                    case 8: op_fg8(p, 2, absmask, signmask); break;
-                    case 7: op_fg7<2>(p, absmask, signmask); break;
-                    case 6: op_fg_reg<2, 6>(p, absmask, signmask); break;
-                    case 5: op_fg_reg<2, 5>(p, absmask, signmask); break;
-                    case 4: op_fg_reg<2, 4>(p, absmask, signmask); break;
-                    case 3: op_fg_reg<2, 3>(p, absmask, signmask); break;
-                    default: op_fg_reg<2, 2>(p, absmask, signmask); break;
+                    if (c1 >= 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                sm.mark(1);
+                if (gk) {
+                    if (gk == 1u) {
+                        switch (gs) {
+                        case 8: op_fg8(p, 1, absmask, signmask); break;
+                        case 7: op_fg7<1>(p, absmask, signmask); break;
+                        case 6: op_fg_reg<1, 6>(p, absmask, signmask); break;
+                        case 5: op_fg_reg<1, 5>(p, absmask, signmask); break;
+                        case 4: op_fg_reg<1, 4>(p, absmask, signmask); break;
+                        case 3: op_fg_reg<1, 3>(p, absmask, signmask); break;
+                        default: op_fg_reg<1, 2>(p, absmask, signmask); break;
+                        }
+                    } else {
+                        switch (gs) {
+                        case 8: op_fg8(p, 2, absmask, signmask); break;
+                        case 7: op_fg7<2>(p, absmask, signmask); break;
+                        case 6: op_fg_reg<2, 6>(p, absmask, signmask); break;
+                        case 5: op_fg_reg<2, 5>(p, absmask, signmask); break;
+                        case 4: op_fg_reg<2, 4>(p, absmask, signmask); break;
+                        case 3: op_fg_reg<2, 3>(p, absmask, signmask); break;
+                        default: op_fg_reg<2, 2>(p, absmask, signmask); break;
+                        }
                     }
                 }
                 sm.mark(2);
-                switch (f1) {
-                case 8: op_fg8(p, 0, absmask, signmask); if (f0 == 8) break; [[fallthrough]];
-                case 7: op_fg7<0>(p, absmask, signmask); if (f0 == 7) break; [[fallthrough]];
-                case 6: op_fg_reg<0, 6>(p, absmask, signmask); if (f0 == 6) break; [[fallthrough]];
-                case 5: op_fg_reg<0, 5>(p, absmask, signmask); if (f0 == 5) break; [[fallthrough]];
-                case 4: op_fg_reg<0, 4>(p, absmask, signmask); if (f0 == 4) break; [[fallthrough]];
-                case 3: op_fg_reg<0, 3>(p, absmask, signmask); if (f0 == 3) break; [[fallthrough]];
-                case 2: op_fg_reg<0, 2>(p, absmask, signmask); break;
-                default: break;
+                if (f1) {
+#pragma unroll 1
+                    for (uint32_t t = f1; t >= f0; --t) {
+                        switch (t) {
+                        case 8: op_fg8(p, 0, absmask, signmask); break;
+                        case 7: op_fg7<0>(p, absmask, signmask); break;
+                        case 6: op_fg_reg<0, 6>(p, absmask, signmask); break;
+                        case 5: op_fg_reg<0, 5>(p, absmask, signmask); break;
+                        case 4: op_fg_reg<0, 4>(p, absmask, signmask); break;
+                        case 3: op_fg_reg<0, 3>(p, absmask, signmask); break;
+                        default: op_fg_reg<0, 2>(p, absmask, signmask); break;
+                        }
+                    }
                 }
                 break;
             }
