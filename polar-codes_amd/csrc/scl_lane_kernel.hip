@@ -349,6 +349,7 @@ struct Path {
     __device__ __forceinline__ uint32_t owner(uint32_t t) const { return (uint32_t)g0 | ((slot >> (3u * (t - 2u))) & 7u); }
     __device__ __forceinline__ void set_field(uint32_t t)
     {
+        if (t < 2u) return;  // (stage 1 is never an inner node: nothing is ever looked up for it)
         const uint32_t sh = 3u * (t - 2u);
         slot = (slot & ~(7u << sh)) | ((uint32_t)q << sh);
     }
@@ -520,9 +521,11 @@ template <int M, int CTRL>
 __device__ __forceinline__ void merge_level(uint32_t (&k)[8])
 {
     if constexpr (M == 8) {
+        uint32_t b[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) k[i] = umin(k[i], dpp_u32<CTRL>(k[7 - i]));  // (partner's list reversed: bitonic)
-        // (k[i] of the partner at index 7 - i: both lanes compute the same multiset, mirrored -- still bitonic)
+        for (int i = 0; i < 8; ++i) b[i] = dpp_u32<CTRL>(k[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k[i] = umin(k[i], b[7 - i]);  // (the partner's list reversed: the minima are bitonic)
         bitonic_clean<8>(k);
     } else {
 #pragma unroll
