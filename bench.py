@@ -36,6 +36,8 @@ def parse_args(argv=None):
                     help="fill roofline.traffic from two rocprofv3 --pmc child passes (default at N = 1 when rocprofv3 "
                          "is on PATH; adds about a minute)")
     ap.add_argument("--no-pmc-traffic", dest="pmc_traffic", action="store_false")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="N > 1 started without a launcher: seconds after which the rank processes are terminated")
     ap.add_argument("--launch-check", action="store_true",
                     help="every rank reports its RANK / WORLD_SIZE / LOCAL_RANK and exits before touching the GPU "
                          "(test of the N > 1 launcher)")
@@ -44,30 +46,68 @@ def parse_args(argv=None):
 
 def self_launch(args):
     """--gpus N > 1 without a launcher: start the N ranks as fresh child processes (this process has not imported
-    torch nor loaded the HIP library yet), wait for them, exit with the first non-zero status."""
+    torch nor loaded the HIP library yet), wait for them, exit with the first non-zero status.  The ranks run in their
+    own sessions: on a failing rank, on SIGTERM / SIGINT to this process and after --launch-timeout seconds every rank's
+    process group is terminated, then killed -- no rank is left waiting in a collective with a GPU in its hands."""
+    import signal
     port = os.environ.get("MASTER_PORT")
     if not port:
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = str(sk.getsockname()[1])
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+
+    def stop_all(sig=signal.SIGTERM):
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(signum, _frame):
+        stop_all()
+        time.sleep(1.0)
+        stop_all(signal.SIGKILL)
+        sys.exit(128 + signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    alive = list(procs)
-    while alive:
-        time.sleep(0.2)
-        for p in list(alive):
-            st = p.poll()
-            if st is None:
-                continue
-            alive.remove(p)
-            if st != 0 and rc == 0:
-                rc = st
-                for q in alive:          # a rank failed: the others would wait in a collective for ever
-                    q.terminate()
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          start_new_session=True))
+        deadline = time.monotonic() + args.launch_timeout
+        alive = list(procs)
+        while alive:
+            time.sleep(0.2)
+            for p in list(alive):
+                st = p.poll()
+                if st is None:
+                    continue
+                alive.remove(p)
+                if st != 0 and rc == 0:
+                    rc = st
+                    stop_all()               # a rank failed: the others would wait in a collective for ever
+            if alive and time.monotonic() > deadline:
+                print(f"[bench] ranks still running after --launch-timeout {args.launch_timeout:.0f} s: terminating them",
+                      file=sys.stderr)
+                rc = rc or 124
+                stop_all()
+                time.sleep(2.0)
+                stop_all(signal.SIGKILL)
+                break
+    finally:
+        stop_all()
+        for q in procs:
+            try:
+                q.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                stop_all(signal.SIGKILL)
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc
 
 
@@ -333,6 +373,49 @@ def pmc_traffic(config, log2b, kernel_substr):
             "bytes": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]}
 
 
+def pmc_issue(config, log2b, kernel_substr, codewords):
+    """Instruction mix and wait share of the dominant kernel from one rocprofv3 --pmc pass over the SQ counters (its own
+    child run, no tracing).  Per codeword: wave-instructions issued; salu_frac / valu_frac: share of the scalar-unit
+    (SALU + branch) / vector-ALU instructions among all issued instructions; wait_frac: SQ_WAIT_ANY / SQ_WAVE_CYCLES."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    names = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+             "SQ_ACTIVE_INST_ANY"]
+    tmp = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", BENCH_PMC_CHILD="1")
+        subprocess.run(["rocprofv3", "--pmc"] + names + ["--output-format", "csv", "-d", tmp, "--", sys.executable,
+                        os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-pmc-traffic", "--log2-batch", str(log2b)],
+                       cwd="/tmp", env=env, capture_output=True, text=True, timeout=300, check=True)
+        agg, n = {}, {}
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if kernel_substr in r["Kernel_Name"]:
+                    agg[r["Counter_Name"]] = agg.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    n[r["Counter_Name"]] = n.get(r["Counter_Name"], 0) + 1
+        if "SQ_INSTS_VALU" not in agg:
+            return None
+        per = {k: agg[k] / n[k] / codewords for k in agg}  # per launch, per codeword
+        insts = sum(per.get(k, 0.0) for k in names[:5])
+        return {"valu_per_codeword": per["SQ_INSTS_VALU"], "salu_per_codeword": per["SQ_INSTS_SALU"],
+                "branch_per_codeword": per["SQ_INSTS_BRANCH"], "lds_per_codeword": per["SQ_INSTS_LDS"],
+                "vmem_per_codeword": per["SQ_INSTS_VMEM"],
+                "salu_frac": (per["SQ_INSTS_SALU"] + per["SQ_INSTS_BRANCH"]) / insts, "valu_frac": per["SQ_INSTS_VALU"] / insts,
+                "wait_frac": per["SQ_WAIT_ANY"] / per["SQ_WAVE_CYCLES"],
+                "active_frac": per["SQ_ACTIVE_INST_ANY"] / per["SQ_WAVE_CYCLES"],
+                "source": "rocprofv3 --pmc " + " ".join(names) + " (one child pass, 1 step)"}
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] PMC pass (SQ) failed: {e}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(cfg, seconds):
     """the reference's own CPU decoder (oracle/_ref, unmodified library) if it travelled with the repo,
     else the oracle port -- on a bounded sample of the same workload; reported, never the target."""
@@ -388,6 +471,8 @@ def main():
                 "gpus": args.gpus}
         if os.environ.get("BENCH_LAUNCH_CHECK_FAIL_RANK") == str(info["rank"]):
             sys.exit(3)
+        if os.environ.get("BENCH_LAUNCH_CHECK_HANG_RANK") == str(info["rank"]):
+            time.sleep(3600)             # (test of --launch-timeout: a rank that never comes back)
         if info["rank"] == 0:
             emit(info)
         return
@@ -450,6 +535,8 @@ def main():
     chr_dec = cfg.get("dectype") == "char"
     dec = pypolar_amd.PolarDecoder(N, L, frozen, "char" if chr_dec else "float", device=dev_index)
     dec.setErrorDetection(cfg["crc"], cfg["crc_type"])
+    # the kernel this decoder launches (the PMC passes filter by it): one lane per path = the lane-per-path list kernel
+    kernel_name = "sc_decode_kernel" if L <= 1 else ("scl_lane_kernel" if dec.launch_info(True)["path_groups"] == 64 else "scl_decode_kernel")
 
     llr, info = make_batch(cfg, frozen, B, dev, seed=1234 + rank)
     if chr_dec:  # int8 rows resident in HBM: round(8 y), clipped to +-127
@@ -480,15 +567,11 @@ def main():
         packed[b][:, :nb].copy_(out)
         packed[b][:, nb].copy_(ok)
         if backend != "nccl":  # rehearsal path: gloo gathers host tensors
-            host = torch.empty((B * world, nb + 1), dtype=torch.uint8)
-            torch.distributed.all_gather_into_tensor(host, packed[b].cpu())
-            return host
+            return sharding.gather_decoded(packed[b].cpu(), equal_rows=True)
         ev_ready[b].record(main)
         with torch.cuda.stream(comm):
             comm.wait_event(ev_ready[b])
-            # (= sharding.gather_decoded(packed[b], equal_rows=True, out=gathered[b]): one collective, no host sync)
-            torch.distributed.all_gather_into_tensor(gathered[b], packed[b])
-            res = gathered[b]
+            res = sharding.gather_decoded(packed[b], equal_rows=True, out=gathered[b])  # one collective, no host sync
             ev_done[b].record(comm)
         return res
 
@@ -543,7 +626,7 @@ def main():
             "detector_pass_fraction": okf, "payload_match_fraction": match,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "scl_decode_kernel" if L > 1 else "sc_decode_kernel",
+                         "kernel": kernel_name,
                          "kernel_ms_avg": k_ms, "algorithmic_bytes_per_codeword": bytes_per_cw,
                          "codewords_per_launch": B},
         }
@@ -554,6 +637,9 @@ def main():
                                         "interface (Infinity-Cache hits included): 2 x FETCH_SIZE + WRITE_SIZE",
                                         "traffic_fetch_size_raw": t["fetch_raw"], "traffic_write_size": t["write"],
                                         "traffic_over_algorithmic": t["bytes"] / (bytes_per_cw * B)})
+            iss = pmc_issue(args.config, log2b, res["roofline"]["kernel"], B)
+            if iss:
+                res["roofline"]["issue"] = iss
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
         emit(res)

@@ -99,15 +99,6 @@ int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4]);
 int pcd_set_timing(pcd_decoder* d, int enable);
 int pcd_kernel_times(pcd_decoder* d, float* ms, size_t cap, size_t* count);
 
-/* Diagnostics: decode ONE row (host float32[N]) with the list decoder and record, after every leaf of
- * the decode tree, (1 + list_size) floats {live path count, path metrics...} into trace (host). */
-int pcd_scl_trace(pcd_decoder* d, const float* llr_row, float* trace, unsigned cap);
-
-/* Diagnostics: shader-clock cycles one wave spends in every instruction of the SCL decode program while
- * decoding ONE row on an otherwise idle GPU (ops[i]/stages[i] describe instruction i; *count = program length). */
-int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
-                    unsigned cap, unsigned* count);
-
 /* =====================================================================================================
  * Batched ENCODER: PolarCode::Encoding::ButterflyFipPacked behind pypolar.PolarEncoder
  *   ButterflyFipPacked(blockLength, frozenBits)   src/polarcode/encoding/butterfly_fip_packed.cpp:27-43
@@ -163,10 +154,6 @@ int ppu_puncture(ppu_puncturer* u, const void* in, size_t rows, void* out, unsig
 int ppu_depuncture(ppu_puncturer* u, const void* in, size_t rows, void* out, unsigned elem_bytes, int mem, void* stream);
 /* puncturePacked: rows x N/8 bytes -> rows x blockLength/8 bytes, bits MSB first (both lengths multiples of 8) */
 int ppu_puncture_packed(ppu_puncturer* u, const uint8_t* in, size_t rows, uint8_t* out, int mem, void* stream);
-
-/* the same for the SC decode program (16 lanes per codeword, i.e. N <= 2048) */
-int pcd_sc_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
-                   unsigned cap, unsigned* count);
 
 const char* pcd_last_error(void);
 const char* pcd_version(void);

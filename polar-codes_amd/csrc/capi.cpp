@@ -1,6 +1,9 @@
 // C ABI of the MI355X polar decoder (include/polar_amd.h).  Host logic only: argument checking in
 // the reference's terms, decode-program compilation, device table upload, launch geometry.
 #include "../../include/polar_amd.h"
+#ifdef PAMD_DIAG
+#include "../../include/polar_amd_diag.h"
+#endif
 
 #include <hip/hip_runtime.h>
 
@@ -1209,7 +1212,7 @@ int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4])
         if (d->has_lane) {  // lane-per-path kernel: 40 KB of LDS per wave of 8 codewords, 1 lane per path, 4 waves per CU
             info[0] = 40960 / 8;
             info[1] = 8;
-            info[2] = 1;
+            info[2] = 64;  // path groups per wave: every lane is one
             info[3] = 4;
             return PCD_OK;
         }
@@ -1247,11 +1250,9 @@ int pcd_kernel_times(pcd_decoder* d, float* ms, size_t cap, size_t* count)
     return PCD_OK;
 }
 
+#ifdef PAMD_DIAG
 int pcd_scl_trace(pcd_decoder* d, const float* llr_row, float* trace, unsigned cap)
 {
-#ifndef PAMD_DIAG
-    return fail(PCD_ERR_UNSUPPORTED, "diagnostics (trace / cycle profile) exist in the diagnostic build only: make -C polar-codes_amd diag");
-#else
     if (!d || !llr_row || !trace) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "not a list decoder");
     pamd::DeviceScope scope;
@@ -1274,15 +1275,13 @@ int pcd_scl_trace(pcd_decoder* d, const float* llr_row, float* trace, unsigned c
     }
     (void)hipFree(dtrace);
     return rc;
-#endif
 }
+#endif  // PAMD_DIAG
 
+#ifdef PAMD_DIAG
 int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
                     unsigned cap, unsigned* count)
 {
-#ifndef PAMD_DIAG
-    return fail(PCD_ERR_UNSUPPORTED, "diagnostics (trace / cycle profile) exist in the diagnostic build only: make -C polar-codes_amd diag");
-#else
     if (!d || !llr_row || !cycles || !count) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "not a list decoder");
     pamd::DeviceScope scope;
@@ -1321,15 +1320,13 @@ int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t*
     }
     (void)hipFree(dcyc);
     return rc;
-#endif
 }
+#endif  // PAMD_DIAG
 
+#ifdef PAMD_DIAG
 int pcd_sc_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* stages, uint32_t* cycles,
                    unsigned cap, unsigned* count)
 {
-#ifndef PAMD_DIAG
-    return fail(PCD_ERR_UNSUPPORTED, "diagnostics (trace / cycle profile) exist in the diagnostic build only: make -C polar-codes_amd diag");
-#else
     if (!d || !llr_row || !cycles || !count) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
     if (d->sc_lcl != 4 || d->sc_arena_cw_words)
@@ -1361,8 +1358,8 @@ int pcd_sc_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* 
     }
     (void)hipFree(dcyc);
     return rc;
-#endif
 }
+#endif  // PAMD_DIAG
 
 const char* pcd_last_error(void) { return g_err.c_str(); }
 const char* pcd_version(void) { return "polar_amd 0.1 (gfx950)"; }

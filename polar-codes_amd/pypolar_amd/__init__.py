@@ -32,8 +32,7 @@ C_SYMBOLS = [
     "pcd_create", "pcd_destroy", "pcd_set_error_detection", "pcd_set_systematic", "pcd_is_systematic",
     "pcd_block_length", "pcd_info_length", "pcd_list_size", "pcd_frozen_bits", "pcd_error_detection_mode",
     "pcd_out_bytes", "pcd_decode_f32", "pcd_decode_i8", "pcd_program_stats", "pcd_launch_info",
-    "pcd_set_timing", "pcd_kernel_times", "pcd_scl_trace", "pcd_scl_profile", "pcd_sc_profile", "pcd_last_error",
-    "pcd_version",
+    "pcd_set_timing", "pcd_kernel_times", "pcd_last_error", "pcd_version",
     "pce_create", "pce_destroy", "pce_set_error_detection", "pce_set_systematic", "pce_is_systematic",
     "pce_block_length", "pce_info_length", "pce_info_bytes", "pce_code_bytes", "pce_frozen_bits",
     "pce_error_detection_mode", "pce_encode",
@@ -93,12 +92,13 @@ def load_library():
     lib.pcd_set_timing.argtypes = [vp, C.c_int]
     lib.pcd_kernel_times.restype = C.c_int
     lib.pcd_kernel_times.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
-    lib.pcd_scl_trace.restype = C.c_int
-    lib.pcd_scl_trace.argtypes = [vp, vp, vp, C.c_uint]
-    lib.pcd_scl_profile.restype = C.c_int
-    lib.pcd_scl_profile.argtypes = [vp, vp, vp, vp, vp, C.c_uint, C.POINTER(C.c_uint)]
-    lib.pcd_sc_profile.restype = C.c_int
-    lib.pcd_sc_profile.argtypes = [vp, vp, vp, vp, vp, C.c_uint, C.POINTER(C.c_uint)]
+    if hasattr(lib, "pcd_scl_trace"):  # include/polar_amd_diag.h: the diagnostic build only (PYPOLAR_AMD_LIB=.../libpolar_amd_diag.so)
+        lib.pcd_scl_trace.restype = C.c_int
+        lib.pcd_scl_trace.argtypes = [vp, vp, vp, C.c_uint]
+        lib.pcd_scl_profile.restype = C.c_int
+        lib.pcd_scl_profile.argtypes = [vp, vp, vp, vp, vp, C.c_uint, C.POINTER(C.c_uint)]
+        lib.pcd_sc_profile.restype = C.c_int
+        lib.pcd_sc_profile.argtypes = [vp, vp, vp, vp, vp, C.c_uint, C.POINTER(C.c_uint)]
     lib.pcd_last_error.restype = C.c_char_p
     lib.pcd_version.restype = C.c_char_p
     lib.pce_create.restype = C.c_int
@@ -369,11 +369,17 @@ class PolarDecoder:
         return {"lds_bytes_per_codeword": int(info[0]), "codewords_per_workgroup": int(info[1]),
                 "path_groups": int(info[2]), "workgroups_per_cu_by_lds": int(info[3])}
 
+    def _need_diag(self):
+        if not hasattr(self._lib, "pcd_scl_trace"):
+            raise PolarAmdError("diagnostics (trace / cycle profile) exist in the diagnostic build only: make -C polar-codes_amd diag, "
+                                "then PYPOLAR_AMD_LIB=<repo>/polar-codes_amd/lib/libpolar_amd_diag.so")
+
     def scl_trace(self, llr_row, cap=4096):
         """diagnostics: per-leaf (path count, metrics) trace of one row -> float32[n, 1 + L]"""
         a = np.ascontiguousarray(llr_row, dtype=np.float32)
         L = self.listSize()
         tr = np.zeros((cap, 1 + L), np.float32)
+        self._need_diag()
         rc = self._lib.pcd_scl_trace(self._h, a.ctypes.data_as(C.c_void_p), tr.ctypes.data_as(C.c_void_p), cap)
         if rc:
             _raise(rc)
@@ -384,6 +390,7 @@ class PolarDecoder:
         a = np.ascontiguousarray(llr_row, dtype=np.float32)
         ops = np.zeros(cap, np.uint8); st = np.zeros(cap, np.uint8); cyc = np.zeros(cap, np.uint32)
         n = C.c_uint()
+        self._need_diag()
         rc = self._lib.pcd_scl_profile(self._h, a.ctypes.data_as(C.c_void_p), ops.ctypes.data_as(C.c_void_p),
                                        st.ctypes.data_as(C.c_void_p), cyc.ctypes.data_as(C.c_void_p), cap, C.byref(n))
         if rc:
@@ -396,6 +403,7 @@ class PolarDecoder:
         a = np.ascontiguousarray(llr_row, dtype=np.float32)
         ops = np.zeros(cap, np.uint8); st = np.zeros(cap, np.uint8); cyc = np.zeros(cap, np.uint32)
         n = C.c_uint()
+        self._need_diag()
         rc = self._lib.pcd_sc_profile(self._h, a.ctypes.data_as(C.c_void_p), ops.ctypes.data_as(C.c_void_p),
                                       st.ctypes.data_as(C.c_void_p), cyc.ctypes.data_as(C.c_void_p), cap, C.byref(n))
         if rc:

@@ -23,8 +23,11 @@ while time.time() < t_end:
         t_print = time.time()
         print(f"... {n_cfg} configurations, {n_rows} rows, {n_bad} mismatching", flush=True)
     logN = int(rng.integers(3, 16))
-    N = 1 << logN
     L = int(rng.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 8, 11, 16, 24, 32]))
+    if os.environ.get("FUZZ_LANE"):  # only what the lane-per-path list kernel takes: N = 1024, 4 < L <= 8
+        logN = 10
+        L = int(rng.choice([5, 6, 7, 8, 8, 8]))
+    N = 1 << logN
     kind = int(rng.integers(0, 3))
     if kind == 2:
         K = int(rng.integers(1, N))
