@@ -11,7 +11,10 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <sched.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -883,11 +886,17 @@ int decode_device(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t
 // host threads copy chunk k + 1 .. k + 2 from the caller's (pageable) memory into the ring while the DMA engine moves
 // chunk k to the device and the decode kernel works on chunk k - 1 -- a copy from pageable memory would be staged by the
 // runtime synchronously and serialise with the kernel.  Results stay on the device until the end (65 bytes per row).
+// Returns PCD_OK, an error, or kPipelineUnavailable when the worker threads could not be started (the caller then takes
+// the simple staged path).
+constexpr int kPipelineUnavailable = 1;
 int decode_host_pipelined(pcd_decoder* d, const void* llr, bool i8, size_t rows, float* dmet)
 {
     constexpr int R = pcd_decoder::kRing;
     const size_t row_bytes = (size_t)d->N * (i8 ? 1 : 4);
-    const size_t chunk_rows = std::max<size_t>(1024, ((size_t)32 << 20) / row_bytes);  // 32 MiB per chunk
+    // chunks of at most 64 MiB (the ring pins three of them on the host and holds three on the device), whole rows, a
+    // multiple of 16 rows so that every chunk starts 16-byte aligned
+    size_t chunk_rows = std::max<size_t>(1, ((size_t)64 << 20) / row_bytes);
+    if (chunk_rows > 16) chunk_rows &= ~(size_t)15;
     const size_t chunk_bytes = chunk_rows * row_bytes;
     const size_t nchunks = (rows + chunk_rows - 1) / chunk_rows;
     int rc;
@@ -912,29 +921,54 @@ int decode_host_pipelined(pcd_decoder* d, const void* llr, bool i8, size_t rows,
             HIP_TRY(hipEventCreateWithFlags(&d->ev_run[b], hipEventDisableTiming));
         }
     }
-    // worker threads: thread t copies slice t of every chunk once the main thread has released the chunk's ring slot
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    // worker threads: thread t copies slice t of every chunk once the main thread has released the chunk's ring slot.
+    // As many as the process may run on (its affinity mask, not the machine), at most 16; they sleep on a condition
+    // variable between chunks.
+    unsigned hw = 1;
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = (unsigned)std::max(1, CPU_COUNT(&set));
+    }
     const unsigned T = std::min(16u, std::max(2u, hw / 2));
-    std::atomic<long> released(-1);
-    std::vector<std::atomic<unsigned>> done(nchunks);
-    for (auto& x : done) x.store(0, std::memory_order_relaxed);
+    std::mutex mu;
+    std::condition_variable cv_rel, cv_done;
+    long released = -1;                     // chunks 0 .. released may be copied      (guarded by mu)
+    std::vector<unsigned> done(nchunks, 0);  // threads that have copied their slice   (guarded by mu)
     const uint8_t* src = reinterpret_cast<const uint8_t*>(llr);
     auto worker = [&](unsigned t) {
         for (size_t k = 0; k < nchunks; ++k) {
-            while (released.load(std::memory_order_acquire) < (long)k) std::this_thread::yield();
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_rel.wait(lk, [&] { return released >= (long)k; });
+                if (released >= (long)nchunks) return;  // (shut down)
+            }
             const size_t r0 = k * chunk_rows, nr = std::min(chunk_rows, rows - r0), bytes = nr * row_bytes;
             const size_t lo = bytes * t / T, hi = bytes * (t + 1) / T;
             std::memcpy(reinterpret_cast<uint8_t*>(d->h_ring[k % R]) + lo, src + r0 * row_bytes + lo, hi - lo);
-            done[k].fetch_add(1, std::memory_order_release);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ++done[k];
+            }
+            cv_done.notify_one();
         }
     };
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t < T; ++t) pool.emplace_back(worker, t);
     auto finish = [&](int code) {
-        released.store((long)nchunks, std::memory_order_release);  // let the workers run out
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            released = (long)nchunks;  // let the workers run out
+        }
+        cv_rel.notify_all();
         for (auto& th : pool) th.join();
         return code;
     };
+    try {
+        pool.reserve(T);
+        for (unsigned t = 0; t < T; ++t) pool.emplace_back(worker, t);
+    } catch (const std::exception&) {  // (thread limit of the container: no pipeline, but no crash either)
+        return finish(kPipelineUnavailable);
+    }
     const unsigned Lm = std::max(1u, d->L);
     size_t rel = 0;  // chunks released to the workers so far
     for (size_t k = 0; k < nchunks; ++k) {
@@ -945,10 +979,17 @@ int decode_host_pipelined(pcd_decoder* d, const void* llr, bool i8, size_t rows,
         while (rel < nchunks && rel < k + (size_t)R) {
             if (rel >= (size_t)R && hipEventSynchronize(d->ev_h2d[rel % R]) != hipSuccess)
                 return finish(fail(PCD_ERR_HIP, "hipEventSynchronize failed in the host-pointer pipeline"));
-            released.store((long)rel, std::memory_order_release);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                released = (long)rel;
+            }
+            cv_rel.notify_all();
             ++rel;
         }
-        while (done[k].load(std::memory_order_acquire) < T) std::this_thread::yield();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return done[k] >= T; });
+        }
         hipError_t e = hipSuccess;
         if (k >= (size_t)R) e = hipStreamWaitEvent(d->s_in, d->ev_run[b], 0);  // device slot b: its kernel has finished
         if (e == hipSuccess) e = hipMemcpyAsync(d->d_ring[b], d->h_ring[b], nr * row_bytes, hipMemcpyHostToDevice, d->s_in);
@@ -992,11 +1033,15 @@ int decode_any(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t* o
             if ((rc = grow(d->d_met, d->d_met_cap, rows * std::max(1u, d->L) * sizeof(float)))) return rc;
             dm = d->d_met;
         }
-        if ((rc = decode_host_pipelined(d, llr, i8, rows, dm))) return rc;
-        HIP_TRY(hipMemcpy(out, d->d_out, out_bytes, hipMemcpyDeviceToHost));
-        if (ok) HIP_TRY(hipMemcpy(ok, d->d_ok, rows, hipMemcpyDeviceToHost));
-        if (metrics) HIP_TRY(hipMemcpy(metrics, dm, rows * std::max(1u, d->L) * sizeof(float), hipMemcpyDeviceToHost));
-        return PCD_OK;
+        rc = decode_host_pipelined(d, llr, i8, rows, dm);
+        if (rc == PCD_OK) {
+            HIP_TRY(hipMemcpy(out, d->d_out, out_bytes, hipMemcpyDeviceToHost));
+            if (ok) HIP_TRY(hipMemcpy(ok, d->d_ok, rows, hipMemcpyDeviceToHost));
+            if (metrics) HIP_TRY(hipMemcpy(metrics, dm, rows * std::max(1u, d->L) * sizeof(float), hipMemcpyDeviceToHost));
+            return PCD_OK;
+        }
+        if (rc != kPipelineUnavailable) return rc;
+        // (no worker threads to be had: the simple staged path below)
     }
     if ((rc = grow(d->d_in, d->d_in_cap, in_bytes))) return rc;
     if ((rc = grow(d->d_out, d->d_out_cap, out_bytes))) return rc;
