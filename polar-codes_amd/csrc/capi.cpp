@@ -1126,7 +1126,14 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         pamd::compile_scl(d->N, d->frozen, d->scl_prog, chr);
         d->has_scl = true;
         // the lane-per-path kernel takes the codes it has every op for (its program is lowered from the plain one)
-        if (!chr && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog);
+        // (measured on one box, DESIGN.md section 3.5: cfg 3 -- 60 forking leaves -- 30.1 against 27.8 M cw/s, cfg 4 -- 40 forking
+        //  leaves, 35 all-frozen ones -- 38.2 against 40.2: its fixed cost per pass, four passes over the channel row, pays off
+        //  from about 48 forking leaves on)
+        if (!chr && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) {
+            unsigned forks = 0;
+            for (const auto& in : d->scl_prog.ins) forks += (in.op == pamd::SCL_R1 || in.op == pamd::SCL_SPC || in.op == pamd::SCL_REP) ? 1u : 0u;
+            if (forks >= 48u || PAMD_ENV("PCD_FORCE_LANE")) d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog);
+        }
     }
     compute_geometry(d);
     if ((size_t)d->sc_wave_words * 4 * (64u >> d->sc_lcl) > kMaxLds && d->has_sc) {

@@ -111,12 +111,19 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out)
                 ++k;
             }
         }
+        // an all-frozen leaf at the end of the descent rides along (one dispatch fewer; its trace record is the walk's)
+        unsigned r0s = 0, r0side = 0;
+        if (o[k].op == LN_R0 && f1 != 0 && o[k].stage + 1u == f0) {
+            r0s = o[k].stage;
+            r0side = o[k].side;
+            ++k;
+        }
         Ins i;
         i.op = (uint8_t)LN_WALK;
         i.stage = 0;
         i.side = (uint8_t)side;
         i.pad = 0;
-        i.off = c0 | (c1 << 4) | (gs << 8) | (gk << 12) | (f1 << 16) | (f0 << 20);
+        i.off = c0 | (c1 << 4) | (gs << 8) | (gk << 12) | (f1 << 16) | (f0 << 20) | (r0s << 24) | (r0side << 28);
         w.push_back(i);
     }
     w.push_back(w.back());  // a spare word behind OP_END: the kernel fetches one instruction ahead

@@ -90,7 +90,8 @@ enum Op : uint8_t {
     LN_SPC,
     // Everything between two leaves (or a leaf and an LN_VT) in one instruction: COMBINEs at stages c0 .. c1 up a right
     // spine (the last one writes to `side`, the others are right children), then a G (kind 1) / G0 (kind 2) at stage gs,
-    // then Fs from stage f1 down to f0.  off: c0 | c1 << 4 | gs << 8 | kind << 12 | f1 << 16 | f0 << 20 (0 = absent)
+    // then Fs from stage f1 down to f0, then an all-frozen leaf of stage r0 (side r0side) if the descent ends at one.
+    // off: c0 | c1 << 4 | gs << 8 | kind << 12 | f1 << 16 | f0 << 20 | r0 << 24 | r0side << 28 (0 = absent)
     LN_WALK,
 };
 

@@ -1168,12 +1168,40 @@ __device__ __forceinline__ void op_vt_t(Path& p, const float* chan, uint32_t abs
     if (F8) p.set_field(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+// The first pass of a codeword (F of the root, F of its left child): one live path, whose lane would do 32 steps while
+// the other seven of the codeword idle.  The steps do not depend on the path, so lane q does the steps j = q, q + 8,
+// q + 16, q + 24 and stores into the column of the codeword's first lane, where the path lives.
+__device__ __forceinline__ void op_vt_first(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
+{
+    const uint32_t* s8base = p.arena + AR_S8;
+    const uint32_t s8off = (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
+    const uint32_t s7addr = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
+    const float* rowp = chan + 4 * p.q;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vt_load<VT_SET0>(rowp);
+    vt_load<VT_SET1>(rowp + 32);
+    vt_load<VT_SET2>(rowp + 64);
+    vt_load<VT_SET3>(rowp + 96);
+    // (vt_step waits for all but the 24 youngest accesses: 8 loads per set, sets 1 .. 3 younger than set 0; the last steps
+    //  wait for everything)
+    vt_step<VT_SET0, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off, s8base, s7addr);
+    vt_step<VT_SET1, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 8192u, s8base, s7addr + 8192u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vt_step<VT_SET2, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 16384u, s8base, s7addr + 16384u);
+    vt_step<VT_SET3, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 24576u, s8base, s7addr + 24576u);
+    p.set_field(8);
+    p.set_field(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 __device__ __forceinline__ void op_vt(Path& p, uint32_t off, const float* chan, uint32_t absmask, uint32_t signmask)
 {
     // (bit 2 of off -- "the F of stage 8 follows" -- needs no variant of its own: stage 7 is dead whenever it is clear, so the
     //  F is computed and stored regardless)
     switch (off & 3u) {
-    case 0: op_vt_t<false, false, true>(p, chan, absmask, signmask); break;
+    case 0:
+        if (p.P == 1u) op_vt_first(p, chan, absmask, signmask);  // (always: the program starts with this op)
+        else op_vt_t<false, false, true>(p, chan, absmask, signmask);
+        break;
     case 1: op_vt_t<true, false, true>(p, chan, absmask, signmask); break;
     case 2: op_vt_t<false, true, true>(p, chan, absmask, signmask); break;
     default: op_vt_t<true, true, true>(p, chan, absmask, signmask); break;
@@ -1329,16 +1357,19 @@ void scl_lane_kernel(const DecodeParams P)
             switch (op) {
             case LN_VT:
                 if (!(DIAG && (P.ablate & 1u))) op_vt(p, off, chan, absmask, signmask);
+                if (DIAG && (P.ablate & 1024u)) op_vt(p, off, chan, absmask, signmask);  // (idempotent: costed by doing it twice)
                 break;
             case LN_WALK: {
                 if (DIAG && (P.ablate & 2u)) break;
                 // everything between two leaves in one dispatch: COMBINEs up the right spine (stages c0 .. c1, the last one
                 // with this instruction's side, the others are right children), the G of the node reached, Fs down to the next leaf
                 const uint32_t c0 = off & 15u, c1 = (off >> 4) & 15u, gs = (off >> 8) & 15u, gk = (off >> 12) & 3u;
-                const uint32_t f1 = (off >> 16) & 15u, f0 = (off >> 20) & 15u;
+                const uint32_t f1 = (off >> 16) & 15u, f0 = (off >> 20) & 15u, r0s = (off >> 24) & 15u, r0side = (off >> 28) & 1u;
                 // (plain loops over the stages with a flat switch each: fall-through switches make the compiler thread
                 //  flag variables through a structured control flow graph -- dozens of scalar instructions per step)
                 if (c0) {
+#pragma unroll 1
+                  for (uint32_t rep = 0; rep < ((DIAG && (P.ablate & 2048u)) ? 2u : 1u); ++rep)
 #pragma unroll 1
                     for (uint32_t t = c0; t <= c1; ++t) {
                         const uint32_t sd = t == c1 ? side : 1u;
@@ -1382,6 +1413,8 @@ void scl_lane_kernel(const DecodeParams P)
                 sm.mark(2);
                 if (f1) {
 #pragma unroll 1
+                  for (uint32_t rep = 0; rep < ((DIAG && (P.ablate & 512u)) ? 2u : 1u); ++rep)
+#pragma unroll 1
                     for (uint32_t t = f1; t >= f0; --t) {
                         switch (t) {
                         case 8: op_fg8(p, 0, absmask, signmask); break;
@@ -1392,6 +1425,19 @@ void scl_lane_kernel(const DecodeParams P)
                         case 3: op_fg_reg<0, 3>(p, absmask, signmask); break;
                         default: op_fg_reg<0, 2>(p, absmask, signmask); break;
                         }
+                    }
+                }
+                if (r0s && !(DIAG && (P.ablate & 32u))) {  // the all-frozen leaf the descent ends at
+                    is_leaf = true;
+                    switch (r0s) {
+                    case 8: leaf_r0<8>(p, r0side); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 7: leaf_r0<7>(p, r0side); break;
+                    case 6: leaf_r0<6>(p, r0side); break;
+                    case 5: leaf_r0<5>(p, r0side); break;
+                    case 4: leaf_r0<4>(p, r0side); break;
+                    case 3: leaf_r0<3>(p, r0side); break;
+                    case 2: leaf_r0<2>(p, r0side); break;
+                    default: leaf_r0<1>(p, r0side); break;
                     }
                 }
                 break;
@@ -1421,6 +1467,8 @@ void scl_lane_kernel(const DecodeParams P)
                 is_leaf = true;
                 if (DIAG && (P.ablate & 8u)) break;
                 fkind = op == LN_SPC ? 2u : 1u;
+#pragma unroll 1
+              for (uint32_t rep = 0; rep < ((DIAG && (P.ablate & 4096u)) ? 2u : 1u); ++rep)
                 switch (st) {
                 case 7: leaf_scan<7>(p, ws); break;
                 case 6: leaf_scan<6>(p, ws); break;
@@ -1515,8 +1563,8 @@ void scl_lane_kernel(const DecodeParams P)
         uint32_t syn = 0;
         if (P.det_on) {
             const uint32_t nwords = (P.nb + 3u) >> 2;
-#pragma unroll 4
-            for (uint32_t j = 0; j < nwords; ++j) {
+#pragma unroll 8
+            for (uint32_t j = 0; j < nwords; ++j) {  // (eight words = 32 independent table loads per wait)
                 const uint32_t word = il[j * 64 + lane];
                 const uint32_t* tb = P.syn_bytes + j * 1024u;
                 syn ^= tb[word & 255u];

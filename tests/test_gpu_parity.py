@@ -520,7 +520,7 @@ def test_mixed_decoder_grid(built_library, N, L):
 
 
 FUSE_SWITCHES = ["PCD_NO_FUSE", "PCD_NO_FUSE_C", "PCD_NO_FUSE_R0", "PCD_NO_FUSE_G0", "PCD_NO_FUSE_GRAND", "PCD_NO_FUSE_CW",
-                 "PCD_NO_FUSE_F", "PCD_NO_FUSE_G", "PCD_SC_NO_SKEW", "PCD_NO_VTOP", "PCD_NO_VIRTUAL", "PCD_NO_WFG", "PCD_VG2", "PCD_NO_LANE"]
+                 "PCD_NO_FUSE_F", "PCD_NO_FUSE_G", "PCD_SC_NO_SKEW", "PCD_NO_VTOP", "PCD_NO_VIRTUAL", "PCD_NO_WFG", "PCD_VG2", "PCD_NO_LANE", "PCD_FORCE_LANE"]
 
 
 @pytest.mark.parametrize("switch", FUSE_SWITCHES)
