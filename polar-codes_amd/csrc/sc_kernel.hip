@@ -1,4 +1,6 @@
 // Fast-SSC kernel, the "mixed" helper kernel, and the launch dispatch of both decoder families.
+#include <algorithm>
+
 #include "device_common.h"
 #include "scl_launch.h"
 
@@ -860,13 +862,16 @@ __global__ void collect_failed_kernel(const uint8_t* ok, uint32_t rows, uint32_t
     }
 }
 
-// float rows for an int8 decoder: _mm256_cvtps_epi32 (round to nearest even) + saturating packs (bitcontainer.cpp:468-503)
+// float rows for an int8 decoder: _mm256_cvtps_epi32 (round to nearest even) + saturating packs (bitcontainer.cpp:468-503).
+// Finite values: round to nearest even, saturate to [-128, 127] -- as the reference.  NaN -> -128, as the reference's
+// conversion gives (cvtps yields INT_MIN, the packs saturate it).  Deliberate deviation: +inf and values >= 2^31 give +127
+// here (the reference's cvtps turns them into INT_MIN, i.e. -128: an artefact of the x86 conversion, not a decision).
 __global__ void f32_to_i8_kernel(const float* in, int8_t* out, size_t n)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const float v = rintf(in[i]);
-        out[i] = (int8_t)(int)(v < -128.0f ? -128.0f : (v > 127.0f ? 127.0f : v));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = in[i];
+        const float v = rintf(x);
+        out[i] = (x != x) ? (int8_t)-128 : (int8_t)(int)(v < -128.0f ? -128.0f : (v > 127.0f ? 127.0f : v));
     }
 }
 
@@ -975,7 +980,8 @@ hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, un
 hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(f32_to_i8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+    const size_t blocks = std::min<size_t>((n + 255) / 256, (size_t)1 << 20);  // (grid-stride loop: any n)
+    hipLaunchKernelGGL(f32_to_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
     return hipGetLastError();
 }
 

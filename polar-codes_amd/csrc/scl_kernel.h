@@ -851,7 +851,8 @@ constexpr uint64_t merge_keepmin_mask(int dist, int dbit)
                  "s_xor_b32 vcc_lo, vcc_lo, %3\n\t"                                                        \
                  "s_xor_b32 vcc_hi, vcc_hi, %3\n\t"                                                        \
                  "v_cndmask_b32_e32 %0, %2, %0, vcc\n\t"                                                   \
-                 "v_cndmask_b32_dpp %1, %1, %1, vcc " DPPSTR " row_mask:0xf bank_mask:0xf bound_ctrl:1"    \
+                 "v_cndmask_b32_dpp %1, %1, %1, vcc " DPPSTR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                 "s_nop 1"  /* (both outputs are VALU-written here: a DPP read by the code behind the statement is safe) */ \
                  : "+v"(k), "+v"(x), "=&v"(pk)                                                            \
                  : "i"(KEEPMIN)                                                                           \
                  : "vcc", "scc")  /* (s_xor_b32 writes SCC) */
