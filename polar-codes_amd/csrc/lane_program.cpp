@@ -111,9 +111,11 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out)
                 ++k;
             }
         }
-        // an all-frozen leaf at the end of the descent rides along (one dispatch fewer; its trace record is the walk's)
-        unsigned r0s = 0, r0side = 0;
-        if (o[k].op == LN_R0 && f1 != 0 && o[k].stage + 1u == f0) {
+        // the leaf the walk ends at rides along (one dispatch fewer; its trace record is the walk's)
+        unsigned r0s = 0, r0side = 0, lkind = 0;
+        if ((o[k].op == LN_R0 || o[k].op == LN_R1 || o[k].op == LN_SPC || o[k].op == LN_REP) && o[k].stage >= 1 &&
+            ((f1 != 0 && o[k].stage + 1u == f0) || (f1 == 0 && gs != 0 && o[k].stage + 1u == gs))) {
+            lkind = o[k].op == LN_R0 ? 1u : (o[k].op == LN_R1 ? 2u : (o[k].op == LN_SPC ? 3u : 4u));
             r0s = o[k].stage;
             r0side = o[k].side;
             ++k;
@@ -123,7 +125,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out)
         i.stage = 0;
         i.side = (uint8_t)side;
         i.pad = 0;
-        i.off = c0 | (c1 << 4) | (gs << 8) | (gk << 12) | (f1 << 16) | (f0 << 20) | (r0s << 24) | (r0side << 28);
+        i.off = c0 | (c1 << 4) | (gs << 8) | (gk << 12) | (f1 << 16) | (f0 << 20) | (r0s << 24) | (r0side << 28) | (lkind << 29);
         w.push_back(i);
     }
     w.push_back(w.back());  // a spare word behind OP_END: the kernel fetches one instruction ahead

@@ -1352,7 +1352,8 @@ void scl_lane_kernel(const DecodeParams P)
             Stamps sm{ nullptr, t_start };
             if (DIAG && P.cycles && grp == 0 && (P.ablate & 256u)) sm.sub = P.cycles + P.prog_len + 4 * pc;  // (PCD_ABLATE=256: phase stamps)
             bool is_leaf = false;
-            uint32_t fkind = 0;  // forking leaf: 1 RateOne, 2 SPC, 3 repetition
+            uint32_t fkind = 0;  // forking leaf: 1 RateOne, 2 SPC
+            uint32_t lk = 0, lst = st, lside = side;  // leaf to run behind the switch: kind, stage, side
             WeakScan ws;
             switch (op) {
             case LN_VT:
@@ -1427,64 +1428,56 @@ void scl_lane_kernel(const DecodeParams P)
                         }
                     }
                 }
-                if (r0s && !(DIAG && (P.ablate & 32u))) {  // the all-frozen leaf the descent ends at
-                    is_leaf = true;
-                    switch (r0s) {
-                    case 8: leaf_r0<8>(p, r0side); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                    case 7: leaf_r0<7>(p, r0side); break;
-                    case 6: leaf_r0<6>(p, r0side); break;
-                    case 5: leaf_r0<5>(p, r0side); break;
-                    case 4: leaf_r0<4>(p, r0side); break;
-                    case 3: leaf_r0<3>(p, r0side); break;
-                    case 2: leaf_r0<2>(p, r0side); break;
-                    default: leaf_r0<1>(p, r0side); break;
-                    }
-                }
+                lk = (off >> 29) & 7u;  // the leaf the descent ends at rides along: 1 all-frozen, 2 RateOne, 3 SPC, 4 repetition
+                lst = r0s;
+                lside = r0side;
                 break;
             }
-            case LN_R0:
-                is_leaf = true;
-                if (DIAG && (P.ablate & 32u)) break;
-                switch (st) {
-                case 8: leaf_r0<8>(p, side); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                case 7: leaf_r0<7>(p, side); break;
-                case 6: leaf_r0<6>(p, side); break;
-                case 5: leaf_r0<5>(p, side); break;
-                case 4: leaf_r0<4>(p, side); break;
-                case 3: leaf_r0<3>(p, side); break;
-                case 2: leaf_r0<2>(p, side); break;
-                default: leaf_r0<1>(p, side); break;
-                }
-                break;
-            case LN_REP:
-                is_leaf = true;
-                if (DIAG && (P.ablate & 16u)) break;
-                if (st == 2) leaf_rep<2>(p, side, sm);
-                else leaf_rep<1>(p, side, sm);
-                break;
-            case LN_R1:
-            case LN_SPC:
-                is_leaf = true;
-                if (DIAG && (P.ablate & 8u)) break;
-                fkind = op == LN_SPC ? 2u : 1u;
-#pragma unroll 1
-              for (uint32_t rep = 0; rep < ((DIAG && (P.ablate & 4096u)) ? 2u : 1u); ++rep)
-                switch (st) {
-                case 7: leaf_scan<7>(p, ws); break;
-                case 6: leaf_scan<6>(p, ws); break;
-                case 5: leaf_scan<5>(p, ws); break;
-                case 4: leaf_scan<4>(p, ws); break;
-                case 3: leaf_scan<3>(p, ws); break;
-                case 2: leaf_scan<2>(p, ws); break;
-                default: leaf_scan<1>(p, ws); break;
-                }
-                break;
+            case LN_R0: lk = 1; break;
+            case LN_R1: lk = 2; break;
+            case LN_SPC: lk = 3; break;
+            case LN_REP: lk = 4; break;
             default: break;
+            }
+            if (lk) {  // the leaf of this instruction (its own op, or the end of a walk): one instance of each leaf routine
+                is_leaf = true;
+                if (lk == 1u) {
+                    if (!(DIAG && (P.ablate & 32u))) {
+                        switch (lst) {
+                        case 8: leaf_r0<8>(p, lside); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                        case 7: leaf_r0<7>(p, lside); break;
+                        case 6: leaf_r0<6>(p, lside); break;
+                        case 5: leaf_r0<5>(p, lside); break;
+                        case 4: leaf_r0<4>(p, lside); break;
+                        case 3: leaf_r0<3>(p, lside); break;
+                        case 2: leaf_r0<2>(p, lside); break;
+                        default: leaf_r0<1>(p, lside); break;
+                        }
+                    }
+                } else if (lk == 4u) {
+                    if (!(DIAG && (P.ablate & 16u))) {
+                        if (lst == 2) leaf_rep<2>(p, lside, sm);
+                        else leaf_rep<1>(p, lside, sm);
+                    }
+                } else if (!(DIAG && (P.ablate & 8u))) {
+                    fkind = lk == 3u ? 2u : 1u;
+#pragma unroll 1
+                    for (uint32_t rep = 0; rep < ((DIAG && (P.ablate & 4096u)) ? 2u : 1u); ++rep)
+                        switch (lst) {
+                        case 7: leaf_scan<7>(p, ws); break;
+                        case 6: leaf_scan<6>(p, ws); break;
+                        case 5: leaf_scan<5>(p, ws); break;
+                        case 4: leaf_scan<4>(p, ws); break;
+                        case 3: leaf_scan<3>(p, ws); break;
+                        case 2: leaf_scan<2>(p, ws); break;
+                        default: leaf_scan<1>(p, ws); break;
+                        }
+                }
             }
             sm.mark(0);
             if (DIAG && (P.ablate & 4u)) fkind = 0;
-            if (fkind == 2u) fork_tail<true>(p, st, side, ws, sm);
-            else if (fkind == 1u) fork_tail<false>(p, st, side, ws, sm);
+            if (fkind == 2u) fork_tail<true>(p, lst, lside, ws, sm);
+            else if (fkind == 1u) fork_tail<false>(p, lst, lside, ws, sm);
             if (DIAG && P.cycles && grp == 0) {
                 const uint64_t t_end = __builtin_amdgcn_s_memtime();
                 if (lane == 0) P.cycles[pc] = (uint32_t)(t_end - t_start);
