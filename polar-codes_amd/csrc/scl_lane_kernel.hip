@@ -326,6 +326,7 @@ __device__ __forceinline__ uint32_t cw_add(uint32_t v)
 struct Stamps {
     uint32_t* sub;
     uint64_t t0;
+    uint32_t ab = 0;  // diagnostics: parts to run twice (PCD_ABLATE bits 16 .. 19)
     __device__ __forceinline__ void mark(int k) const
     {
         if (sub) {
@@ -614,6 +615,15 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     uint32_t own[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) own[c] = k[c];
+    if (sm.ab & 131072u) {  // (diagnostics: the merge network twice)
+        merge_level<C, 0xB1>(k);
+        merge_level<(2 * C < 8 ? 2 * C : 8), 0x4E>(k);
+        merge_level<(4 * C < 8 ? 4 * C : 8), 0x141>(k);
+        asm volatile("" : "+v"(k[0]), "+v"(k[7]));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) k[c] = c < C ? own[c] : INF;
+        asm volatile("" : "+v"(k[0]), "+v"(k[1]));
+    }
     merge_level<C, 0xB1>(k);
     merge_level<(2 * C < 8 ? 2 * C : 8), 0x4E>(k);
     merge_level<(4 * C < 8 ? 4 * C : 8), 0x141>(k);
@@ -832,16 +842,19 @@ __device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
 {
     constexpr int n = 1 << T;
     ws.init();
-    if constexpr (T <= 4) {
-        uint32_t s = 0;
-        static_for<n>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            const uint32_t b = rdu<RS(T) + i>();
-            s |= (b >> 31) << i;
-            if constexpr (i < 4) ws.hv[i] = b & 0x7FFFFFFFu;
-            else ws.tail(b & 0x7FFFFFFFu, (uint32_t)i);
+    if constexpr (T <= 6) {  // straight from the registers (stages 5 and 6 used to go through a dump in the arena: a store -> load round trip)
+        static_for<(n + 31) / 32>([&](auto Wd) {
+            constexpr int wd = decltype(Wd)::value;
+            uint32_t s = 0;
+            static_for<(n < 32 ? n : 32)>([&](auto I) {
+                constexpr int i = 32 * wd + decltype(I)::value;
+                const uint32_t b = rdu<RS(T) + i>();
+                s |= (b >> 31) << (i & 31);
+                if constexpr (i < 4) ws.hv[i] = b & 0x7FFFFFFFu;
+                else ws.tail(b & 0x7FFFFFFFu, (uint32_t)i);
+            });
+            ws.sg[wd] = s;
         });
-        ws.sg[0] = s;
     } else {
         stage_to_dump<T>(p);
         const ChunkSrc<T> x(p);
@@ -880,6 +893,11 @@ __device__ __forceinline__ void fork_tail(Path& p, uint32_t T, uint32_t side, We
 {
     const uint32_t n = 1u << T;
     uint32_t wv[4], wi[4];
+    if (sm.ab & 65536u) {  // (diagnostics: the weak-LLR order twice)
+        bool r = ws.finish_fast(wv, wi, T);
+        asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wi[0]), "+v"(ws.hv[0]), "+v"(ws.tv[0]), "+v"(ws.tp[0]));
+        (void)r;
+    }
     if (ballot64(!ws.finish_fast(wv, wi, T)) != 0) ws.finish(n, SPC ? 4u : 2u, wv, wi);  // (equal magnitudes somewhere in the wave)
     const float m = p.metric;
     constexpr int C = SPC ? 8 : 4;
@@ -1290,10 +1308,13 @@ __device__ __forceinline__ void op_fg7(Path& p, uint32_t absmask, uint32_t signm
 }
 
 template <int KIND, int T>
-__device__ __forceinline__ void op_fg_reg(Path& p, uint32_t absmask, uint32_t signmask)
+__device__ __forceinline__ void op_fg_reg(Path& p, uint32_t absmask, uint32_t signmask, bool twice = false)
 {
     if constexpr (KIND == 0) f_reg<T>(absmask);
-    else if constexpr (KIND == 1) g_reg<T>(p.owner(T) << 2, signmask);
+    else if constexpr (KIND == 1) {
+        g_reg<T>(p.owner(T) << 2, signmask);
+        if (twice) g_reg<T>(p.owner(T) << 2, signmask);  // (diagnostics: the op is idempotent until its slot field is set)
+    }
     else g0_reg<T>();
     if (KIND != 0) p.set_field(T);
     p.set_field(T - 1);
@@ -1349,13 +1370,16 @@ void scl_lane_kernel(const DecodeParams P)
             if (op == OP_END) break;
             uint64_t t_start = 0;
             if (DIAG && P.cycles && grp == 0) t_start = __builtin_amdgcn_s_memtime();
-            Stamps sm{ nullptr, t_start };
+            Stamps sm{ nullptr, t_start, DIAG ? P.ablate : 0u };
             if (DIAG && P.cycles && grp == 0 && (P.ablate & 256u)) sm.sub = P.cycles + P.prog_len + 4 * pc;  // (PCD_ABLATE=256: phase stamps)
             bool is_leaf = false;
             uint32_t fkind = 0;  // forking leaf: 1 RateOne, 2 SPC
             uint32_t lk = 0, lst = st, lside = side;  // leaf to run behind the switch: kind, stage, side
             WeakScan ws;
-            switch (op) {
+            uint32_t opx = op;
+#pragma unroll 1
+          for (uint32_t again = 0; again < ((DIAG && (P.ablate & 32768u)) ? 2u : 1u); ++again, opx = 0xFFu)  // (PCD_ABLATE=32768: every dispatch twice, the second one of nothing)
+            switch (opx) {
             case LN_VT:
                 if (!(DIAG && (P.ablate & 1u))) op_vt(p, off, chan, absmask, signmask);
                 if (DIAG && (P.ablate & 1024u)) op_vt(p, off, chan, absmask, signmask);  // (idempotent: costed by doing it twice)
@@ -1393,11 +1417,11 @@ void scl_lane_kernel(const DecodeParams P)
                         switch (gs) {
                         case 8: op_fg8(p, 1, absmask, signmask); break;
                         case 7: op_fg7<1>(p, absmask, signmask); break;
-                        case 6: op_fg_reg<1, 6>(p, absmask, signmask); break;
-                        case 5: op_fg_reg<1, 5>(p, absmask, signmask); break;
-                        case 4: op_fg_reg<1, 4>(p, absmask, signmask); break;
-                        case 3: op_fg_reg<1, 3>(p, absmask, signmask); break;
-                        default: op_fg_reg<1, 2>(p, absmask, signmask); break;
+                        case 6: op_fg_reg<1, 6>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                        case 5: op_fg_reg<1, 5>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                        case 4: op_fg_reg<1, 4>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                        case 3: op_fg_reg<1, 3>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                        default: op_fg_reg<1, 2>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
                         }
                     } else {
                         switch (gs) {
