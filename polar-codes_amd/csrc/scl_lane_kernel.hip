@@ -1200,11 +1200,11 @@ __device__ __forceinline__ void op_vt_first(Path& p, const float* chan, uint32_t
     vt_load<VT_SET1>(rowp + 32);
     vt_load<VT_SET2>(rowp + 64);
     vt_load<VT_SET3>(rowp + 96);
-    // (vt_step waits for all but the 24 youngest accesses: 8 loads per set, sets 1 .. 3 younger than set 0; the last steps
-    //  wait for everything)
+    // (vt_step's counted wait assumes the next set's loads are issued in front of every step; here nothing follows the
+    //  four sets, so everything is waited for first)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     vt_step<VT_SET0, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off, s8base, s7addr);
     vt_step<VT_SET1, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 8192u, s8base, s7addr + 8192u);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     vt_step<VT_SET2, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 16384u, s8base, s7addr + 16384u);
     vt_step<VT_SET3, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 24576u, s8base, s7addr + 24576u);
     p.set_field(8);
