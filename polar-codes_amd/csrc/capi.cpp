@@ -76,6 +76,9 @@ struct pcd_decoder {
     pamd::Program lane_prog;
     bool has_lane = false;
     pamd::Ins* d_lane_prog = nullptr;
+    pamd::Program pair_prog;          // two-lanes-per-codeword SC kernel (sc_pair_kernel.hip)
+    bool has_pair = false;
+    pamd::Ins* d_pair_prog = nullptr;
     uint32_t* d_ext = nullptr;        // extraction masks per 32 code bits (deposit_table)
     uint32_t* d_syn_bytes = nullptr;  // nb x 256 syndrome words per output byte value
 
@@ -656,6 +659,13 @@ int ensure_device(pcd_decoder* d, pamd::DeviceScope& scope)
             const size_t b = d->lane_prog.ins.size() * sizeof(pamd::Ins);
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_lane_prog), b));
             HIP_TRY(hipMemcpy(d->d_lane_prog, d->lane_prog.ins.data(), b, hipMemcpyHostToDevice));
+        }
+        if (d->has_pair) {
+            const size_t b = d->pair_prog.ins.size() * sizeof(pamd::Ins);
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_pair_prog), b));
+            HIP_TRY(hipMemcpy(d->d_pair_prog, d->pair_prog.ins.data(), b, hipMemcpyHostToDevice));
+        }
+        if (d->has_lane || d->has_pair) {
             const std::vector<pamd::DepositWord> ext = pamd::deposit_table(d->N, d->frozen);
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_ext), ext.size() * sizeof(pamd::DepositWord)));
             HIP_TRY(hipMemcpy(d->d_ext, ext.data(), ext.size() * sizeof(pamd::DepositWord), hipMemcpyHostToDevice));
@@ -682,7 +692,7 @@ int ensure_device(pcd_decoder* d, pamd::DeviceScope& scope)
     if (d->det_dirty) {
         const std::vector<uint32_t> syn = d->det.syndrome_table(d->K);
         if (!syn.empty()) HIP_TRY(hipMemcpy(d->d_syn, syn.data(), syn.size() * 4, hipMemcpyHostToDevice));
-        if (d->has_lane && d->nb) {
+        if ((d->has_lane || d->has_pair) && d->nb) {
             // the same syndrome per (output byte, byte value): information bit 8 j + i is bit 7 - i of byte j
             std::vector<uint32_t> tb((size_t)d->nb * 256, 0u);
             for (unsigned j = 0; j < d->nb; ++j)
@@ -724,8 +734,27 @@ pamd::DecodeParams base_params(const pcd_decoder* d, const void* llr, size_t row
     return P;
 }
 
+// two-lanes-per-codeword SC kernel: 32 codewords per single-wave workgroup, 4 workgroups per CU (40 KB of LDS and all 512
+// registers of a SIMD lane each)
+int run_sc_pair(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
+{
+    P.prog = d->d_pair_prog;
+    P.ext = d->d_ext;
+    P.syn_bytes = d->d_syn_bytes;
+    P.prog_len = (uint32_t)d->pair_prog.ins.size() - 2u;
+    P.metrics = nullptr;
+    const unsigned need = (unsigned)((P.rows + 31u) / 32u);
+    unsigned per_cu = 4;
+    if (const char* e = PAMD_ENV("PCD_PAIR_BLOCKS_PER_CU")) per_cu = (unsigned)std::max(1, std::min(4, std::atoi(e)));  // experiments
+    unsigned grid = std::max(1u, std::min(need, (unsigned)d->num_cu * per_cu));
+    if (const char* e = PAMD_ENV("PCD_PAIR_GRID")) grid = (unsigned)std::max(1, std::atoi(e));  // experiments
+    HIP_TRY(pamd::launch_sc_pair(P, grid, st));
+    return PCD_OK;
+}
+
 int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
+    if (d->has_pair && !i8 && !P.cycles) return run_sc_pair(d, P, st);
     P.prog = d->d_sc_prog;
     P.prog_len = (uint32_t)d->sc_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->sc_wave_words;
@@ -1121,6 +1150,9 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
             return fail(PCD_ERR_FROZEN_SET, e);
         }
         d->has_sc = true;
+        // the two-lanes-per-codeword kernel takes the float codes it has every op for (lowered from the plain program,
+        // before fuse_sc rewrites it for sc_decode_kernel)
+        if (!chr && !PAMD_ENV("PCD_NO_PAIR")) d->has_pair = pamd::lower_pair(d->logN, d->sc_prog, d->pair_prog);
     }
     if (d->L > 1) {
         pamd::compile_scl(d->N, d->frozen, d->scl_prog, chr);
@@ -1168,6 +1200,7 @@ void pcd_destroy(pcd_decoder* d)
         (void)hipFree(d->d_sc_prog);
         (void)hipFree(d->d_scl_prog);
         if (d->d_lane_prog) (void)hipFree(d->d_lane_prog);
+        if (d->d_pair_prog) (void)hipFree(d->d_pair_prog);
         if (d->d_ext) (void)hipFree(d->d_ext);
         if (d->d_syn_bytes) (void)hipFree(d->d_syn_bytes);
         (void)hipFree(d->d_lut);
@@ -1274,6 +1307,13 @@ int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4])
         info[3] = (unsigned)(kMaxLds / ((size_t)d->scl_wpb * d->scl_wave_words * 4));
     } else {
         if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
+        if (d->has_pair) {  // two lanes per codeword: 40 KB of LDS per wave of 32 codewords, 4 waves per CU
+            info[0] = 40960 / 32;
+            info[1] = 32;
+            info[2] = 1;
+            info[3] = 4;
+            return PCD_OK;
+        }
         info[0] = d->sc_wave_words * 4;
         info[1] = d->sc_wpb * (64u >> d->sc_lcl);
         info[2] = 1;

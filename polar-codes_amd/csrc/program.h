@@ -93,6 +93,27 @@ enum Op : uint8_t {
     // then Fs from stage f1 down to f0, then an all-frozen leaf of stage r0 (side r0side) if the descent ends at one.
     // off: c0 | c1 << 4 | gs << 8 | kind << 12 | f1 << 16 | f0 << 20 | r0 << 24 | r0side << 28 (0 = absent)
     LN_WALK,
+    // ---- two-lanes-per-codeword SC kernel (sc_pair_kernel.hip): 32 codewords per wave ---------------------------------------
+    // Lowered from the plain SC program by lower_pair (pair_program.cpp).  `stage` = LOCAL stage T = log2(block) - 1 (the
+    // parent block for F / G / G0R / C / C0R / RONE), `side` = 1 when the finished block is a right child.
+    PR_F = 96,
+    PR_G,
+    PR_G0R,
+    PR_C,
+    PR_C0R,
+    PR_RONE,
+    PR_R0,
+    PR_R1,
+    PR_REP,
+    PR_SPC,
+    PR_DREP,
+    PR_DSPC,
+    PR_DSPC8,
+    PR_TREP,
+    PR_TYPE5,
+    PR_REPONE8,
+    PR_ZSPC8,
+    PR_ZEROSPC,
 };
 
 struct Ins {
@@ -119,6 +140,10 @@ std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program
 // program of the lane-per-path kernel.  Returns false when the tree needs an op that kernel does not have (a leaf above
 // stage 8, ...): the caller then keeps the path-group kernels.
 bool lower_lane(unsigned logN, const Program& scl, Program& out);
+// Lowers a plain SC program (compile_sc output, float decoder) of a code with N = 1024 to the program of the
+// two-lanes-per-codeword kernel.  Returns false when the tree needs an op that kernel does not have (a leaf or a ROne node
+// above 128 positions, ...): the caller then keeps sc_decode_kernel.
+bool lower_pair(unsigned logN, const Program& sc, Program& out);
 
 // ---- error detection -------------------------------------------------------------------------
 // All supported detectors are linear over GF(2) with a zero initial value, so

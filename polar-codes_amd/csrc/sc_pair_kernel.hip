@@ -1,0 +1,1087 @@
+// Fast-SSC decoder, two-lanes-per-codeword form: N = 1024, fp32 rows.
+//
+// Reference: FastSscAvxFloat  src/polarcode/decoding/fastssc_avx_float.cpp (nodes :148-792, createDecoder :797-896,
+// decode :940-955).  The kernel of sc_kernel.hip gives a codeword 16 lanes and keeps its tree in LDS; here a codeword
+// has TWO lanes and the tree lives in their registers, so a wave decodes 32 codewords and f / g / COMBINE are lane-local:
+//
+//   code position e of a block belongs to lane (e >> 1) & 1 of the pair, local index j = ((e >> 2) << 1) | (e & 1)
+//   -- the lanes alternate in PAIRS of positions.  Partners of f / g are e and e + h with h >= 4 (a block of 4 is always
+//   a leaf: createDecoder :797-870), so they always sit in the same lane, h / 2 apart; a lane reads its pairs of the
+//   channel row with 8-byte loads.  Every block of 2^t positions is a local block of 2^(t-1) = 2^T, T the LOCAL stage:
+//
+//   local stage T <= 6     VGPRs v[128..253], hand-allocated (the compiler is confined to v0..v103): asm blocks on fixed
+//                          register numbers, the same map as scl_lane_kernel.hip
+//   local stage 7          LDS, [16-byte chunk][lane]  (32 KB per wave)
+//   local stage 8          the lane's 256 AGPRs (v_accvgpr_write / _read; the compiler uses none)
+//   local stage 9          the channel row itself: read twice per codeword (f and g of the root)
+//   partial sums           bit-packed per lane (bit j = local index j): stages <= 7 in v[104..127], stage 8 and the
+//                          code word in LDS rows
+//
+// One wave per SIMD (4 single-wave workgroups per CU: 40 KB of LDS and all 512 registers of a SIMD lane each), 128
+// codewords in flight per CU.  What crosses the two lanes: the reductions inside the leaves (one DPP quad_perm swap
+// each), the interleave of the two half code words at the end.
+//
+// Bit-exactness: f exact; g is one fp32 addition (v_fma_f32 with a factor of +-1.0); the leaf sums keep the reference's
+// order -- the 8 strided accumulators of fold8 are 4 per lane (acc[s] of lane p is AVX lane (s & 1) + 4 (s >> 1) + 2 p),
+// every cross-lane sum the reference takes is a sum of one value per lane (commutative) or is rebuilt in full in both lanes.
+#define PAMD_POLAR_F_MINF 1
+#include "device_common.h"
+
+#include <utility>
+
+namespace pamd {
+namespace pair {
+
+// ---- register map (per lane) ---------------------------------------------------------------------------------------
+constexpr int KV = 104;      // the compiler's VGPR budget: v0 .. v103
+constexpr int RBL0 = 104;    // left-child / root output bits of local stage T <= 5: v[104 + T]
+constexpr int RBR0 = 110;    // right-child output bits of stage T <= 5: v[110 + T]
+constexpr int RBL6 = 116, RBR6 = 118;  // stage 6: 2 words each
+constexpr int RBL7 = 120, RBR7 = 124;  // stage 7: 4 words each
+__host__ __device__ constexpr int RS(int t) { return t == 1 ? 128 : t == 2 ? 130 : t == 3 ? 134 : t == 4 ? 142 : t == 5 ? 158 : 190; }
+__host__ __device__ constexpr int RB(int side, int t) { return t <= 5 ? (side ? RBR0 : RBL0) + t : t == 6 ? (side ? RBR6 : RBL6) : (side ? RBR7 : RBL7); }
+// LDS of one wave (32-bit words)
+constexpr uint32_t LDS_S7 = 0;                     // [32 chunks][64 lanes][4 words]
+constexpr uint32_t LDS_B8L = 8192;                 // stage-8 bits, left child: [8 words][64 lanes]
+constexpr uint32_t LDS_B8R = 8192 + 512;
+constexpr uint32_t LDS_X = 8192 + 1024;            // code word (local order): [16 words][64 lanes]
+constexpr uint32_t LDS_WORDS = 10240;
+constexpr uint32_t LDS_OUT = 0;                    // epilogue: information words [word][codeword of the wave] (stage 7 is dead)
+
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---- accessors for the hand-allocated registers (volatile: the compiler does not know their contents change) -------
+template <int R>
+__device__ __forceinline__ uint32_t rdu()
+{
+    uint32_t x;
+    asm volatile("v_mov_b32 %0, v[%1]" : "=v"(x) : "n"(R));
+    return x;
+}
+template <int R>
+__device__ __forceinline__ float rdf()
+{
+    return bitsf(rdu<R>());
+}
+template <int R>
+__device__ __forceinline__ void wru(uint32_t x)
+{
+    asm volatile("v_mov_b32 v[%0], %1" ::"n"(R), "v"(x));
+}
+// s = (s << 1) | sign(v[R]): the signs of a run of registers, taken from the highest index down, end up with element i at bit i
+template <int R>
+__device__ __forceinline__ void sgn_in(uint32_t& s)
+{
+    asm volatile("v_alignbit_b32 %0, %0, v[%1], 31" : "+v"(s) : "n"(R));
+}
+template <int R>
+__device__ __forceinline__ void amin_in(float& m)
+{
+    asm volatile("v_min_f32_e64 %0, |v[%1]|, %0" : "+v"(m) : "n"(R));
+}
+// e = (e << 1) | (|v[R]| == m)
+template <int R>
+__device__ __forceinline__ void eq_in(uint32_t& e, float m)
+{
+    asm volatile("v_cmp_eq_f32_e64 vcc, |v[%2]|, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(e) : "v"(m), "n"(R) : "vcc");
+}
+template <int R>
+__device__ __forceinline__ void add_in(float& a)
+{
+    asm volatile("v_add_f32 %0, %0, v[%1]" : "+v"(a) : "n"(R));
+}
+// the other lane of the pair
+__device__ __forceinline__ uint32_t px(uint32_t v) { return dpp_u32<0xB1>(v); }
+__device__ __forceinline__ float pxf(float v) { return bitsf(dpp_u32<0xB1>(fbits(v))); }
+
+// ---- f / g blocks on registers (local stages <= 6) -------------------------------------------------------------------
+// text of f over 4 consecutive elements: v[D+k] = f(v[A+k], v[B+k]), D may equal A (the xor is taken first)
+#define PR_F4T(D_, A_, B_)                                       \
+    "v_xor_b32 %[t0], v[" A_ "], v[" B_ "]\n\t"                  \
+    "v_xor_b32 %[t1], v[" A_ "+1], v[" B_ "+1]\n\t"              \
+    "v_xor_b32 %[t2], v[" A_ "+2], v[" B_ "+2]\n\t"              \
+    "v_xor_b32 %[t3], v[" A_ "+3], v[" B_ "+3]\n\t"              \
+    "v_min_f32_e64 v[" D_ "], |v[" A_ "]|, |v[" B_ "]|\n\t"      \
+    "v_min_f32_e64 v[" D_ "+1], |v[" A_ "+1]|, |v[" B_ "+1]|\n\t" \
+    "v_min_f32_e64 v[" D_ "+2], |v[" A_ "+2]|, |v[" B_ "+2]|\n\t" \
+    "v_min_f32_e64 v[" D_ "+3], |v[" A_ "+3]|, |v[" B_ "+3]|\n\t" \
+    "v_bfi_b32 v[" D_ "], %[am], v[" D_ "], %[t0]\n\t"           \
+    "v_bfi_b32 v[" D_ "+1], %[am], v[" D_ "+1], %[t1]\n\t"       \
+    "v_bfi_b32 v[" D_ "+2], %[am], v[" D_ "+2], %[t2]\n\t"       \
+    "v_bfi_b32 v[" D_ "+3], %[am], v[" D_ "+3], %[t3]\n\t"
+// text of g over 4 consecutive elements: v[D+k] = g(v[A+k], v[B+k], bit (31 - %[s0] + k) of v[W]) (D may equal A)
+#define PR_G4T(D_, A_, B_, W_)                                   \
+    "v_lshlrev_b32 %[t0], %[s0], v[" W_ "]\n\t"                  \
+    "v_lshlrev_b32 %[t1], %[s0]-1, v[" W_ "]\n\t"                \
+    "v_lshlrev_b32 %[t2], %[s0]-2, v[" W_ "]\n\t"                \
+    "v_lshlrev_b32 %[t3], %[s0]-3, v[" W_ "]\n\t"                \
+    "v_and_or_b32 %[t0], %[t0], %[sm], 1.0\n\t"                  \
+    "v_and_or_b32 %[t1], %[t1], %[sm], 1.0\n\t"                  \
+    "v_and_or_b32 %[t2], %[t2], %[sm], 1.0\n\t"                  \
+    "v_and_or_b32 %[t3], %[t3], %[sm], 1.0\n\t"                  \
+    "v_fma_f32 v[" D_ "], v[" A_ "], %[t0], v[" B_ "]\n\t"       \
+    "v_fma_f32 v[" D_ "+1], v[" A_ "+1], %[t1], v[" B_ "+1]\n\t" \
+    "v_fma_f32 v[" D_ "+2], v[" A_ "+2], %[t2], v[" B_ "+2]\n\t" \
+    "v_fma_f32 v[" D_ "+3], v[" A_ "+3], %[t3], v[" B_ "+3]\n\t"
+
+template <int G, int D, int A, int B>
+__device__ __forceinline__ void f_block(uint32_t absmask)
+{
+    static_assert(G == 1 || G == 2 || G == 4, "block size");
+    uint32_t t0, t1, t2, t3;
+    if constexpr (G == 4) {
+        asm volatile(PR_F4T("%[d]", "%[a]", "%[b]")
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [d] "n"(D), [a] "n"(A), [b] "n"(B), [am] "s"(absmask));
+    } else if constexpr (G == 2) {
+        asm volatile(
+            "v_xor_b32 %[t0], v[%[a]], v[%[b]]\n\t"
+            "v_xor_b32 %[t1], v[%[a]+1], v[%[b]+1]\n\t"
+            "v_min_f32_e64 v[%[d]], |v[%[a]]|, |v[%[b]]|\n\t"
+            "v_min_f32_e64 v[%[d]+1], |v[%[a]+1]|, |v[%[b]+1]|\n\t"
+            "v_bfi_b32 v[%[d]], %[am], v[%[d]], %[t0]\n\t"
+            "v_bfi_b32 v[%[d]+1], %[am], v[%[d]+1], %[t1]"
+            : [t0] "=&v"(t0), [t1] "=&v"(t1)
+            : [d] "n"(D), [a] "n"(A), [b] "n"(B), [am] "s"(absmask));
+    } else {
+        asm volatile(
+            "v_xor_b32 %[t0], v[%[a]], v[%[b]]\n\t"
+            "v_min_f32_e64 v[%[d]], |v[%[a]]|, |v[%[b]]|\n\t"
+            "v_bfi_b32 v[%[d]], %[am], v[%[d]], %[t0]"
+            : [t0] "=&v"(t0)
+            : [d] "n"(D), [a] "n"(A), [b] "n"(B), [am] "s"(absmask));
+    }
+}
+// llr[T-1] = f(llr[T]) on registers, T = 2 .. 6
+template <int T>
+__device__ __forceinline__ void f_reg(uint32_t absmask)
+{
+    constexpr int h = 1 << (T - 1), A = RS(T), D = RS(T - 1);
+    constexpr int G = h < 4 ? h : 4;
+    static_for<h / G>([&](auto J) {
+        constexpr int j = decltype(J)::value * G;
+        f_block<G, D + j, A + j, A + h + j>(absmask);
+    });
+}
+// llr[T-1] = a + b (ZeroRNode :232-237), T = 2 .. 6
+template <int T>
+__device__ __forceinline__ void g0_reg()
+{
+    constexpr int h = 1 << (T - 1), A = RS(T), D = RS(T - 1);
+    static_for<h>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        asm volatile("v_add_f32 v[%0], v[%1], v[%2]" ::"n"(D + i), "n"(A + i), "n"(A + h + i));
+    });
+}
+// g over G consecutive elements: v[D+k] = g(v[A+k], v[B+k], bit (31 - S0 + k) of v[W])
+template <int G, int D, int A, int B, int W, int S0>
+__device__ __forceinline__ void g_block(uint32_t signmask)
+{
+    if constexpr (G == 4) {
+        uint32_t t0, t1, t2, t3;
+        asm volatile(PR_G4T("%[d]", "%[a]", "%[b]", "%[w]")
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [d] "n"(D), [a] "n"(A), [b] "n"(B), [w] "n"(W), [s0] "n"(S0), [sm] "s"(signmask));
+    } else {
+        uint32_t t0;
+        asm volatile("v_lshlrev_b32 %[t0], %[s0], v[%[w]]\n\t"
+                     "v_and_or_b32 %[t0], %[t0], %[sm], 1.0\n\t"
+                     "v_fma_f32 v[%[d]], v[%[a]], %[t0], v[%[b]]"
+                     : [t0] "=&v"(t0)
+                     : [d] "n"(D), [a] "n"(A), [b] "n"(B), [w] "n"(W), [s0] "n"(S0), [sm] "s"(signmask));
+    }
+}
+// llr[T-1] = g(llr[T], left bits), T = 2 .. 6: the left child's bits are the word v[RBL0 + T - 1]
+template <int T>
+__device__ __forceinline__ void g_reg(uint32_t signmask)
+{
+    constexpr int h = 1 << (T - 1), A = RS(T), D = RS(T - 1), W = RBL0 + (T - 1);
+    constexpr int G = h >= 4 ? 4 : 1;
+    static_for<h / G>([&](auto J) {
+        constexpr int j = decltype(J)::value * G;
+        g_block<G, D + j, A + j, A + h + j, W, 31 - j>(signmask);
+    });
+}
+
+// ---- local stage 7 (LDS column, 16-byte chunks 1 KB apart) -> stage 6 (registers) --------------------------------------
+// Round r loads the chunks 8r .. 8r+7 into v[D .. D+31] and their partners 16+8r .. into v[T .. T+31] (the registers of
+// stage 5, dead while stage 6 is being produced), then works on them in place as they arrive.
+#define PR_RD2(c) "ds_read_b128 v[%[d]+4*" #c ":%[d]+4*" #c "+3], %[ad] offset:%[oa]+1024*" #c "\n\t" \
+                  "ds_read_b128 v[%[t]+4*" #c ":%[t]+4*" #c "+3], %[ad] offset:%[ob]+1024*" #c "\n\t"
+#define PR_WAITL(n) "s_waitcnt lgkmcnt(" #n ")\n\t"
+// chunk c of round R of the g: element 4c + k of the round is bit 4c + k of the word v[RBL6 + R]
+template <int R, int C>
+__device__ __forceinline__ void g7_chunk(uint32_t signmask)
+{
+    uint32_t u0, u1, u2, u3;
+    asm volatile("s_waitcnt lgkmcnt(%[wt])\n\t" PR_G4T("%[d]", "%[d]", "%[t]", "%[w]")
+                 : [t0] "=&v"(u0), [t1] "=&v"(u1), [t2] "=&v"(u2), [t3] "=&v"(u3)
+                 : [d] "n"(RS(6) + 32 * R + 4 * C), [t] "n"(RS(5) + 4 * C), [w] "n"(RBL6 + R), [s0] "n"(31 - 4 * C),
+                   [wt] "n"(14 - 2 * C), [sm] "s"(signmask)
+                 : "memory");
+}
+// KIND 0: f, 1: g with the bits of word v[RBL6 + R], 2: a + b
+template <int KIND, int R>
+__device__ __forceinline__ void s7_round(uint32_t addr, uint32_t absmask, uint32_t signmask)
+{
+    uint32_t t0, t1, t2, t3;
+    if constexpr (KIND == 0) {
+        asm volatile(PR_RD2(0) PR_RD2(1) PR_RD2(2) PR_RD2(3) PR_RD2(4) PR_RD2(5) PR_RD2(6) PR_RD2(7)
+                     PR_WAITL(14) PR_F4T("%[d]", "%[d]", "%[t]")
+                     PR_WAITL(12) PR_F4T("%[d]+4", "%[d]+4", "%[t]+4")
+                     PR_WAITL(10) PR_F4T("%[d]+8", "%[d]+8", "%[t]+8")
+                     PR_WAITL(8) PR_F4T("%[d]+12", "%[d]+12", "%[t]+12")
+                     PR_WAITL(6) PR_F4T("%[d]+16", "%[d]+16", "%[t]+16")
+                     PR_WAITL(4) PR_F4T("%[d]+20", "%[d]+20", "%[t]+20")
+                     PR_WAITL(2) PR_F4T("%[d]+24", "%[d]+24", "%[t]+24")
+                     PR_WAITL(0) PR_F4T("%[d]+28", "%[d]+28", "%[t]+28")
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [d] "n"(RS(6) + 32 * R), [t] "n"(RS(5)), [ad] "v"(addr), [oa] "n"(4 * LDS_S7 + 8192 * R),
+                       [ob] "n"(4 * LDS_S7 + 16384 + 8192 * R), [am] "s"(absmask)
+                     : "memory");
+    } else if constexpr (KIND == 2) {
+#define PR_ADD4(o) "v_add_f32 v[%[d]+" #o "], v[%[d]+" #o "], v[%[t]+" #o "]\n\t" "v_add_f32 v[%[d]+" #o "+1], v[%[d]+" #o "+1], v[%[t]+" #o "+1]\n\t" \
+                   "v_add_f32 v[%[d]+" #o "+2], v[%[d]+" #o "+2], v[%[t]+" #o "+2]\n\t" "v_add_f32 v[%[d]+" #o "+3], v[%[d]+" #o "+3], v[%[t]+" #o "+3]\n\t"
+        asm volatile(PR_RD2(0) PR_RD2(1) PR_RD2(2) PR_RD2(3) PR_RD2(4) PR_RD2(5) PR_RD2(6) PR_RD2(7)
+                     PR_WAITL(14) PR_ADD4(0) PR_WAITL(12) PR_ADD4(4) PR_WAITL(10) PR_ADD4(8) PR_WAITL(8) PR_ADD4(12)
+                     PR_WAITL(6) PR_ADD4(16) PR_WAITL(4) PR_ADD4(20) PR_WAITL(2) PR_ADD4(24) PR_WAITL(0) PR_ADD4(28)
+                     :
+                     : [d] "n"(RS(6) + 32 * R), [t] "n"(RS(5)), [ad] "v"(addr), [oa] "n"(4 * LDS_S7 + 8192 * R),
+                       [ob] "n"(4 * LDS_S7 + 16384 + 8192 * R)
+                     : "memory");
+#undef PR_ADD4
+    } else {
+        asm volatile(PR_RD2(0) PR_RD2(1) PR_RD2(2) PR_RD2(3) PR_RD2(4) PR_RD2(5) PR_RD2(6) PR_RD2(7)
+                     :
+                     : [d] "n"(RS(6) + 32 * R), [t] "n"(RS(5)), [ad] "v"(addr), [oa] "n"(4 * LDS_S7 + 8192 * R),
+                       [ob] "n"(4 * LDS_S7 + 16384 + 8192 * R)
+                     : "memory");
+        static_for<8>([&](auto C) { g7_chunk<R, decltype(C)::value>(signmask); });
+    }
+    (void)t0; (void)t1; (void)t2; (void)t3;
+}
+#undef PR_RD2
+template <int KIND>
+__device__ __forceinline__ void op_s7(uint32_t lane16, uint32_t absmask, uint32_t signmask)
+{
+    s7_round<KIND, 0>(lane16, absmask, signmask);
+    s7_round<KIND, 1>(lane16, absmask, signmask);
+}
+
+// ---- local stage 8 (AGPRs) -> stage 7 (LDS column) -----------------------------------------------------------------------
+// chunk c = outputs 4c .. 4c+3 from a[4c+k] and a[128+4c+k]; temporaries rotate through v[128..247] (stages <= 6 are dead)
+template <int KIND, int c>
+__device__ __forceinline__ void s8_chunk(uint32_t lane16, uint32_t absmask, uint32_t signmask)
+{
+    constexpr int X = 128 + 8 * (c % 15);
+    uint32_t t0, t1, t2, t3;
+#define PR_RDA(k) "v_accvgpr_read_b32 v[%[x]+" #k "], a[%[ia]+" #k "]\n\t" "v_accvgpr_read_b32 v[%[x]+4+" #k "], a[%[ia]+128+" #k "]\n\t"
+    if constexpr (KIND == 0) {
+        asm volatile(PR_RDA(0) PR_RDA(1) PR_RDA(2) PR_RDA(3) PR_F4T("%[x]", "%[x]", "%[x]+4")
+                     "ds_write_b128 %[ad], v[%[x]:%[x]+3] offset:%[of]"
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [x] "n"(X), [ia] "n"(4 * c), [ad] "v"(lane16), [of] "n"(4 * LDS_S7 + 1024 * c), [am] "s"(absmask)
+                     : "memory");
+    } else if constexpr (KIND == 1) {
+        asm volatile(PR_RDA(0) PR_RDA(1) PR_RDA(2) PR_RDA(3) PR_G4T("%[x]", "%[x]", "%[x]+4", "%[w]")
+                     "ds_write_b128 %[ad], v[%[x]:%[x]+3] offset:%[of]"
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [x] "n"(X), [ia] "n"(4 * c), [ad] "v"(lane16), [of] "n"(4 * LDS_S7 + 1024 * c), [w] "n"(RBL7 + (c >> 3)),
+                       [s0] "n"(31 - ((4 * c) & 31)), [sm] "s"(signmask)
+                     : "memory");
+    } else {
+        asm volatile(PR_RDA(0) PR_RDA(1) PR_RDA(2) PR_RDA(3)
+                     "v_add_f32 v[%[x]], v[%[x]], v[%[x]+4]\n\t" "v_add_f32 v[%[x]+1], v[%[x]+1], v[%[x]+5]\n\t"
+                     "v_add_f32 v[%[x]+2], v[%[x]+2], v[%[x]+6]\n\t" "v_add_f32 v[%[x]+3], v[%[x]+3], v[%[x]+7]\n\t"
+                     "ds_write_b128 %[ad], v[%[x]:%[x]+3] offset:%[of]"
+                     :
+                     : [x] "n"(X), [ia] "n"(4 * c), [ad] "v"(lane16), [of] "n"(4 * LDS_S7 + 1024 * c)
+                     : "memory");
+    }
+#undef PR_RDA
+    (void)t0; (void)t1; (void)t2; (void)t3;
+}
+template <int KIND>
+__device__ __forceinline__ void op_s8(uint32_t lane16, uint32_t absmask, uint32_t signmask)
+{
+    static_for<32>([&](auto C) { s8_chunk<KIND, decltype(C)::value>(lane16, absmask, signmask); });
+}
+
+// ---- local stage 9 (the channel row) -> stage 8 (AGPRs) -----------------------------------------------------------------
+// Step q = outputs 2q, 2q+1 from the row's pairs q and q + 128 of this lane (8-byte loads 16 q and 16 q + 2048 bytes behind
+// `rowp`, which already points at the lane's first pair).  The loads run D steps ahead through a ring in v[128..247].
+#ifndef PR_TOP_D
+#define PR_TOP_D 30
+#endif
+constexpr int TOP_D = PR_TOP_D;
+template <int Q>
+__device__ __forceinline__ void top_load(const float* rowp)
+{
+    constexpr int S = 128 + 4 * (Q % TOP_D);
+    asm volatile("global_load_dwordx2 v[%[s]:%[s]+1], %[a], off offset:%[o]\n\t"
+                 "global_load_dwordx2 v[%[s]+2:%[s]+3], %[a], off offset:%[o]+2048"
+                 :
+                 : [s] "n"(S), [a] "v"(rowp), [o] "n"(16 * Q)
+                 : "memory");
+}
+// KIND 0: f, 1: g (w = the 32 left-child bits that hold outputs 2q, 2q+1), 2: a + b
+template <int KIND, int Q>
+__device__ __forceinline__ void top_step(const float* rowp, uint32_t w, uint32_t absmask, uint32_t signmask)
+{
+    constexpr int S = 128 + 4 * (Q % TOP_D);
+    constexpr int WT = (Q + TOP_D - 1 <= 127) ? 2 * (TOP_D - 1) : 2 * (127 - Q);
+    uint32_t t0, t1;
+    if constexpr (KIND == 0) {
+        asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
+                     "v_xor_b32 %[t0], v[%[s]], v[%[s]+2]\n\t"
+                     "v_xor_b32 %[t1], v[%[s]+1], v[%[s]+3]\n\t"
+                     "v_min_f32_e64 v[%[s]], |v[%[s]]|, |v[%[s]+2]|\n\t"
+                     "v_min_f32_e64 v[%[s]+1], |v[%[s]+1]|, |v[%[s]+3]|\n\t"
+                     "v_bfi_b32 v[%[s]], %[am], v[%[s]], %[t0]\n\t"
+                     "v_bfi_b32 v[%[s]+1], %[am], v[%[s]+1], %[t1]\n\t"
+                     "v_accvgpr_write_b32 a[%[o]], v[%[s]]\n\t"
+                     "v_accvgpr_write_b32 a[%[o]+1], v[%[s]+1]"
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1)
+                     : [s] "n"(S), [o] "n"(2 * Q), [wt] "n"(WT), [am] "s"(absmask)
+                     : "memory");
+    } else if constexpr (KIND == 1) {
+        asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
+                     "v_lshlrev_b32 %[t0], %[s0], %[w]\n\t"
+                     "v_lshlrev_b32 %[t1], %[s0]-1, %[w]\n\t"
+                     "v_and_or_b32 %[t0], %[t0], %[sm], 1.0\n\t"
+                     "v_and_or_b32 %[t1], %[t1], %[sm], 1.0\n\t"
+                     "v_fma_f32 v[%[s]], v[%[s]], %[t0], v[%[s]+2]\n\t"
+                     "v_fma_f32 v[%[s]+1], v[%[s]+1], %[t1], v[%[s]+3]\n\t"
+                     "v_accvgpr_write_b32 a[%[o]], v[%[s]]\n\t"
+                     "v_accvgpr_write_b32 a[%[o]+1], v[%[s]+1]"
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1)
+                     : [s] "n"(S), [o] "n"(2 * Q), [wt] "n"(WT), [w] "v"(w), [s0] "n"(31 - ((2 * Q) & 31)), [sm] "s"(signmask)
+                     : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
+                     "v_add_f32 v[%[s]], v[%[s]], v[%[s]+2]\n\t"
+                     "v_add_f32 v[%[s]+1], v[%[s]+1], v[%[s]+3]\n\t"
+                     "v_accvgpr_write_b32 a[%[o]], v[%[s]]\n\t"
+                     "v_accvgpr_write_b32 a[%[o]+1], v[%[s]+1]"
+                     :
+                     : [s] "n"(S), [o] "n"(2 * Q), [wt] "n"(WT)
+                     : "memory");
+    }
+    (void)t0; (void)t1;
+    if constexpr (Q + TOP_D <= 127) top_load<Q + TOP_D>(rowp);
+}
+template <int KIND>
+__device__ __forceinline__ void op_top(const float* rowp, const uint32_t* lds, int lane, uint32_t absmask, uint32_t signmask)
+{
+    static_for<TOP_D>([&](auto Q) { top_load<decltype(Q)::value>(rowp); });
+    uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if constexpr (KIND == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = lds[LDS_B8L + i * 64 + lane];
+    }
+    static_for<128>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        top_step<KIND, q>(rowp, w[q >> 4], absmask, signmask);
+    });
+}
+
+// ---- partial sums ---------------------------------------------------------------------------------------------------------
+template <int T>
+struct Words { static constexpr int N = T <= 5 ? 1 : (1 << (T - 5)); };
+// the output bits of a block of local stage T: side 0 = left child (or root), 1 = right child
+template <int T>
+__device__ __forceinline__ void put_bits(uint32_t* lds, int lane, uint32_t side, const uint32_t (&w)[Words<T>::N])
+{
+    constexpr int NW = Words<T>::N;
+    if constexpr (T <= 7) {
+        if (side) {
+            static_for<NW>([&](auto I) { wru<RB(1, T) + decltype(I)::value>(w[decltype(I)::value]); });
+        } else {
+            static_for<NW>([&](auto I) { wru<RB(0, T) + decltype(I)::value>(w[decltype(I)::value]); });
+        }
+    } else if constexpr (T == 8) {
+        uint32_t* o = lds + (side ? LDS_B8R : LDS_B8L) + lane;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) o[i * 64] = w[i];
+    } else {
+        uint32_t* o = lds + LDS_X + lane;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) o[i * 64] = w[i];
+    }
+}
+// the children's bits of a block of local stage T (T - 1 <= 7: registers, 8: LDS rows)
+template <int T, int SIDE>
+__device__ __forceinline__ void get_child(const uint32_t* lds, int lane, uint32_t (&w)[Words<T - 1>::N])
+{
+    constexpr int NW = Words<T - 1>::N;
+    if constexpr (T - 1 <= 7) {
+        static_for<NW>([&](auto I) { w[decltype(I)::value] = rdu<RB(SIDE, T - 1) + decltype(I)::value>(); });
+    } else {
+        const uint32_t* s = lds + (SIDE ? LDS_B8R : LDS_B8L) + lane;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = s[i * 64];
+    }
+}
+// parent bits = [l ^ r | r] from the children's words (h = 2^(T-1) bits each)
+template <int T>
+__device__ __forceinline__ void join(const uint32_t (&l)[Words<T - 1>::N], const uint32_t (&r)[Words<T - 1>::N], uint32_t (&w)[Words<T>::N])
+{
+    constexpr int h = 1 << (T - 1);
+    if constexpr (T <= 5) {
+        w[0] = ((l[0] ^ r[0]) & ((1u << h) - 1u)) | (r[0] << h);
+    } else {
+        constexpr int NC = Words<T - 1>::N;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            w[i] = l[i] ^ r[i];
+            w[NC + i] = r[i];
+        }
+    }
+}
+// COMBINE (avx_float.h:190-197) / COMBINE_0R (:199-204, ZERO: the left child was never decoded, its bits count as 0)
+template <int T, bool ZERO>
+__device__ __forceinline__ void op_combine(uint32_t* lds, int lane, uint32_t side)
+{
+    uint32_t l[Words<T - 1>::N], r[Words<T - 1>::N], w[Words<T>::N];
+    get_child<T, 1>(lds, lane, r);
+    if constexpr (ZERO) {
+#pragma unroll
+        for (int i = 0; i < Words<T - 1>::N; ++i) l[i] = 0;
+    } else {
+        get_child<T, 0>(lds, lane, l);
+    }
+    join<T>(l, r, w);
+    put_bits<T>(lds, lane, side, w);
+}
+// signs of the registers v[R .. R+cnt), element i at bit i (cnt <= 32)
+template <int R, int CNT>
+__device__ __forceinline__ uint32_t sign_word()
+{
+    uint32_t s = 0;
+    static_for<CNT>([&](auto I) { sgn_in<R + CNT - 1 - decltype(I)::value>(s); });
+    return s;
+}
+// signs of the block of local stage T held in v[R ..)
+template <int T, int R>
+__device__ __forceinline__ void sign_words(uint32_t (&w)[Words<T>::N])
+{
+    constexpr int m = 1 << T;
+    if constexpr (m <= 32) {
+        w[0] = sign_word<R, m>();
+    } else {
+        static_for<m / 32>([&](auto I) { w[decltype(I)::value] = sign_word<R + 32 * decltype(I)::value, 32>(); });
+    }
+}
+// ROneNode::rightDecode :205-219 (T = 3 .. 6): lam = g(llr[T], left bits); bits = [left ^ sign(lam) | sign(lam)]
+template <int T>
+__device__ __forceinline__ void op_rone(uint32_t* lds, int lane, uint32_t side, uint32_t signmask)
+{
+    g_reg<T>(signmask);
+    uint32_t l[Words<T - 1>::N], r[Words<T - 1>::N], w[Words<T>::N];
+    sign_words<T - 1, RS(T - 1)>(r);
+    get_child<T, 0>(lds, lane, l);
+    join<T>(l, r, w);
+    put_bits<T>(lds, lane, side, w);
+}
+
+// ---- leaves (local stage T <= 6: the block sits in v[RS(T) ..)) ----------------------------------------------------------
+struct Lane {
+    uint32_t* lds;
+    int lane;
+    uint32_t p;  // 0 / 1: which lane of the pair
+};
+template <int T>
+__device__ __forceinline__ uint32_t maskw(int i)
+{
+    constexpr int m = 1 << T;
+    return m >= 32 ? 0xFFFFFFFFu : (i == 0 ? ((1u << (m & 31)) - 1u) : 0u);
+}
+// the 8 accumulators of fold8 ("acc = 0; acc += x[8k + v]", avx_float.h:238-243): this lane's four -- acc[s] belongs to
+// AVX lane (s & 1) + 4 (s >> 1) + 2 p
+template <int T>
+__device__ __forceinline__ void fold4(float (&acc)[4])
+{
+    constexpr int m = 1 << T;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s] = 0.0f;
+    static_for<m>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        add_in<RS(T) + i>(acc[i & 3]);
+    });
+}
+// ... all eight, in both lanes, in the reference's order
+__device__ __forceinline__ void gather8(const Lane& L, const float (&acc)[4], float (&a)[8])
+{
+    float pa[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) pa[s] = pxf(acc[s]);
+    const bool odd = L.p != 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float lo = odd ? pa[s] : acc[s], hi = odd ? acc[s] : pa[s];  // the even lane's value, the odd lane's value
+        a[(s & 1) + 4 * (s >> 1)] = lo;
+        a[(s & 1) + 4 * (s >> 1) + 2] = hi;
+    }
+}
+// _mm256_spc_right4_ps avx_float.h:289-302 on four values, two per lane (t0 = in[2p], t1 = in[2p+1]): the output signs of
+// this lane's two; flips EVERY position tied for the minimum
+__device__ __forceinline__ void spc4_pair(float t0, float t1, uint32_t& r0, uint32_t& r1)
+{
+    const float a0 = absf(t0), a1 = absf(t1);
+    float mm = a0 < a1 ? a0 : a1;
+    const float om = pxf(mm);
+    mm = om < mm ? om : mm;
+    uint32_t par = sgn(t0) ^ sgn(t1);
+    par ^= px(par);
+    r0 = sgn(t0) ^ ((par && a0 == mm) ? 1u : 0u);
+    r1 = sgn(t1) ^ ((par && a1 == mm) ? 1u : 0u);
+}
+// position e of a block for the local index j of lane p
+__device__ __forceinline__ uint32_t real_index(uint32_t j, uint32_t p) { return ((j >> 1) << 2) | (p << 1) | (j & 1u); }
+
+template <int T>
+__device__ __forceinline__ void leaf_r0(const Lane& L, uint32_t side)
+{
+    uint32_t w[Words<T>::N];
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) w[i] = 0;
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+template <int T>
+__device__ __forceinline__ void leaf_r1(const Lane& L, uint32_t side)
+{
+    uint32_t w[Words<T>::N];
+    sign_words<T, RS(T)>(w);
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// RepetitionDecoder :273-287: every bit = the sign of the block's sum (fold8, then x0 + ... + x7 left to right)
+template <int T>
+__device__ __forceinline__ void leaf_rep(const Lane& L, uint32_t side)
+{
+    float acc[4], a[8];
+    fold4<T>(acc);
+    gather8(L, acc, a);
+    const float s = ((((((a[0] + a[1]) + a[2]) + a[3]) + a[4]) + a[5]) + a[6]) + a[7];
+    uint32_t w[Words<T>::N];
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) w[i] = sgn(s) ? maskw<T>(i) : 0u;
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// hard decisions w of v[R .. R+m), their parity over the pair, and -- when it is odd -- the flip of the FIRST position of the
+// minimum magnitude (SpcDecoder :342-373, strict '<' = first index); returns the flip mask words
+template <int T, int R>
+__device__ __forceinline__ void spc_core(const Lane& L, uint32_t (&w)[Words<T>::N], uint32_t (&flip)[Words<T>::N])
+{
+    constexpr int m = 1 << T, NW = Words<T>::N;
+    sign_words<T, R>(w);
+    float mn = bitsf(0x7F800000u);
+    static_for<m>([&](auto I) { amin_in<R + decltype(I)::value>(mn); });
+    uint32_t par = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) par ^= (uint32_t)__builtin_popcount(w[i]);
+    par &= 1u;
+    par ^= px(par);
+    const float om = pxf(mn);
+    const float mall = om < mn ? om : mn;
+    uint32_t e[NW];
+    if constexpr (m <= 32) {
+        e[0] = 0;
+        static_for<m>([&](auto I) { eq_in<R + m - 1 - decltype(I)::value>(e[0], mall); });
+    } else {
+        static_for<NW>([&](auto Wd) {
+            constexpr int wd = decltype(Wd)::value;
+            e[wd] = 0;
+            static_for<32>([&](auto I) { eq_in<R + 32 * wd + 31 - decltype(I)::value>(e[wd], mall); });
+        });
+    }
+    uint32_t j = 0xFFFFu;
+    if constexpr (NW == 2) {
+        if (e[1]) j = 32u + (uint32_t)__builtin_ctz(e[1]);
+    }
+    if (e[0]) j = (uint32_t)__builtin_ctz(e[0]);
+    const uint32_t mine = j == 0xFFFFu ? 0xFFFFu : real_index(j, L.p);
+    const uint32_t other = px(mine);
+    const bool doit = par && mine < other;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) flip[i] = (doit && (j >> 5) == (uint32_t)i) ? (1u << (j & 31u)) : 0u;
+}
+template <int T>
+__device__ __forceinline__ void leaf_spc(const Lane& L, uint32_t side)
+{
+    uint32_t w[Words<T>::N], f[Words<T>::N];
+    spc_core<T, RS(T)>(L, w, f);
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) w[i] ^= f[i];
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// ZeroSpcDecoder :503-546 (block of 2^(T+1) positions > 8): SPC on y = a + b, the output is the RIGHT half's signs, twice
+template <int T>
+__device__ __forceinline__ void leaf_zerospc(const Lane& L, uint32_t side)
+{
+    constexpr int hl = 1 << (T - 1);
+    g0_reg<T>();  // y -> the registers of stage T - 1
+    uint32_t ys[Words<T - 1>::N], f[Words<T - 1>::N], r[Words<T - 1>::N], w[Words<T>::N];
+    spc_core<T - 1, RS(T - 1)>(L, ys, f);
+    sign_words<T - 1, RS(T) + hl>(r);
+#pragma unroll
+    for (int i = 0; i < Words<T - 1>::N; ++i) r[i] ^= f[i];
+    if constexpr (T <= 5) {
+        w[0] = r[0] | (r[0] << hl);
+    } else {
+        w[0] = r[0];
+        w[1] = r[0];
+    }
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// DoubleRepetitionDecoder :303-332: even positions = sign of the even sum, odd positions = sign of the odd sum
+template <int T>
+__device__ __forceinline__ void leaf_drep(const Lane& L, uint32_t side)
+{
+    float acc[4];
+    fold4<T>(acc);
+    float e, o;
+    if constexpr (T >= 2) {  // e = (a0 + a4) + (a2 + a6): one bracket per lane
+        const float eo = acc[0] + acc[2], oo = acc[1] + acc[3];
+        e = eo + pxf(eo);
+        o = oo + pxf(oo);
+    } else {  // block of 4: e = ((a0 + a2) + a4) + a6 with a4 = a6 = +0
+        e = ((acc[0] + pxf(acc[0])) + 0.0f) + 0.0f;
+        o = ((acc[1] + pxf(acc[1])) + 0.0f) + 0.0f;
+    }
+    const uint32_t pat = (sgn(e) ? 0x55555555u : 0u) | (sgn(o) ? 0xAAAAAAAAu : 0u);
+    uint32_t w[Words<T>::N];
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) w[i] = pat & maskw<T>(i);
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// DoubleSpcDecoderShort8 :473-488 (T = 2): per parity class, flip EVERY member tied for the class minimum
+__device__ __forceinline__ void leaf_dspc8(const Lane& L, uint32_t side)
+{
+    const float x0 = rdf<RS(2)>(), x1 = rdf<RS(2) + 1>(), x2 = rdf<RS(2) + 2>(), x3 = rdf<RS(2) + 3>();
+    auto cls = [&](float a, float b, uint32_t& fa, uint32_t& fb) {
+        const float aa = absf(a), ab = absf(b);
+        float mm = aa < ab ? aa : ab;
+        const float om = pxf(mm);
+        mm = om < mm ? om : mm;
+        uint32_t par = sgn(a) ^ sgn(b);
+        par ^= px(par);
+        fa = sgn(a) ^ ((par && aa == mm) ? 1u : 0u);
+        fb = sgn(b) ^ ((par && ab == mm) ? 1u : 0u);
+    };
+    uint32_t b0, b1, b2, b3;
+    cls(x0, x2, b0, b2);
+    cls(x1, x3, b1, b3);
+    const uint32_t w[1] = { b0 | (b1 << 1) | (b2 << 2) | (b3 << 3) };
+    put_bits<2>(L.lds, L.lane, side, w);
+}
+// DoubleSpcDecoder :425-466 (T >= 3): per AVX lane the LAST row with the lane minimum, per parity class the LOWEST AVX lane
+// with the class minimum; that one position is flipped when the class parity is odd
+template <int T>
+__device__ __forceinline__ void leaf_dspc(const Lane& L, uint32_t side)
+{
+    constexpr int m = 1 << T, NW = Words<T>::N;
+    uint32_t w[NW];
+    sign_words<T, RS(T)>(w);
+    float mv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mv[s] = bitsf(0x7F800000u);
+    static_for<m>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        amin_in<RS(T) + i>(mv[i & 3]);
+    });
+    uint32_t e[NW];
+    if constexpr (m <= 32) {
+        e[0] = 0;
+        static_for<m>([&](auto I) {
+            constexpr int i = m - 1 - decltype(I)::value;
+            eq_in<RS(T) + i>(e[0], mv[i & 3]);
+        });
+    } else {
+        static_for<NW>([&](auto Wd) {
+            constexpr int wd = decltype(Wd)::value;
+            e[wd] = 0;
+            static_for<32>([&](auto I) {
+                constexpr int i = 32 * wd + 31 - decltype(I)::value;
+                eq_in<RS(T) + i>(e[wd], mv[i & 3]);
+            });
+        });
+    }
+    // last local index of slot s holding its minimum
+    auto last = [&](int s) -> uint32_t {
+        const uint32_t sm = 0x11111111u << s;
+        uint32_t j = 31u - (uint32_t)__builtin_clz((e[0] & sm) | (1u << s));
+        if constexpr (NW == 2) {
+            if (e[1] & sm) j = 63u - (uint32_t)__builtin_clz(e[1] & sm);
+        }
+        return j;
+    };
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        // class c: AVX lanes c + 2p (slot c) and c + 4 + 2p (slot c + 2) of this lane, the partner's in between
+        float cm = mv[c] < mv[c + 2] ? mv[c] : mv[c + 2];
+        const float om = pxf(cm);
+        cm = om < cm ? om : cm;
+        const uint32_t mine = mv[c] == cm ? (uint32_t)c + 2u * L.p : (mv[c + 2] == cm ? (uint32_t)c + 4u + 2u * L.p : 99u);
+        const uint32_t other = px(mine);
+        const uint32_t cmask = c ? 0xAAAAAAAAu : 0x55555555u;
+        uint32_t par = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) par ^= (uint32_t)__builtin_popcount(w[i] & cmask);
+        par &= 1u;
+        par ^= px(par);
+        if (par && mine < other) {
+            const uint32_t j = mine >= 4u ? last(c + 2) : last(c);
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                if ((j >> 5) == (uint32_t)i) w[i] ^= 1u << (j & 31u);
+        }
+    }
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// TripleRepetitionDecoder :572-589 (T >= 3): t[j] = a[j] + a[j+4], spc4, bit i = sign of r[i & 3]
+template <int T>
+__device__ __forceinline__ void leaf_trep(const Lane& L, uint32_t side)
+{
+    float acc[4];
+    fold4<T>(acc);
+    uint32_t r0, r1;
+    spc4_pair(acc[0] + acc[2], acc[1] + acc[3], r0, r1);
+    const uint32_t pat = (r0 ? 0x55555555u : 0u) | (r1 ? 0xAAAAAAAAu : 0u);
+    uint32_t w[Words<T>::N];
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) w[i] = pat & maskw<T>(i);
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// TypeFiveDecoder :762-792 (FOLD: fold8 of the block, T >= 2) and RepetitionRateOneDecoderShort8 :718-739 (the block of 8
+// itself, no spc4): q = f(l[j], l[j+4]); rho = (q0 + q1) + (q2 + q3); gg = g(l[j], l[j+4], sign rho); s = spc4(gg);
+// bits 8i + j = sign rho ^ sign s[j], bits 8i + 4 + j = sign s[j]
+template <int T, bool FOLD>
+__device__ __forceinline__ void leaf_type5(const Lane& L, uint32_t side)
+{
+    float l4[4];
+    if constexpr (FOLD) {
+        fold4<T>(l4);
+    } else {
+        static_assert(T == 2, "block of 8");
+        static_for<4>([&](auto I) { l4[decltype(I)::value] = rdf<RS(2) + decltype(I)::value>(); });
+    }
+    const float q0 = polar_f(l4[0], l4[2]), q1 = polar_f(l4[1], l4[3]);
+    const float qs = q0 + q1;
+    const float rho = qs + pxf(qs);
+    const uint32_t sr = sgn(rho);
+    const float g0 = polar_g(l4[0], l4[2], sr), g1 = polar_g(l4[1], l4[3], sr);
+    uint32_t s0, s1;
+    if constexpr (FOLD) {
+        spc4_pair(g0, g1, s0, s1);
+    } else {
+        s0 = sgn(g0);
+        s1 = sgn(g1);
+    }
+    const uint32_t nib = (sr ^ s0) | ((sr ^ s1) << 1) | (s0 << 2) | (s1 << 3);
+    const uint32_t pat = nib * 0x11111111u;
+    uint32_t w[Words<T>::N];
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) w[i] = pat & maskw<T>(i);
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// ZeroSpcDecoderShort8 :556-565 (T = 2): t[j] = x[j] + x[j+4], spc4, the four signs twice
+__device__ __forceinline__ void leaf_zspc8(const Lane& L, uint32_t side)
+{
+    const float x0 = rdf<RS(2)>(), x1 = rdf<RS(2) + 1>(), x2 = rdf<RS(2) + 2>(), x3 = rdf<RS(2) + 3>();
+    uint32_t r0, r1;
+    spc4_pair(x0 + x2, x1 + x3, r0, r1);
+    const uint32_t w[1] = { r0 | (r1 << 1) | (r0 << 2) | (r1 << 3) };
+    put_bits<2>(L.lds, L.lane, side, w);
+}
+
+}  // namespace pair
+
+// =====================================================================================================================
+//  kernel
+// =====================================================================================================================
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(pair::KV)))
+void sc_pair_kernel(const DecodeParams P)
+{
+    using namespace pair;
+    // (dynamic: with a static 40 KB the compiler derives one wave per SIMD from the LDS size and then ignores the VGPR cap)
+    extern __shared__ uint32_t lds[];
+    asm volatile("" ::: "v255", "a255");  // (sizes the register file: all 256 + 256 registers of the lane)
+    const int lane = (int)threadIdx.x;
+    const uint32_t ngroups = (P.rows + 31u) >> 5;
+    const uint32_t absmask = 0x7FFFFFFFu, signmask = 0x80000000u;
+    const_u64_ptr prog = (const_u64_ptr)(const void*)P.prog;
+    const uint32_t N = P.N;
+    Lane L;
+    L.lds = lds;
+    L.lane = lane;
+    L.p = (uint32_t)lane & 1u;
+    const uint32_t lane16 = (uint32_t)lane << 4;
+
+    for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const uint32_t ci = grp * 32u + ((uint32_t)lane >> 1);
+        const bool live = ci < P.rows;
+        const uint32_t cj = live ? ci : grp * 32u;
+        const uint32_t row = P.rowidx ? P.rowidx[cj] : cj;
+        const float* rowp = reinterpret_cast<const float*>(P.llr) + (size_t)row * N + 2u * L.p;
+
+        uint64_t nraw = prog[0];
+        for (uint32_t pc = 0;; ++pc) {
+            const uint64_t raw = nraw;
+            nraw = prog[pc + 1];  // (fetched one instruction ahead; the host appends a spare word behind OP_END)
+            const uint32_t op = (uint32_t)raw & 0xFFu, st = ((uint32_t)raw >> 8) & 0xFFu, side = ((uint32_t)raw >> 16) & 0xFFu;
+            if (op == OP_END) break;
+#ifdef PAMD_DIAG
+            if ((P.ablate & 2u) && st == 9 && op <= PR_G0R) continue;  // (fault hunt: no pass over the channel row)
+#endif
+            switch (op) {
+            case PR_F:
+                switch (st) {
+                case 9: op_top<0>(rowp, lds, lane, absmask, signmask); break;
+                case 8: op_s8<0>(lane16, absmask, signmask); break;
+                case 7: op_s7<0>(lane16, absmask, signmask); break;
+                case 6: f_reg<6>(absmask); break;
+                case 5: f_reg<5>(absmask); break;
+                case 4: f_reg<4>(absmask); break;
+                case 3: f_reg<3>(absmask); break;
+                default: f_reg<2>(absmask); break;
+                }
+                break;
+            case PR_G:
+                switch (st) {
+                case 9: op_top<1>(rowp, lds, lane, absmask, signmask); break;
+                case 8: op_s8<1>(lane16, absmask, signmask); break;
+                case 7: op_s7<1>(lane16, absmask, signmask); break;
+                case 6: g_reg<6>(signmask); break;
+                case 5: g_reg<5>(signmask); break;
+                case 4: g_reg<4>(signmask); break;
+                case 3: g_reg<3>(signmask); break;
+                default: g_reg<2>(signmask); break;
+                }
+                break;
+            case PR_G0R:
+                switch (st) {
+#ifndef PR_SMALL
+                case 9: op_top<2>(rowp, lds, lane, absmask, signmask); break;
+                case 8: op_s8<2>(lane16, absmask, signmask); break;
+#endif
+                case 7: op_s7<2>(lane16, absmask, signmask); break;
+                case 6: g0_reg<6>(); break;
+                case 5: g0_reg<5>(); break;
+                case 4: g0_reg<4>(); break;
+                case 3: g0_reg<3>(); break;
+                default: g0_reg<2>(); break;
+                }
+                break;
+            case PR_C:
+                switch (st) {
+                case 9: op_combine<9, false>(lds, lane, side); break;
+                case 8: op_combine<8, false>(lds, lane, side); break;
+                case 7: op_combine<7, false>(lds, lane, side); break;
+                case 6: op_combine<6, false>(lds, lane, side); break;
+                case 5: op_combine<5, false>(lds, lane, side); break;
+                case 4: op_combine<4, false>(lds, lane, side); break;
+                case 3: op_combine<3, false>(lds, lane, side); break;
+                default: op_combine<2, false>(lds, lane, side); break;
+                }
+                break;
+            case PR_C0R:
+                switch (st) {
+                case 9: op_combine<9, true>(lds, lane, side); break;
+                case 8: op_combine<8, true>(lds, lane, side); break;
+                case 7: op_combine<7, true>(lds, lane, side); break;
+                case 6: op_combine<6, true>(lds, lane, side); break;
+                case 5: op_combine<5, true>(lds, lane, side); break;
+                case 4: op_combine<4, true>(lds, lane, side); break;
+                case 3: op_combine<3, true>(lds, lane, side); break;
+                default: op_combine<2, true>(lds, lane, side); break;
+                }
+                break;
+            case PR_RONE:
+                switch (st) {
+                case 6: op_rone<6>(lds, lane, side, signmask); break;
+                case 5: op_rone<5>(lds, lane, side, signmask); break;
+                case 4: op_rone<4>(lds, lane, side, signmask); break;
+                default: op_rone<3>(lds, lane, side, signmask); break;
+                }
+                break;
+            case PR_R0:
+                if (st == 1) leaf_r0<1>(L, side);
+                else leaf_r0<2>(L, side);
+                break;
+            case PR_R1:
+                if (st == 1) leaf_r1<1>(L, side);
+                else leaf_r1<2>(L, side);
+                break;
+#ifdef PR_SMALL
+#define PR_CASE6(FN) default: break;
+#else
+#define PR_CASE6(FN) default: FN<6>(L, side); break;
+#endif
+#define PR_LEAF_1_6(FN)                  \
+    switch (st) {                        \
+    case 1: FN<1>(L, side); break;       \
+    case 2: FN<2>(L, side); break;       \
+    case 3: FN<3>(L, side); break;       \
+    case 4: FN<4>(L, side); break;       \
+    case 5: FN<5>(L, side); break;       \
+    PR_CASE6(FN)                         \
+    }
+#define PR_LEAF_3_6(FN)                  \
+    switch (st) {                        \
+    case 3: FN<3>(L, side); break;       \
+    case 4: FN<4>(L, side); break;       \
+    case 5: FN<5>(L, side); break;       \
+    PR_CASE6(FN)                         \
+    }
+            case PR_REP: PR_LEAF_1_6(leaf_rep) break;
+            case PR_SPC: PR_LEAF_1_6(leaf_spc) break;
+            case PR_DREP: PR_LEAF_1_6(leaf_drep) break;
+            case PR_DSPC: PR_LEAF_3_6(leaf_dspc) break;
+            case PR_DSPC8: leaf_dspc8(L, side); break;
+            case PR_TREP: PR_LEAF_3_6(leaf_trep) break;
+            case PR_TYPE5:
+                switch (st) {
+                case 2: leaf_type5<2, true>(L, side); break;
+                case 3: leaf_type5<3, true>(L, side); break;
+                case 4: leaf_type5<4, true>(L, side); break;
+                case 5: leaf_type5<5, true>(L, side); break;
+                default: leaf_type5<6, true>(L, side); break;
+                }
+                break;
+            case PR_REPONE8: leaf_type5<2, false>(L, side); break;
+            case PR_ZSPC8: leaf_zspc8(L, side); break;
+            case PR_ZEROSPC: PR_LEAF_3_6(leaf_zerospc) break;
+            default: break;
+            }
+        }
+
+        // ---- output: FastSscAvxFloat::decode :940-955 -------------------------------------------------------------------
+        // this lane's half of the code word, local order: 16 words
+        uint32_t x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = lds[LDS_X + i * 64 + lane];
+        if (!P.systematic) {  // re-encode u = x G (butterfly_fip.cpp:15-63) in the local order: position distance 1 = local bit
+                              // distance 1, 2 = the other lane, 2^k (k >= 2) = local distance 2^(k-1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                uint32_t v = x[i];
+                v ^= (v >> 1) & 0x55555555u;
+                const uint32_t o = px(v);
+                v ^= L.p ? 0u : o;
+                v ^= (v >> 2) & 0x33333333u;
+                v ^= (v >> 4) & 0x0F0F0F0Fu;
+                v ^= (v >> 8) & 0x00FF00FFu;
+                v ^= (v >> 16) & 0x0000FFFFu;
+                x[i] = v;
+            }
+#pragma unroll
+            for (int hw = 1; hw < 16; hw <<= 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (!(i & hw)) x[i] ^= x[i + hw];
+            }
+        }
+        // Interleave: lane p takes the code words 16 p .. 16 p + 15 (positions 512 p ..): word 2k + hf of them = the half
+        // hf of the local word 8 p + k of BOTH lanes, pairs of bits alternating
+        uint32_t rw[16];
+        {
+            const bool odd = L.p != 0;
+            auto spread = [](uint32_t v) {  // 16 bits -> pairs of bits to the low half of every nibble
+                v = (v | (v << 8)) & 0x00FF00FFu;
+                v = (v | (v << 4)) & 0x0F0F0F0Fu;
+                return (v | (v << 2)) & 0x33333333u;
+            };
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t keep = odd ? x[8 + k] : x[k], send = odd ? x[k] : x[8 + k];
+                const uint32_t recv = px(send);
+                const uint32_t ev = odd ? recv : keep, ov = odd ? keep : recv;  // the even lane's word, the odd lane's word
+                rw[2 * k] = spread(ev & 0xFFFFu) | (spread(ov & 0xFFFFu) << 2);
+                rw[2 * k + 1] = spread(ev >> 16) | (spread(ov >> 16) << 2);
+            }
+        }
+        // information bits, packed like the output (bit t of the information word = bit 7 - t % 8 of byte t / 8): per 32 code
+        // bits a log-step bit compress with host-made move masks (program.cpp, deposit_table), strung together in a 64-bit
+        // shift register; both lanes OR their words into the LDS rows [word][codeword of the wave] (the lanes meet in the
+        // word where the second half of the code word starts)
+        WAVE_SYNC();
+        uint32_t* il = lds + LDS_OUT;
+        const uint32_t cw = (uint32_t)lane >> 1;
+        const uint32_t nwords = (P.nb + 3u) >> 2;
+        for (uint32_t j = L.p; j <= nwords; j += 2) il[j * 32 + cw] = 0;
+        WAVE_SYNC();
+        {
+            const uint4* ext = reinterpret_cast<const uint4*>(P.ext) + 32u * L.p;  // (two uint4 per code word of 32 bits)
+            uint64_t acc = 0;
+            uint32_t cur = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint4 ea = ext[2 * i], eb = ext[2 * i + 1];  // mask, base, mv0, mv1 | mv2, mv3, mv4, pad
+                const uint32_t mask = ea.x, base = ea.y;
+                const uint32_t mv[5] = { ea.z, ea.w, eb.x, eb.y, eb.z };
+                uint32_t v = rw[i] & mask;
+#pragma unroll
+                for (int s = 0; s < 5; ++s) {
+                    const uint32_t t = v & mv[s];
+                    v = (v ^ t) | (t >> (1u << s));
+                }
+                if (i == 0) cur = base;
+                acc |= (uint64_t)v << (base & 31u);
+                const uint32_t end = base + (uint32_t)__builtin_popcount(mask);
+                if ((end >> 5) != (base >> 5)) {
+                    atomicOr(&il[(base >> 5) * 32 + cw], __builtin_bswap32(__brev((uint32_t)acc)));
+                    acc >>= 32;
+                }
+                cur = end;
+            }
+            if (cur & 31u) atomicOr(&il[(cur >> 5) * 32 + cw], __builtin_bswap32(__brev((uint32_t)acc)));
+        }
+        WAVE_SYNC();
+        // detector verdict (XOR of the syndrome words of the output bytes) and the output row: the lanes take alternate words
+        uint32_t syn = 0;
+        uint8_t* orow = P.out + (size_t)row * P.nb;
+        for (uint32_t j = L.p; j < nwords; j += 2) {
+            const uint32_t word = il[j * 32 + cw];
+            if (P.det_on) {
+                const uint32_t* tb = P.syn_bytes + j * 1024u;
+                syn ^= tb[word & 255u];
+                if (4 * j + 1 < P.nb) syn ^= tb[256 + ((word >> 8) & 255u)];
+                if (4 * j + 2 < P.nb) syn ^= tb[512 + ((word >> 16) & 255u)];
+                if (4 * j + 3 < P.nb) syn ^= tb[768 + (word >> 24)];
+            }
+#ifdef PAMD_DIAG
+            if (P.ablate & 1u) continue;  // (fault hunt: no output)
+#endif
+            if (live) {
+                if (4 * j + 4 <= P.nb && (P.nb & 3u) == 0) {
+                    reinterpret_cast<uint32_t*>(orow)[j] = word;
+                } else {
+                    for (uint32_t b = 0; b < 4 && 4 * j + b < P.nb; ++b) orow[4 * j + b] = (uint8_t)(word >> (8u * b));
+                }
+            }
+        }
+        syn ^= px(syn);
+#ifdef PAMD_DIAG
+        if (!(P.ablate & 1u))
+#endif
+        if (live && L.p == 0 && P.ok) P.ok[row] = (syn == 0) ? 1 : 0;
+        WAVE_SYNC();
+    }
+}
+
+hipError_t launch_sc_pair(const DecodeParams& P, unsigned grid, hipStream_t st)
+{
+    hipLaunchKernelGGL(sc_pair_kernel, dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    return hipGetLastError();
+}
+
+}  // namespace pamd

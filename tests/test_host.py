@@ -322,7 +322,7 @@ def test_sc_builder_refuses_the_sets_the_reference_refuses(built_library):
 
 
 @pytest.mark.parametrize("N,L,cw,groups", [
-    (128, 1, 8, 1), (256, 1, 8, 1), (512, 1, 4, 1), (1024, 1, 4, 1), (4096, 1, 4, 1),        # SC: 8 lanes per codeword up to 256
+    (128, 1, 8, 1), (256, 1, 8, 1), (512, 1, 4, 1), (1024, 1, 32, 1), (4096, 1, 4, 1),       # SC: 8 lanes per codeword up to 256, 2 lanes at N = 1024 (sc_pair_kernel)
     (1024, 2, 8, 16), (1024, 4, 4, 16), (512, 8, 2, 16), (2048, 3, 4, 16),                     # 4 lanes per path up to N = 2048
     (1024, 8, 8, 64), (1024, 5, 8, 64),                                                       # lane-per-path kernel: N = 1024, 4 < L <= 8
     (4096, 2, 4, 8), (4096, 4, 2, 8), (4096, 8, 1, 8), (1024, 16, 1, 16), (4096, 32, 1, 32)])  # 8 lanes / one codeword above
