@@ -754,7 +754,7 @@ int run_sc_pair(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
 
 int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
-    if (d->has_pair && !i8 && !P.cycles) return run_sc_pair(d, P, st);
+    if (d->has_pair && !i8) return run_sc_pair(d, P, st);
     P.prog = d->d_sc_prog;
     P.prog_len = (uint32_t)d->sc_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->sc_wave_words;
@@ -1421,12 +1421,13 @@ int pcd_sc_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* 
 {
     if (!d || !llr_row || !cycles || !count) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
-    if (d->sc_lcl != 4 || d->sc_arena_cw_words)
+    if (!d->has_pair && (d->sc_lcl != 4 || d->sc_arena_cw_words))
         return fail(PCD_ERR_UNSUPPORTED, "the SC cycle profile exists for the all-LDS kernel (N <= 1024) only");
     pamd::DeviceScope scope;
     int rc = ensure_device(d, scope);
     if (rc) return rc;
-    const unsigned n = (unsigned)d->sc_prog.ins.size();
+    const pamd::Program& prog = d->has_pair ? d->pair_prog : d->sc_prog;  // (the program the kernel of this decoder runs)
+    const unsigned n = (unsigned)prog.ins.size();
     *count = n;
     uint32_t* dcyc = nullptr;
     if ((rc = grow(d->d_in, d->d_in_cap, (size_t)d->N * 4))) return rc;
@@ -1444,8 +1445,8 @@ int pcd_sc_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t* 
         HIP_TRY(hipMemcpy(h.data(), dcyc, (size_t)n * 4, hipMemcpyDeviceToHost));
         for (unsigned i = 0; i < n && i < cap; ++i) {
             cycles[i] = h[i];
-            if (ops) ops[i] = d->sc_prog.ins[i].op;
-            if (stages) stages[i] = d->sc_prog.ins[i].stage;
+            if (ops) ops[i] = prog.ins[i].op;
+            if (stages) stages[i] = prog.ins[i].stage;
         }
     }
     (void)hipFree(dcyc);

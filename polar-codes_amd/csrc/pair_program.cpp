@@ -56,6 +56,55 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out)
     }
     // the root must end in a COMBINE / COMBINE0R of the whole block: that is what fills the code word for the epilogue
     if (out.ins.empty() || (out.ins.back().op != PR_C && out.ins.back().op != PR_C0R) || out.ins.back().stage != logN - 1) return false;
+    // Fuse everything between two leaves into one PR_WALK:
+    //   word 0: op | leaf kind (op - PR_R0 + 1, 0 = none) << 8 | c0 << 12 | steps up << 16 | d1 << 20 | steps down << 24 | first step down << 28
+    //           (0 F, 1 G, 2 G0R)
+    //   word 1: 2 bits per step up (1 COMBINE, 2 COMBINE0R, 3 RONE; stages c0, c0 + 1, ...) | bit 16 + i: step i > 0 down is a G0R
+    //           (stages d1, d1 - 1, ...)
+    // The leaf's stage (one below the last step down) and every side (a finished block is a right child unless a RONE, the G or
+    // the end follows; the leaf is a left child behind an F) follow from the steps.
+    std::vector<Ins> plain;
+    plain.swap(out.ins);
+    size_t k = 0;
+    const size_t n = plain.size();
+    auto is_up = [](uint8_t op) { return op == PR_C || op == PR_C0R || op == PR_RONE; };
+    while (k < n) {
+        uint32_t c0 = 0, nup = 0, upk = 0, d1 = 0, ndn = 0, first = 0, dnk = 0, lk = 0;
+        while (k < n && is_up(plain[k].op)) {
+            if (nup == 0) c0 = plain[k].stage;
+            else if (plain[k].stage != c0 + nup) return false;
+            if (nup >= 8) return false;
+            upk |= (plain[k].op == PR_C ? 1u : plain[k].op == PR_C0R ? 2u : 3u) << (2 * nup);
+            ++nup;
+            ++k;
+        }
+        if (k < n) {
+            if (plain[k].op != PR_F && plain[k].op != PR_G && plain[k].op != PR_G0R) return false;
+            while (k < n && (plain[k].op == PR_F || plain[k].op == PR_G0R || (plain[k].op == PR_G && ndn == 0))) {
+                if (ndn == 0) {
+                    d1 = plain[k].stage;
+                    first = plain[k].op == PR_F ? 0u : plain[k].op == PR_G ? 1u : 2u;
+                } else {
+                    if (plain[k].stage + ndn != d1) return false;
+                    if (plain[k].op == PR_G0R) dnk |= 1u << ndn;
+                }
+                if (ndn >= 9) return false;
+                ++ndn;
+                ++k;
+            }
+            if (k >= n || plain[k].op < PR_R0 || plain[k].op > PR_ZEROSPC) return false;
+            if (plain[k].stage + ndn != d1) return false;
+            lk = (uint32_t)plain[k].op - PR_R0 + 1u;
+            ++k;
+        }
+        Ins w;
+        w.op = PR_WALK;
+        w.stage = (uint8_t)(lk | (c0 << 4));
+        w.side = (uint8_t)(nup | (d1 << 4));
+        w.pad = (uint8_t)(ndn | (first << 4));
+        w.off = upk | (dnk << 16);
+        out.ins.push_back(w);
+    }
     put(OP_END, 0, 0);
     put(OP_END, 0, 0);  // (the kernel fetches one instruction ahead)
     return true;

@@ -114,6 +114,7 @@ enum Op : uint8_t {
     PR_REPONE8,
     PR_ZSPC8,
     PR_ZEROSPC,
+    PR_WALK,  // everything between two leaves, the leaf included (pair_program.cpp)
 };
 
 struct Ins {

@@ -317,80 +317,128 @@ __device__ __forceinline__ void op_s8(uint32_t lane16, uint32_t absmask, uint32_
 }
 
 // ---- local stage 9 (the channel row) -> stage 8 (AGPRs) -----------------------------------------------------------------
-// Step q = outputs 2q, 2q+1 from the row's pairs q and q + 128 of this lane (8-byte loads 16 q and 16 q + 2048 bytes behind
-// `rowp`, which already points at the lane's first pair).  The loads run D steps ahead through a ring in v[128..247].
-#ifndef PR_TOP_D
-#define PR_TOP_D 30
-#endif
-constexpr int TOP_D = PR_TOP_D;
-template <int Q>
-__device__ __forceinline__ void top_load(const float* rowp)
+// A lane reading its own pairs of its own row would touch 32 different 128-byte lines per load instruction, 16 bytes of
+// each.  Instead the wave fetches whole lines -- eight lanes per row, 16 bytes each, four instructions for one line of
+// each of the 32 rows -- and transposes them through the LDS (the stage-7 area, dead during this pass): line step L takes
+// the lines L and L + 16 of every row (positions 32 L .. and 512 + 32 L ..), the lane pair of a row reads its 16 + 16
+// values back as 8-byte pieces and produces the local outputs 16 L .. 16 L + 15 -> a[16 L ..].
+// LDS unit (16 bytes) of (row, segment) = row * 8 + ((segment + row + (row >> 3)) & 7): the 64 lanes of a read spread over
+// all banks twice (the minimum for 512 bytes).  Two buffers of 8 KB (line L, line L + 16), loads two steps ahead.
+struct TopAddr {
+    const float* rp[4];  // this lane's piece of the rows (lane >> 3) + 8 i of the group (line 0)
+    uint32_t wa[4];      // LDS byte address of that piece
+    uint32_t ra[8];      // LDS byte address of the k-th pair of this lane's row
+};
+constexpr int TOP_WORK = 192;  // v[192..207]: the pairs of line L, v[208..223]: of line L + 16
+template <int L_>
+__device__ __forceinline__ void top_load(const TopAddr& A)
 {
-    constexpr int S = 128 + 4 * (Q % TOP_D);
-    asm volatile("global_load_dwordx2 v[%[s]:%[s]+1], %[a], off offset:%[o]\n\t"
-                 "global_load_dwordx2 v[%[s]+2:%[s]+3], %[a], off offset:%[o]+2048"
+    constexpr int S = 128 + 32 * (L_ & 1);
+    const float *r0 = A.rp[0], *r1 = A.rp[1], *r2 = A.rp[2], *r3 = A.rp[3];
+    asm volatile("global_load_dwordx4 v[%[s]:%[s]+3], %[r0], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+4:%[s]+7], %[r1], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+8:%[s]+11], %[r2], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+12:%[s]+15], %[r3], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+16:%[s]+19], %[r0], off offset:%[o]+2048\n\t"
+                 "global_load_dwordx4 v[%[s]+20:%[s]+23], %[r1], off offset:%[o]+2048\n\t"
+                 "global_load_dwordx4 v[%[s]+24:%[s]+27], %[r2], off offset:%[o]+2048\n\t"
+                 "global_load_dwordx4 v[%[s]+28:%[s]+31], %[r3], off offset:%[o]+2048"
                  :
-                 : [s] "n"(S), [a] "v"(rowp), [o] "n"(16 * Q)
+                 : [s] "n"(S), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [o] "n"(128 * L_)
                  : "memory");
 }
-// KIND 0: f, 1: g (w = the 32 left-child bits that hold outputs 2q, 2q+1), 2: a + b
-template <int KIND, int Q>
-__device__ __forceinline__ void top_step(const float* rowp, uint32_t w, uint32_t absmask, uint32_t signmask)
+// KIND 0: f, 1: g (w = the left-child word that holds the bits of the outputs 16 L ..), 2: a + b
+template <int KIND, int L_, int M>
+__device__ __forceinline__ void top_chunk(uint32_t w, uint32_t absmask, uint32_t signmask)
 {
-    constexpr int S = 128 + 4 * (Q % TOP_D);
-    constexpr int WT = (Q + TOP_D - 1 <= 127) ? 2 * (TOP_D - 1) : 2 * (127 - Q);
-    uint32_t t0, t1;
+    constexpr int X = TOP_WORK + 4 * M, Y = TOP_WORK + 16 + 4 * M, O = 16 * L_ + 4 * M;
+    uint32_t t0, t1, t2, t3;
+#define PR_WRA "v_accvgpr_write_b32 a[%[o]], v[%[x]]\n\t" "v_accvgpr_write_b32 a[%[o]+1], v[%[x]+1]\n\t" \
+               "v_accvgpr_write_b32 a[%[o]+2], v[%[x]+2]\n\t" "v_accvgpr_write_b32 a[%[o]+3], v[%[x]+3]"
     if constexpr (KIND == 0) {
-        asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
-                     "v_xor_b32 %[t0], v[%[s]], v[%[s]+2]\n\t"
-                     "v_xor_b32 %[t1], v[%[s]+1], v[%[s]+3]\n\t"
-                     "v_min_f32_e64 v[%[s]], |v[%[s]]|, |v[%[s]+2]|\n\t"
-                     "v_min_f32_e64 v[%[s]+1], |v[%[s]+1]|, |v[%[s]+3]|\n\t"
-                     "v_bfi_b32 v[%[s]], %[am], v[%[s]], %[t0]\n\t"
-                     "v_bfi_b32 v[%[s]+1], %[am], v[%[s]+1], %[t1]\n\t"
-                     "v_accvgpr_write_b32 a[%[o]], v[%[s]]\n\t"
-                     "v_accvgpr_write_b32 a[%[o]+1], v[%[s]+1]"
-                     : [t0] "=&v"(t0), [t1] "=&v"(t1)
-                     : [s] "n"(S), [o] "n"(2 * Q), [wt] "n"(WT), [am] "s"(absmask)
+        asm volatile("s_waitcnt lgkmcnt(%[wt])\n\t" PR_F4T("%[x]", "%[x]", "%[y]") PR_WRA
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [x] "n"(X), [y] "n"(Y), [o] "n"(O), [wt] "n"(12 - 4 * M), [am] "s"(absmask)
                      : "memory");
     } else if constexpr (KIND == 1) {
-        asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
+        asm volatile("s_waitcnt lgkmcnt(%[wt])\n\t"
                      "v_lshlrev_b32 %[t0], %[s0], %[w]\n\t"
                      "v_lshlrev_b32 %[t1], %[s0]-1, %[w]\n\t"
+                     "v_lshlrev_b32 %[t2], %[s0]-2, %[w]\n\t"
+                     "v_lshlrev_b32 %[t3], %[s0]-3, %[w]\n\t"
                      "v_and_or_b32 %[t0], %[t0], %[sm], 1.0\n\t"
                      "v_and_or_b32 %[t1], %[t1], %[sm], 1.0\n\t"
-                     "v_fma_f32 v[%[s]], v[%[s]], %[t0], v[%[s]+2]\n\t"
-                     "v_fma_f32 v[%[s]+1], v[%[s]+1], %[t1], v[%[s]+3]\n\t"
-                     "v_accvgpr_write_b32 a[%[o]], v[%[s]]\n\t"
-                     "v_accvgpr_write_b32 a[%[o]+1], v[%[s]+1]"
-                     : [t0] "=&v"(t0), [t1] "=&v"(t1)
-                     : [s] "n"(S), [o] "n"(2 * Q), [wt] "n"(WT), [w] "v"(w), [s0] "n"(31 - ((2 * Q) & 31)), [sm] "s"(signmask)
+                     "v_and_or_b32 %[t2], %[t2], %[sm], 1.0\n\t"
+                     "v_and_or_b32 %[t3], %[t3], %[sm], 1.0\n\t"
+                     "v_fma_f32 v[%[x]], v[%[x]], %[t0], v[%[y]]\n\t"
+                     "v_fma_f32 v[%[x]+1], v[%[x]+1], %[t1], v[%[y]+1]\n\t"
+                     "v_fma_f32 v[%[x]+2], v[%[x]+2], %[t2], v[%[y]+2]\n\t"
+                     "v_fma_f32 v[%[x]+3], v[%[x]+3], %[t3], v[%[y]+3]\n\t" PR_WRA
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [x] "n"(X), [y] "n"(Y), [o] "n"(O), [wt] "n"(12 - 4 * M), [w] "v"(w), [s0] "n"(31 - (16 * (L_ & 1) + 4 * M)),
+                       [sm] "s"(signmask)
                      : "memory");
     } else {
-        asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
-                     "v_add_f32 v[%[s]], v[%[s]], v[%[s]+2]\n\t"
-                     "v_add_f32 v[%[s]+1], v[%[s]+1], v[%[s]+3]\n\t"
-                     "v_accvgpr_write_b32 a[%[o]], v[%[s]]\n\t"
-                     "v_accvgpr_write_b32 a[%[o]+1], v[%[s]+1]"
+        asm volatile("s_waitcnt lgkmcnt(%[wt])\n\t"
+                     "v_add_f32 v[%[x]], v[%[x]], v[%[y]]\n\t" "v_add_f32 v[%[x]+1], v[%[x]+1], v[%[y]+1]\n\t"
+                     "v_add_f32 v[%[x]+2], v[%[x]+2], v[%[y]+2]\n\t" "v_add_f32 v[%[x]+3], v[%[x]+3], v[%[y]+3]\n\t" PR_WRA
                      :
-                     : [s] "n"(S), [o] "n"(2 * Q), [wt] "n"(WT)
+                     : [x] "n"(X), [y] "n"(Y), [o] "n"(O), [wt] "n"(12 - 4 * M)
                      : "memory");
     }
-    (void)t0; (void)t1;
-    if constexpr (Q + TOP_D <= 127) top_load<Q + TOP_D>(rowp);
+#undef PR_WRA
+    (void)t0; (void)t1; (void)t2; (void)t3;
+}
+template <int KIND, int L_>
+__device__ __forceinline__ void top_step(const TopAddr& A, uint32_t w, uint32_t absmask, uint32_t signmask)
+{
+    constexpr int S = 128 + 32 * (L_ & 1), BUF = 8192 * (L_ & 1);
+    {
+        const uint32_t w0 = A.wa[0], w1 = A.wa[1], w2 = A.wa[2], w3 = A.wa[3];
+        asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
+                     "ds_write_b128 %[w0], v[%[s]:%[s]+3] offset:%[b]\n\t"
+                     "ds_write_b128 %[w1], v[%[s]+4:%[s]+7] offset:%[b]\n\t"
+                     "ds_write_b128 %[w2], v[%[s]+8:%[s]+11] offset:%[b]\n\t"
+                     "ds_write_b128 %[w3], v[%[s]+12:%[s]+15] offset:%[b]\n\t"
+                     "ds_write_b128 %[w0], v[%[s]+16:%[s]+19] offset:%[b]+4096\n\t"
+                     "ds_write_b128 %[w1], v[%[s]+20:%[s]+23] offset:%[b]+4096\n\t"
+                     "ds_write_b128 %[w2], v[%[s]+24:%[s]+27] offset:%[b]+4096\n\t"
+                     "ds_write_b128 %[w3], v[%[s]+28:%[s]+31] offset:%[b]+4096"
+                     :
+                     : [s] "n"(S), [b] "n"(BUF), [wt] "n"(L_ < 15 ? 8 : 0), [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3)
+                     : "memory");
+    }
+    if constexpr (L_ + 2 <= 15) top_load<L_ + 2>(A);
+    {
+        const uint32_t r0 = A.ra[0], r1 = A.ra[1], r2 = A.ra[2], r3 = A.ra[3], r4 = A.ra[4], r5 = A.ra[5], r6 = A.ra[6], r7 = A.ra[7];
+#define PR_RD(k) "ds_read_b64 v[%[x]+2*" #k ":%[x]+2*" #k "+1], %[r" #k "] offset:%[b]\n\t" \
+                 "ds_read_b64 v[%[x]+16+2*" #k ":%[x]+16+2*" #k "+1], %[r" #k "] offset:%[b]+4096\n\t"
+        // (issued as A0 B0 A1 B1 ...: chunk m of four outputs needs the first 4 (m + 1) reads)
+        asm volatile(PR_RD(0) PR_RD(1) PR_RD(2) PR_RD(3) PR_RD(4) PR_RD(5) PR_RD(6) PR_RD(7)
+                     :
+                     : [x] "n"(TOP_WORK), [b] "n"(BUF), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [r4] "v"(r4), [r5] "v"(r5),
+                       [r6] "v"(r6), [r7] "v"(r7)
+                     : "memory");
+#undef PR_RD
+    }
+    top_chunk<KIND, L_, 0>(w, absmask, signmask);
+    top_chunk<KIND, L_, 1>(w, absmask, signmask);
+    top_chunk<KIND, L_, 2>(w, absmask, signmask);
+    top_chunk<KIND, L_, 3>(w, absmask, signmask);
 }
 template <int KIND>
-__device__ __forceinline__ void op_top(const float* rowp, const uint32_t* lds, int lane, uint32_t absmask, uint32_t signmask)
+__device__ __forceinline__ void op_top(const TopAddr& A, const uint32_t* lds, int lane, uint32_t absmask, uint32_t signmask)
 {
-    static_for<TOP_D>([&](auto Q) { top_load<decltype(Q)::value>(rowp); });
+    top_load<0>(A);
+    top_load<1>(A);
     uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if constexpr (KIND == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[i] = lds[LDS_B8L + i * 64 + lane];
     }
-    static_for<128>([&](auto Q) {
-        constexpr int q = decltype(Q)::value;
-        top_step<KIND, q>(rowp, w[q >> 4], absmask, signmask);
+    static_for<16>([&](auto Q) {
+        constexpr int l = decltype(Q)::value;
+        top_step<KIND, l>(A, w[l >> 1], absmask, signmask);
     });
 }
 
@@ -825,107 +873,127 @@ void sc_pair_kernel(const DecodeParams P)
     L.lane = lane;
     L.p = (uint32_t)lane & 1u;
     const uint32_t lane16 = (uint32_t)lane << 4;
+    TopAddr TA;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t r = ((uint32_t)lane >> 3) + 8u * (uint32_t)i, seg = (uint32_t)lane & 7u;
+        TA.wa[i] = 4u * LDS_S7 + r * 128u + ((seg + r + (r >> 3)) & 7u) * 16u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t r = (uint32_t)lane >> 1;
+        TA.ra[k] = 4u * LDS_S7 + r * 128u + (((uint32_t)k + r + (r >> 3)) & 7u) * 16u + 8u * L.p;
+    }
 
     for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const uint32_t ci = grp * 32u + ((uint32_t)lane >> 1);
         const bool live = ci < P.rows;
         const uint32_t cj = live ? ci : grp * 32u;
         const uint32_t row = P.rowidx ? P.rowidx[cj] : cj;
-        const float* rowp = reinterpret_cast<const float*>(P.llr) + (size_t)row * N + 2u * L.p;
+        // the pieces of the channel rows this lane fetches for the wave (whole 128-byte lines, eight lanes per row)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t ri = grp * 32u + ((uint32_t)lane >> 3) + 8u * (uint32_t)i;
+            const uint32_t rj = ri < P.rows ? ri : grp * 32u;
+            const uint32_t rr = P.rowidx ? P.rowidx[rj] : rj;
+            TA.rp[i] = reinterpret_cast<const float*>(P.llr) + (size_t)rr * N + 4u * ((uint32_t)lane & 7u);
+        }
 
         uint64_t nraw = prog[0];
         for (uint32_t pc = 0;; ++pc) {
             const uint64_t raw = nraw;
             nraw = prog[pc + 1];  // (fetched one instruction ahead; the host appends a spare word behind OP_END)
-            const uint32_t op = (uint32_t)raw & 0xFFu, st = ((uint32_t)raw >> 8) & 0xFFu, side = ((uint32_t)raw >> 16) & 0xFFu;
-            if (op == OP_END) break;
+            const uint32_t lo = (uint32_t)raw, hi = (uint32_t)(raw >> 32);
+            if ((lo & 0xFFu) == OP_END) break;
 #ifdef PAMD_DIAG
-            if ((P.ablate & 2u) && st == 9 && op <= PR_G0R) continue;  // (fault hunt: no pass over the channel row)
+            uint64_t t_start = 0;
+            if (P.cycles && grp == 0) t_start = __builtin_amdgcn_s_memtime();
 #endif
-            switch (op) {
-            case PR_F:
-                switch (st) {
-                case 9: op_top<0>(rowp, lds, lane, absmask, signmask); break;
-                case 8: op_s8<0>(lane16, absmask, signmask); break;
-                case 7: op_s7<0>(lane16, absmask, signmask); break;
-                case 6: f_reg<6>(absmask); break;
-                case 5: f_reg<5>(absmask); break;
-                case 4: f_reg<4>(absmask); break;
-                case 3: f_reg<3>(absmask); break;
-                default: f_reg<2>(absmask); break;
+            // PR_WALK (pair_program.cpp): everything between two leaves in one instruction -- the blocks finished on the way up
+            // (COMBINE / COMBINE0R / RONE at consecutive stages c0 ..), the way down to the next leaf (G or G0R or F first, then
+            // F / G0R at consecutive stages d1, d1 - 1, ...), the leaf.  Plain loops with a flat switch per step.
+            const uint32_t lk = (lo >> 8) & 15u, c0 = (lo >> 12) & 15u, nup = (lo >> 16) & 15u, d1 = (lo >> 20) & 15u, ndn = (lo >> 24) & 15u;
+            const uint32_t first = (lo >> 28) & 3u;  // first step down: 0 F, 1 G, 2 G0R
+            const uint32_t upk = hi & 0xFFFFu;       // 2 bits per step up: 1 COMBINE, 2 COMBINE0R, 3 RONE
+            const uint32_t dnk = hi >> 16;           // bit i: step i (> 0) down is a G0R (else F)
+#pragma unroll 1
+            for (uint32_t i = 0; i < nup; ++i) {
+                const uint32_t st = c0 + i, kind = (upk >> (2u * i)) & 3u;
+                // the finished block is a right child unless what follows takes it as a left child (RONE, the G, the end)
+                const uint32_t side = (i + 1u < nup && ((upk >> (2u * i + 2u)) & 3u) != 3u) ? 1u : 0u;
+                if (kind == 1u) {
+                    switch (st) {
+                    case 9: op_combine<9, false>(lds, lane, side); break;
+                    case 8: op_combine<8, false>(lds, lane, side); break;
+                    case 7: op_combine<7, false>(lds, lane, side); break;
+                    case 6: op_combine<6, false>(lds, lane, side); break;
+                    case 5: op_combine<5, false>(lds, lane, side); break;
+                    case 4: op_combine<4, false>(lds, lane, side); break;
+                    case 3: op_combine<3, false>(lds, lane, side); break;
+                    default: op_combine<2, false>(lds, lane, side); break;
+                    }
+                } else if (kind == 2u) {
+                    switch (st) {
+                    case 9: op_combine<9, true>(lds, lane, side); break;
+                    case 8: op_combine<8, true>(lds, lane, side); break;
+                    case 7: op_combine<7, true>(lds, lane, side); break;
+                    case 6: op_combine<6, true>(lds, lane, side); break;
+                    case 5: op_combine<5, true>(lds, lane, side); break;
+                    case 4: op_combine<4, true>(lds, lane, side); break;
+                    case 3: op_combine<3, true>(lds, lane, side); break;
+                    default: op_combine<2, true>(lds, lane, side); break;
+                    }
+                } else {
+                    switch (st) {
+                    case 6: op_rone<6>(lds, lane, side, signmask); break;
+                    case 5: op_rone<5>(lds, lane, side, signmask); break;
+                    case 4: op_rone<4>(lds, lane, side, signmask); break;
+                    default: op_rone<3>(lds, lane, side, signmask); break;
+                    }
                 }
-                break;
-            case PR_G:
-                switch (st) {
-                case 9: op_top<1>(rowp, lds, lane, absmask, signmask); break;
-                case 8: op_s8<1>(lane16, absmask, signmask); break;
-                case 7: op_s7<1>(lane16, absmask, signmask); break;
-                case 6: g_reg<6>(signmask); break;
-                case 5: g_reg<5>(signmask); break;
-                case 4: g_reg<4>(signmask); break;
-                case 3: g_reg<3>(signmask); break;
-                default: g_reg<2>(signmask); break;
+            }
+            uint32_t lastk = 0;
+#pragma unroll 1
+            for (uint32_t i = 0; i < ndn; ++i) {
+                const uint32_t st = d1 - i, kind = i == 0 ? first : (((dnk >> i) & 1u) ? 2u : 0u);
+                lastk = kind;
+                if (kind == 0u) {
+                    switch (st) {
+                    case 9: op_top<0>(TA, lds, lane, absmask, signmask); break;
+                    case 8: op_s8<0>(lane16, absmask, signmask); break;
+                    case 7: op_s7<0>(lane16, absmask, signmask); break;
+                    case 6: f_reg<6>(absmask); break;
+                    case 5: f_reg<5>(absmask); break;
+                    case 4: f_reg<4>(absmask); break;
+                    case 3: f_reg<3>(absmask); break;
+                    default: f_reg<2>(absmask); break;
+                    }
+                } else if (kind == 1u) {
+                    switch (st) {
+                    case 9: op_top<1>(TA, lds, lane, absmask, signmask); break;
+                    case 8: op_s8<1>(lane16, absmask, signmask); break;
+                    case 7: op_s7<1>(lane16, absmask, signmask); break;
+                    case 6: g_reg<6>(signmask); break;
+                    case 5: g_reg<5>(signmask); break;
+                    case 4: g_reg<4>(signmask); break;
+                    case 3: g_reg<3>(signmask); break;
+                    default: g_reg<2>(signmask); break;
+                    }
+                } else {
+                    switch (st) {
+                    case 9: op_top<2>(TA, lds, lane, absmask, signmask); break;
+                    case 8: op_s8<2>(lane16, absmask, signmask); break;
+                    case 7: op_s7<2>(lane16, absmask, signmask); break;
+                    case 6: g0_reg<6>(); break;
+                    case 5: g0_reg<5>(); break;
+                    case 4: g0_reg<4>(); break;
+                    case 3: g0_reg<3>(); break;
+                    default: g0_reg<2>(); break;
+                    }
                 }
-                break;
-            case PR_G0R:
-                switch (st) {
-#ifndef PR_SMALL
-                case 9: op_top<2>(rowp, lds, lane, absmask, signmask); break;
-                case 8: op_s8<2>(lane16, absmask, signmask); break;
-#endif
-                case 7: op_s7<2>(lane16, absmask, signmask); break;
-                case 6: g0_reg<6>(); break;
-                case 5: g0_reg<5>(); break;
-                case 4: g0_reg<4>(); break;
-                case 3: g0_reg<3>(); break;
-                default: g0_reg<2>(); break;
-                }
-                break;
-            case PR_C:
-                switch (st) {
-                case 9: op_combine<9, false>(lds, lane, side); break;
-                case 8: op_combine<8, false>(lds, lane, side); break;
-                case 7: op_combine<7, false>(lds, lane, side); break;
-                case 6: op_combine<6, false>(lds, lane, side); break;
-                case 5: op_combine<5, false>(lds, lane, side); break;
-                case 4: op_combine<4, false>(lds, lane, side); break;
-                case 3: op_combine<3, false>(lds, lane, side); break;
-                default: op_combine<2, false>(lds, lane, side); break;
-                }
-                break;
-            case PR_C0R:
-                switch (st) {
-                case 9: op_combine<9, true>(lds, lane, side); break;
-                case 8: op_combine<8, true>(lds, lane, side); break;
-                case 7: op_combine<7, true>(lds, lane, side); break;
-                case 6: op_combine<6, true>(lds, lane, side); break;
-                case 5: op_combine<5, true>(lds, lane, side); break;
-                case 4: op_combine<4, true>(lds, lane, side); break;
-                case 3: op_combine<3, true>(lds, lane, side); break;
-                default: op_combine<2, true>(lds, lane, side); break;
-                }
-                break;
-            case PR_RONE:
-                switch (st) {
-                case 6: op_rone<6>(lds, lane, side, signmask); break;
-                case 5: op_rone<5>(lds, lane, side, signmask); break;
-                case 4: op_rone<4>(lds, lane, side, signmask); break;
-                default: op_rone<3>(lds, lane, side, signmask); break;
-                }
-                break;
-            case PR_R0:
-                if (st == 1) leaf_r0<1>(L, side);
-                else leaf_r0<2>(L, side);
-                break;
-            case PR_R1:
-                if (st == 1) leaf_r1<1>(L, side);
-                else leaf_r1<2>(L, side);
-                break;
-#ifdef PR_SMALL
-#define PR_CASE6(FN) default: break;
-#else
-#define PR_CASE6(FN) default: FN<6>(L, side); break;
-#endif
+            }
+            if (lk) {  // the leaf the way down ends at: its stage is one below the last step, it is a left child behind an F
+                const uint32_t st = d1 - ndn, side = lastk != 0u ? 1u : 0u;
 #define PR_LEAF_1_6(FN)                  \
     switch (st) {                        \
     case 1: FN<1>(L, side); break;       \
@@ -933,35 +1001,53 @@ void sc_pair_kernel(const DecodeParams P)
     case 3: FN<3>(L, side); break;       \
     case 4: FN<4>(L, side); break;       \
     case 5: FN<5>(L, side); break;       \
-    PR_CASE6(FN)                         \
+    default: FN<6>(L, side); break;      \
     }
 #define PR_LEAF_3_6(FN)                  \
     switch (st) {                        \
     case 3: FN<3>(L, side); break;       \
     case 4: FN<4>(L, side); break;       \
     case 5: FN<5>(L, side); break;       \
-    PR_CASE6(FN)                         \
+    default: FN<6>(L, side); break;      \
     }
-            case PR_REP: PR_LEAF_1_6(leaf_rep) break;
-            case PR_SPC: PR_LEAF_1_6(leaf_spc) break;
-            case PR_DREP: PR_LEAF_1_6(leaf_drep) break;
-            case PR_DSPC: PR_LEAF_3_6(leaf_dspc) break;
-            case PR_DSPC8: leaf_dspc8(L, side); break;
-            case PR_TREP: PR_LEAF_3_6(leaf_trep) break;
-            case PR_TYPE5:
-                switch (st) {
-                case 2: leaf_type5<2, true>(L, side); break;
-                case 3: leaf_type5<3, true>(L, side); break;
-                case 4: leaf_type5<4, true>(L, side); break;
-                case 5: leaf_type5<5, true>(L, side); break;
-                default: leaf_type5<6, true>(L, side); break;
+                switch (lk) {
+                case PR_R0 - PR_R0 + 1:
+                    if (st == 1) leaf_r0<1>(L, side);
+                    else leaf_r0<2>(L, side);
+                    break;
+                case PR_R1 - PR_R0 + 1:
+                    if (st == 1) leaf_r1<1>(L, side);
+                    else leaf_r1<2>(L, side);
+                    break;
+                case PR_REP - PR_R0 + 1: PR_LEAF_1_6(leaf_rep) break;
+                case PR_SPC - PR_R0 + 1: PR_LEAF_1_6(leaf_spc) break;
+                case PR_DREP - PR_R0 + 1: PR_LEAF_1_6(leaf_drep) break;
+                case PR_DSPC - PR_R0 + 1: PR_LEAF_3_6(leaf_dspc) break;
+                case PR_DSPC8 - PR_R0 + 1: leaf_dspc8(L, side); break;
+                case PR_TREP - PR_R0 + 1: PR_LEAF_3_6(leaf_trep) break;
+                case PR_TYPE5 - PR_R0 + 1:
+                    switch (st) {
+                    case 2: leaf_type5<2, true>(L, side); break;
+                    case 3: leaf_type5<3, true>(L, side); break;
+                    case 4: leaf_type5<4, true>(L, side); break;
+                    case 5: leaf_type5<5, true>(L, side); break;
+                    default: leaf_type5<6, true>(L, side); break;
+                    }
+                    break;
+                case PR_REPONE8 - PR_R0 + 1: leaf_type5<2, false>(L, side); break;
+                case PR_ZSPC8 - PR_R0 + 1: leaf_zspc8(L, side); break;
+                case PR_ZEROSPC - PR_R0 + 1: PR_LEAF_3_6(leaf_zerospc) break;
+                default: break;
                 }
-                break;
-            case PR_REPONE8: leaf_type5<2, false>(L, side); break;
-            case PR_ZSPC8: leaf_zspc8(L, side); break;
-            case PR_ZEROSPC: PR_LEAF_3_6(leaf_zerospc) break;
-            default: break;
+#undef PR_LEAF_1_6
+#undef PR_LEAF_3_6
             }
+#ifdef PAMD_DIAG
+            if (P.cycles && grp == 0) {  // diagnostics: cycles this instruction took for the first group
+                const uint64_t t_end = __builtin_amdgcn_s_memtime();
+                if (lane == 0) P.cycles[pc] = (uint32_t)(t_end - t_start);
+            }
+#endif
         }
 
         // ---- output: FastSscAvxFloat::decode :940-955 -------------------------------------------------------------------

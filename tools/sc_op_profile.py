@@ -11,7 +11,9 @@ os.environ.setdefault('PYPOLAR_AMD_LIB', os.path.join(_R, 'polar-codes_amd', 'li
 import pypolar_amd
 
 names = {1: 'F', 2: 'G', 3: 'G0R', 4: 'COMBINE', 5: 'COMBINE0R', 6: 'RONE', 7: 'R0', 8: 'R1', 9: 'REP', 10: 'SPC',
-         11: 'DREP', 12: 'DSPC', 13: 'DSPC8', 14: 'TREP', 15: 'TYPE5', 16: 'REPONE8', 17: 'ZSPC8', 18: 'ZEROSPC', 0: 'END'}
+         11: 'DREP', 12: 'DSPC', 13: 'DSPC8', 14: 'TREP', 15: 'TYPE5', 16: 'REPONE8', 17: 'ZSPC8', 18: 'ZEROSPC', 0: 'END',
+         96: 'F', 97: 'G', 98: 'G0R', 99: 'C', 100: 'C0R', 101: 'RONE', 102: 'R0', 103: 'R1', 104: 'REP', 105: 'SPC', 106: 'DREP', 107: 'DSPC',
+         108: 'DSPC8', 109: 'TREP', 110: 'TYPE5', 111: 'REPONE8', 112: 'ZSPC8', 113: 'ZEROSPC'}  # (96..: sc_pair_kernel, local stages)
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2_n1024_k512_sc_awgn.bin"
 fx = gio.load_named(name)
 d = pypolar_amd.PolarDecoder(fx.N, 1, fx.frozen, "float")
