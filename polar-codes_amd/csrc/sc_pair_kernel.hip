@@ -912,135 +912,116 @@ void sc_pair_kernel(const DecodeParams P)
             // PR_WALK (pair_program.cpp): everything between two leaves in one instruction -- the blocks finished on the way up
             // (COMBINE / COMBINE0R / RONE at consecutive stages c0 ..), the way down to the next leaf (G or G0R or F first, then
             // F / G0R at consecutive stages d1, d1 - 1, ...), the leaf.  Plain loops with a flat switch per step.
-            const uint32_t lk = (lo >> 8) & 15u, c0 = (lo >> 12) & 15u, nup = (lo >> 16) & 15u, d1 = (lo >> 20) & 15u, ndn = (lo >> 24) & 15u;
+            uint32_t lk = (lo >> 8) & 15u, nup = (lo >> 16) & 15u, ndn = (lo >> 24) & 15u;
+            const uint32_t c0 = (lo >> 12) & 15u, d1 = (lo >> 20) & 15u;
+#ifdef PAMD_DIAG
+            if (P.ablate & 8u) lk = 0;    // (cost hunt: no leaves / no way up / no way down -- results are wrong)
+            if (P.ablate & 16u) nup = 0;
+            if (P.ablate & 32u) ndn = 0;
+#endif
             const uint32_t first = (lo >> 28) & 3u;  // first step down: 0 F, 1 G, 2 G0R
             const uint32_t upk = hi & 0xFFFFu;       // 2 bits per step up: 1 COMBINE, 2 COMBINE0R, 3 RONE
             const uint32_t dnk = hi >> 16;           // bit i: step i (> 0) down is a G0R (else F)
 #pragma unroll 1
             for (uint32_t i = 0; i < nup; ++i) {
-                const uint32_t st = c0 + i, kind = (upk >> (2u * i)) & 3u;
                 // the finished block is a right child unless what follows takes it as a left child (RONE, the G, the end)
                 const uint32_t side = (i + 1u < nup && ((upk >> (2u * i + 2u)) & 3u) != 3u) ? 1u : 0u;
-                if (kind == 1u) {
-                    switch (st) {
-                    case 9: op_combine<9, false>(lds, lane, side); break;
-                    case 8: op_combine<8, false>(lds, lane, side); break;
-                    case 7: op_combine<7, false>(lds, lane, side); break;
-                    case 6: op_combine<6, false>(lds, lane, side); break;
-                    case 5: op_combine<5, false>(lds, lane, side); break;
-                    case 4: op_combine<4, false>(lds, lane, side); break;
-                    case 3: op_combine<3, false>(lds, lane, side); break;
-                    default: op_combine<2, false>(lds, lane, side); break;
-                    }
-                } else if (kind == 2u) {
-                    switch (st) {
-                    case 9: op_combine<9, true>(lds, lane, side); break;
-                    case 8: op_combine<8, true>(lds, lane, side); break;
-                    case 7: op_combine<7, true>(lds, lane, side); break;
-                    case 6: op_combine<6, true>(lds, lane, side); break;
-                    case 5: op_combine<5, true>(lds, lane, side); break;
-                    case 4: op_combine<4, true>(lds, lane, side); break;
-                    case 3: op_combine<3, true>(lds, lane, side); break;
-                    default: op_combine<2, true>(lds, lane, side); break;
-                    }
-                } else {
-                    switch (st) {
-                    case 6: op_rone<6>(lds, lane, side, signmask); break;
-                    case 5: op_rone<5>(lds, lane, side, signmask); break;
-                    case 4: op_rone<4>(lds, lane, side, signmask); break;
-                    default: op_rone<3>(lds, lane, side, signmask); break;
-                    }
+                // (ONE flat switch per step: nested if / switch ladders make the compiler thread flag registers through a
+                //  structured control flow graph -- dozens of scalar instructions per step)
+                switch ((((upk >> (2u * i)) & 3u) << 4) | (c0 + i)) {
+                case 0x19: op_combine<9, false>(lds, lane, side); break;
+                case 0x18: op_combine<8, false>(lds, lane, side); break;
+                case 0x17: op_combine<7, false>(lds, lane, side); break;
+                case 0x16: op_combine<6, false>(lds, lane, side); break;
+                case 0x15: op_combine<5, false>(lds, lane, side); break;
+                case 0x14: op_combine<4, false>(lds, lane, side); break;
+                case 0x13: op_combine<3, false>(lds, lane, side); break;
+                case 0x12: op_combine<2, false>(lds, lane, side); break;
+                case 0x29: op_combine<9, true>(lds, lane, side); break;
+                case 0x28: op_combine<8, true>(lds, lane, side); break;
+                case 0x27: op_combine<7, true>(lds, lane, side); break;
+                case 0x26: op_combine<6, true>(lds, lane, side); break;
+                case 0x25: op_combine<5, true>(lds, lane, side); break;
+                case 0x24: op_combine<4, true>(lds, lane, side); break;
+                case 0x23: op_combine<3, true>(lds, lane, side); break;
+                case 0x22: op_combine<2, true>(lds, lane, side); break;
+                case 0x36: op_rone<6>(lds, lane, side, signmask); break;
+                case 0x35: op_rone<5>(lds, lane, side, signmask); break;
+                case 0x34: op_rone<4>(lds, lane, side, signmask); break;
+                case 0x33: op_rone<3>(lds, lane, side, signmask); break;
+                default: break;
                 }
             }
             uint32_t lastk = 0;
 #pragma unroll 1
             for (uint32_t i = 0; i < ndn; ++i) {
-                const uint32_t st = d1 - i, kind = i == 0 ? first : (((dnk >> i) & 1u) ? 2u : 0u);
+                const uint32_t kind = i == 0 ? first : (((dnk >> i) & 1u) ? 2u : 0u);
                 lastk = kind;
-                if (kind == 0u) {
-                    switch (st) {
-                    case 9: op_top<0>(TA, lds, lane, absmask, signmask); break;
-                    case 8: op_s8<0>(lane16, absmask, signmask); break;
-                    case 7: op_s7<0>(lane16, absmask, signmask); break;
-                    case 6: f_reg<6>(absmask); break;
-                    case 5: f_reg<5>(absmask); break;
-                    case 4: f_reg<4>(absmask); break;
-                    case 3: f_reg<3>(absmask); break;
-                    default: f_reg<2>(absmask); break;
-                    }
-                } else if (kind == 1u) {
-                    switch (st) {
-                    case 9: op_top<1>(TA, lds, lane, absmask, signmask); break;
-                    case 8: op_s8<1>(lane16, absmask, signmask); break;
-                    case 7: op_s7<1>(lane16, absmask, signmask); break;
-                    case 6: g_reg<6>(signmask); break;
-                    case 5: g_reg<5>(signmask); break;
-                    case 4: g_reg<4>(signmask); break;
-                    case 3: g_reg<3>(signmask); break;
-                    default: g_reg<2>(signmask); break;
-                    }
-                } else {
-                    switch (st) {
-                    case 9: op_top<2>(TA, lds, lane, absmask, signmask); break;
-                    case 8: op_s8<2>(lane16, absmask, signmask); break;
-                    case 7: op_s7<2>(lane16, absmask, signmask); break;
-                    case 6: g0_reg<6>(); break;
-                    case 5: g0_reg<5>(); break;
-                    case 4: g0_reg<4>(); break;
-                    case 3: g0_reg<3>(); break;
-                    default: g0_reg<2>(); break;
-                    }
+#ifdef PAMD_DIAG
+                if ((P.ablate & 64u) && d1 - i == 9u) continue;   // (cost hunt: no pass over the channel row / no stage 8 / no stage 7)
+                if ((P.ablate & 128u) && d1 - i == 8u) continue;
+                if ((P.ablate & 256u) && d1 - i == 7u) continue;
+                if ((P.ablate & 512u) && d1 - i <= 6u) continue;
+#endif
+                switch ((kind << 4) | (d1 - i)) {
+                case 0x09: op_top<0>(TA, lds, lane, absmask, signmask); break;
+                case 0x08: op_s8<0>(lane16, absmask, signmask); break;
+                case 0x07: op_s7<0>(lane16, absmask, signmask); break;
+                case 0x06: f_reg<6>(absmask); break;
+                case 0x05: f_reg<5>(absmask); break;
+                case 0x04: f_reg<4>(absmask); break;
+                case 0x03: f_reg<3>(absmask); break;
+                case 0x02: f_reg<2>(absmask); break;
+                case 0x19: op_top<1>(TA, lds, lane, absmask, signmask); break;
+                case 0x18: op_s8<1>(lane16, absmask, signmask); break;
+                case 0x17: op_s7<1>(lane16, absmask, signmask); break;
+                case 0x16: g_reg<6>(signmask); break;
+                case 0x15: g_reg<5>(signmask); break;
+                case 0x14: g_reg<4>(signmask); break;
+                case 0x13: g_reg<3>(signmask); break;
+                case 0x12: g_reg<2>(signmask); break;
+                case 0x29: op_top<2>(TA, lds, lane, absmask, signmask); break;
+                case 0x28: op_s8<2>(lane16, absmask, signmask); break;
+                case 0x27: op_s7<2>(lane16, absmask, signmask); break;
+                case 0x26: g0_reg<6>(); break;
+                case 0x25: g0_reg<5>(); break;
+                case 0x24: g0_reg<4>(); break;
+                case 0x23: g0_reg<3>(); break;
+                case 0x22: g0_reg<2>(); break;
+                default: break;
                 }
             }
             if (lk) {  // the leaf the way down ends at: its stage is one below the last step, it is a left child behind an F
-                const uint32_t st = d1 - ndn, side = lastk != 0u ? 1u : 0u;
-#define PR_LEAF_1_6(FN)                  \
-    switch (st) {                        \
-    case 1: FN<1>(L, side); break;       \
-    case 2: FN<2>(L, side); break;       \
-    case 3: FN<3>(L, side); break;       \
-    case 4: FN<4>(L, side); break;       \
-    case 5: FN<5>(L, side); break;       \
-    default: FN<6>(L, side); break;      \
-    }
-#define PR_LEAF_3_6(FN)                  \
-    switch (st) {                        \
-    case 3: FN<3>(L, side); break;       \
-    case 4: FN<4>(L, side); break;       \
-    case 5: FN<5>(L, side); break;       \
-    default: FN<6>(L, side); break;      \
-    }
-                switch (lk) {
-                case PR_R0 - PR_R0 + 1:
-                    if (st == 1) leaf_r0<1>(L, side);
-                    else leaf_r0<2>(L, side);
-                    break;
-                case PR_R1 - PR_R0 + 1:
-                    if (st == 1) leaf_r1<1>(L, side);
-                    else leaf_r1<2>(L, side);
-                    break;
-                case PR_REP - PR_R0 + 1: PR_LEAF_1_6(leaf_rep) break;
-                case PR_SPC - PR_R0 + 1: PR_LEAF_1_6(leaf_spc) break;
-                case PR_DREP - PR_R0 + 1: PR_LEAF_1_6(leaf_drep) break;
-                case PR_DSPC - PR_R0 + 1: PR_LEAF_3_6(leaf_dspc) break;
-                case PR_DSPC8 - PR_R0 + 1: leaf_dspc8(L, side); break;
-                case PR_TREP - PR_R0 + 1: PR_LEAF_3_6(leaf_trep) break;
-                case PR_TYPE5 - PR_R0 + 1:
-                    switch (st) {
-                    case 2: leaf_type5<2, true>(L, side); break;
-                    case 3: leaf_type5<3, true>(L, side); break;
-                    case 4: leaf_type5<4, true>(L, side); break;
-                    case 5: leaf_type5<5, true>(L, side); break;
-                    default: leaf_type5<6, true>(L, side); break;
-                    }
-                    break;
-                case PR_REPONE8 - PR_R0 + 1: leaf_type5<2, false>(L, side); break;
-                case PR_ZSPC8 - PR_R0 + 1: leaf_zspc8(L, side); break;
-                case PR_ZEROSPC - PR_R0 + 1: PR_LEAF_3_6(leaf_zerospc) break;
+                const uint32_t side = lastk != 0u ? 1u : 0u;
+#define PR_LF(K_, T_) (((K_) - PR_R0 + 1) << 3 | (T_))
+                switch ((lk << 3) | (d1 - ndn)) {
+                case PR_LF(PR_R0, 1): leaf_r0<1>(L, side); break;
+                case PR_LF(PR_R0, 2): leaf_r0<2>(L, side); break;
+                case PR_LF(PR_R1, 1): leaf_r1<1>(L, side); break;
+                case PR_LF(PR_R1, 2): leaf_r1<2>(L, side); break;
+#define PR_LEAF_1_6(K_, FN) case PR_LF(K_, 1): FN<1>(L, side); break; case PR_LF(K_, 2): FN<2>(L, side); break; case PR_LF(K_, 3): FN<3>(L, side); break; \
+                            case PR_LF(K_, 4): FN<4>(L, side); break; case PR_LF(K_, 5): FN<5>(L, side); break; case PR_LF(K_, 6): FN<6>(L, side); break;
+#define PR_LEAF_3_6(K_, FN) case PR_LF(K_, 3): FN<3>(L, side); break; case PR_LF(K_, 4): FN<4>(L, side); break; case PR_LF(K_, 5): FN<5>(L, side); break; \
+                            case PR_LF(K_, 6): FN<6>(L, side); break;
+                PR_LEAF_1_6(PR_REP, leaf_rep)
+                PR_LEAF_1_6(PR_SPC, leaf_spc)
+                PR_LEAF_1_6(PR_DREP, leaf_drep)
+                PR_LEAF_3_6(PR_DSPC, leaf_dspc)
+                PR_LEAF_3_6(PR_TREP, leaf_trep)
+                PR_LEAF_3_6(PR_ZEROSPC, leaf_zerospc)
+                case PR_LF(PR_DSPC8, 2): leaf_dspc8(L, side); break;
+                case PR_LF(PR_TYPE5, 2): leaf_type5<2, true>(L, side); break;
+                case PR_LF(PR_TYPE5, 3): leaf_type5<3, true>(L, side); break;
+                case PR_LF(PR_TYPE5, 4): leaf_type5<4, true>(L, side); break;
+                case PR_LF(PR_TYPE5, 5): leaf_type5<5, true>(L, side); break;
+                case PR_LF(PR_TYPE5, 6): leaf_type5<6, true>(L, side); break;
+                case PR_LF(PR_REPONE8, 2): leaf_type5<2, false>(L, side); break;
+                case PR_LF(PR_ZSPC8, 2): leaf_zspc8(L, side); break;
                 default: break;
                 }
 #undef PR_LEAF_1_6
 #undef PR_LEAF_3_6
+#undef PR_LF
             }
 #ifdef PAMD_DIAG
             if (P.cycles && grp == 0) {  // diagnostics: cycles this instruction took for the first group
@@ -1050,6 +1031,9 @@ void sc_pair_kernel(const DecodeParams P)
 #endif
         }
 
+#ifdef PAMD_DIAG
+        if (P.ablate & 4u) continue;  // (cost hunt: no epilogue)
+#endif
         // ---- output: FastSscAvxFloat::decode :940-955 -------------------------------------------------------------------
         // this lane's half of the code word, local order: 16 words
         uint32_t x[16];

@@ -323,6 +323,40 @@ def test_lane_per_path_kernel_codes(built_library, N, K, L, kind):
         assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), "path metrics differ from the oracle's"
 
 
+PAIR_CODES = [(512, 0.0, "BB"), (400, 0.0, "BB"), (640, 1.0, "BB"), (176, 0.0, "5G"), (512, 2.0, "BB"), (300, -1.0, "BB"), (768, 0.0, "BB"),
+              (256, 1.0, "BB"), (100, 0.0, "BB"), (900, 2.0, "BB"), (512, 0.0, "BE"), (448, 0.5, "BB"), (576, 3.0, "BB")]
+
+
+@pytest.mark.parametrize("K,dsnr,kind", PAIR_CODES, ids=[f"K{k}_{c}_{d}" for k, d, c in PAIR_CODES])
+def test_pair_kernel_codes(built_library, K, dsnr, kind):
+    """The two-lanes-per-codeword SC kernel (N = 1024, float) over rates and constructions -- whatever tree its lowering
+    cannot express falls back to sc_decode_kernel, the results must be the reference's either way -- on AWGN, pure-noise and
+    tie-heavy rows, ragged batch sizes (the last wave of 32 codewords partly idle), systematic and not, with and without a
+    detector."""
+    import pypolar_amd
+    N = 1024
+    rng = np.random.default_rng(K + int(10 * dsnr) + 7)
+    frozen = np.asarray(pypolar_amd.frozen_bits(N, K, dsnr, kind), dtype=np.uint32)
+    rows = 70
+    awgn = (1.0 + 0.8 * rng.standard_normal((rows, N))).astype(np.float32) * np.where(rng.random((rows, N)) < 0.5, 1, -1).astype(np.float32)
+    noise = rng.standard_normal((13, N)).astype(np.float32)
+    ties = rng.integers(-3, 4, (22, N)).astype(np.float32)
+    half = (rng.integers(-6, 7, (16, N)) / 2.0).astype(np.float32)
+    half[half == 0] = -0.0  # (negative zeros among the inputs: the leaf sums start from +0)
+    llr = np.concatenate([awgn, noise, ties, half])
+    for systematic, det in ((True, 8), (False, 32), (True, 0)):
+        e_out, e_ok, _ = ob.decode_batch(N, 1, frozen, det, llr, systematic, "float")
+        d = pypolar_amd.PolarDecoder(N, 1, frozen, "float")
+        d.setErrorDetection(det, "crc")
+        d.setSystematic(systematic)
+        if (K, kind) == (512, "BB"):
+            assert d.launch_info(False)["codewords_per_workgroup"] == 32, "the headline SC code must run on sc_pair_kernel"
+        for cnt in (len(llr), 1, 33):
+            out, ok = d.decode_batch(llr[:cnt])
+            assert np.array_equal(out, e_out[:cnt]), (K, dsnr, kind, systematic, det, cnt)
+            assert np.array_equal(ok.astype(np.uint8), e_ok[:cnt])
+
+
 def test_cpp_shim_decodes_on_gpu(built_library):
     """C++ host side (polar_decoder.hpp over the C ABI): N=8 known answer of decodingtest.cpp:1143-1173"""
     import subprocess
