@@ -754,7 +754,7 @@ int run_sc_pair(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
 
 int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
-    if (d->has_pair && !i8) return run_sc_pair(d, P, st);
+    if (d->has_pair && i8 == (d->dectype == 0)) return run_sc_pair(d, P, st);  // (fp32 rows for the float decoder, int8 rows for the int8 one)
     P.prog = d->d_sc_prog;
     P.prog_len = (uint32_t)d->sc_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->sc_wave_words;
@@ -1152,7 +1152,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         d->has_sc = true;
         // the two-lanes-per-codeword kernel takes the float codes it has every op for (lowered from the plain program,
         // before fuse_sc rewrites it for sc_decode_kernel)
-        if (!chr && !PAMD_ENV("PCD_NO_PAIR")) d->has_pair = pamd::lower_pair(d->logN, d->sc_prog, d->pair_prog);
+        if (!PAMD_ENV("PCD_NO_PAIR")) d->has_pair = pamd::lower_pair(d->logN, d->sc_prog, d->pair_prog, chr);
     }
     if (d->L > 1) {
         pamd::compile_scl(d->N, d->frozen, d->scl_prog, chr);

@@ -4,7 +4,7 @@
 
 namespace pamd {
 
-bool lower_pair(unsigned logN, const Program& sc, Program& out)
+bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr)
 {
     out = Program();
     out.leaves = sc.leaves;
@@ -19,7 +19,8 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out)
         i.off = 0;
         out.ins.push_back(i);
     };
-    for (const Ins& x : sc.ins) {
+    for (size_t xi = 0; xi < sc.ins.size(); ++xi) {
+        const Ins& x = sc.ins[xi];
         if (x.op == OP_END) break;
         const unsigned s = x.stage;  // log2 of the block the op works on (the parent block for F / G / COMBINE ...)
         if (s < 2 || s > logN) return false;
@@ -34,10 +35,21 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out)
         switch (x.op) {
         case SC_F: if (T < 2) return false; put(PR_F, T, 0); break;
         case SC_G: if (T < 2) return false; put(PR_G, T, 0); break;
-        case SC_G0R: if (T < 2) return false; put(PR_G0R, T, 0); break;
+        case SC_G0R:
+            if (chr && s == 2) {  // int8 decoder: a block of 4 whose left half is frozen and whose right half is free, as ONE leaf
+                if (xi + 2 >= sc.ins.size() || sc.ins[xi + 1].op != SC_R1 || sc.ins[xi + 1].stage != 1 || sc.ins[xi + 2].op != SC_COMBINE0R ||
+                    sc.ins[xi + 2].stage != 2)
+                    return false;
+                put(PR_ZR1, 1, side);
+                xi += 2;
+                break;
+            }
+            if (T < 2) return false;
+            put(PR_G0R, T, 0);
+            break;
         case SC_COMBINE: if (T < 2) return false; put(PR_C, T, side); break;
         case SC_COMBINE0R: if (T < 2) return false; put(PR_C0R, T, side); break;
-        case SC_RONE: if (T < 3 || T > 6) return false; put(PR_RONE, T, side); break;
+        case SC_RONE: if (T < 2 || T > 6) return false; put(PR_RONE, T, side); break;
         case SC_R0: ok = leaf(PR_R0, 1, 2); break;
         case SC_R1: ok = leaf(PR_R1, 1, 2); break;
         case SC_REP: ok = leaf(PR_REP, 1, 6); break;
@@ -50,6 +62,10 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out)
         case SC_REPONE8: ok = leaf(PR_REPONE8, 2, 2); break;
         case SC_ZSPC8: ok = leaf(PR_ZSPC8, 2, 2); break;
         case SC_ZEROSPC: ok = leaf(PR_ZEROSPC, 3, 6); break;
+        case SCC_REP: ok = chr && leaf(PR_REP, 1, 6); break;
+        case SCC_SPC: ok = chr && leaf(PR_SPC, 1, 6); break;
+        case SCC_DREP: ok = chr && leaf(PR_DREP, 4, 6); break;
+        case SCC_ZEROSPC: ok = chr && leaf(PR_ZEROSPC, 2, 6); break;
         default: return false;
         }
         if (!ok) return false;
@@ -92,7 +108,7 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out)
                 ++ndn;
                 ++k;
             }
-            if (k >= n || plain[k].op < PR_R0 || plain[k].op > PR_ZEROSPC) return false;
+            if (k >= n || plain[k].op < PR_R0 || plain[k].op > PR_ZR1) return false;
             if (plain[k].stage + ndn != d1) return false;
             lk = (uint32_t)plain[k].op - PR_R0 + 1u;
             ++k;

@@ -114,6 +114,7 @@ enum Op : uint8_t {
     PR_REPONE8,
     PR_ZSPC8,
     PR_ZEROSPC,
+    PR_ZR1,   // int8 decoder: block of 4 positions, left half frozen, right half free (G0R / RateOne / COMBINE0R of the plain program)
     PR_WALK,  // everything between two leaves, the leaf included (pair_program.cpp)
 };
 
@@ -141,10 +142,10 @@ std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program
 // program of the lane-per-path kernel.  Returns false when the tree needs an op that kernel does not have (a leaf above
 // stage 8, ...): the caller then keeps the path-group kernels.
 bool lower_lane(unsigned logN, const Program& scl, Program& out);
-// Lowers a plain SC program (compile_sc output, float decoder) of a code with N = 1024 to the program of the
+// Lowers a plain SC program (compile_sc output; chr: of the int8 decoder) of a code with N = 1024 to the program of the
 // two-lanes-per-codeword kernel.  Returns false when the tree needs an op that kernel does not have (a leaf or a ROne node
 // above 128 positions, ...): the caller then keeps sc_decode_kernel.
-bool lower_pair(unsigned logN, const Program& sc, Program& out);
+bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr = false);
 
 // ---- error detection -------------------------------------------------------------------------
 // All supported detectors are linear over GF(2) with a zero initial value, so

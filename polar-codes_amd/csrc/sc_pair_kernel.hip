@@ -103,6 +103,36 @@ __device__ __forceinline__ void add_in(float& a)
 __device__ __forceinline__ uint32_t px(uint32_t v) { return dpp_u32<0xB1>(v); }
 __device__ __forceinline__ float pxf(float v) { return bitsf(dpp_u32<0xB1>(fbits(v))); }
 
+// ---- int8 decoder (FastSscFipChar): an int8 LLR is the float of the same value, saturation is a clamp ---------------------------
+// (fip_char.h:45-74; device_common.h polar_f_char / polar_g_char are the same arithmetic in C++)
+struct Sat {
+    float c127;  // 127.0 (scalar operand)
+    float m128;  // -128.0 in a VGPR (a VALU instruction of gfx9 takes one scalar operand)
+};
+// f of the int8 decoder from the float f already in v[R .. R+CNT): magnitude clamped to [1, 127], sign kept (also of a -0)
+template <int R, int CNT>
+__device__ __forceinline__ void clamp_f(const Sat& S, uint32_t absmask)
+{
+    const float c = S.c127;
+    static_for<CNT>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        uint32_t t;
+        const float cc = c;
+        const uint32_t am = absmask;
+        asm volatile("v_med3_f32 %[t], |v[%[r]]|, 1.0, %[c]\n\tv_bfi_b32 v[%[r]], %[am], %[t], v[%[r]]" : [t] "=&v"(t) : [r] "n"(R + i), [c] "s"(cc), [am] "s"(am));
+    });
+}
+// g / a + b of the int8 decoder: clamp to [-128, 127]
+template <int R, int CNT>
+__device__ __forceinline__ void clamp_g(const Sat& S)
+{
+    static_for<CNT>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const float cc = S.c127, mm = S.m128;
+        asm volatile("v_med3_f32 v[%[r]], v[%[r]], %[m], %[c]" ::[r] "n"(R + i), [c] "s"(cc), [m] "v"(mm));
+    });
+}
+
 // ---- f / g blocks on registers (local stages <= 6) -------------------------------------------------------------------
 // text of f over 4 consecutive elements: v[D+k] = f(v[A+k], v[B+k]), D may equal A (the xor is taken first)
 #define PR_F4T(D_, A_, B_)                                       \
@@ -279,41 +309,38 @@ __device__ __forceinline__ void op_s7(uint32_t lane16, uint32_t absmask, uint32_
 
 // ---- local stage 8 (AGPRs) -> stage 7 (LDS column) -----------------------------------------------------------------------
 // chunk c = outputs 4c .. 4c+3 from a[4c+k] and a[128+4c+k]; temporaries rotate through v[128..247] (stages <= 6 are dead)
-template <int KIND, int c>
-__device__ __forceinline__ void s8_chunk(uint32_t lane16, uint32_t absmask, uint32_t signmask)
+template <bool CH, int KIND, int c>
+__device__ __forceinline__ void s8_chunk(uint32_t lane16, uint32_t absmask, uint32_t signmask, const Sat& S)
 {
     constexpr int X = 128 + 8 * (c % 15);
     uint32_t t0, t1, t2, t3;
 #define PR_RDA(k) "v_accvgpr_read_b32 v[%[x]+" #k "], a[%[ia]+" #k "]\n\t" "v_accvgpr_read_b32 v[%[x]+4+" #k "], a[%[ia]+128+" #k "]\n\t"
     if constexpr (KIND == 0) {
         asm volatile(PR_RDA(0) PR_RDA(1) PR_RDA(2) PR_RDA(3) PR_F4T("%[x]", "%[x]", "%[x]+4")
-                     "ds_write_b128 %[ad], v[%[x]:%[x]+3] offset:%[of]"
                      : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
-                     : [x] "n"(X), [ia] "n"(4 * c), [ad] "v"(lane16), [of] "n"(4 * LDS_S7 + 1024 * c), [am] "s"(absmask)
-                     : "memory");
+                     : [x] "n"(X), [ia] "n"(4 * c), [am] "s"(absmask));
+        if constexpr (CH) clamp_f<X, 4>(S, absmask);
     } else if constexpr (KIND == 1) {
         asm volatile(PR_RDA(0) PR_RDA(1) PR_RDA(2) PR_RDA(3) PR_G4T("%[x]", "%[x]", "%[x]+4", "%[w]")
-                     "ds_write_b128 %[ad], v[%[x]:%[x]+3] offset:%[of]"
                      : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
-                     : [x] "n"(X), [ia] "n"(4 * c), [ad] "v"(lane16), [of] "n"(4 * LDS_S7 + 1024 * c), [w] "n"(RBL7 + (c >> 3)),
-                       [s0] "n"(31 - ((4 * c) & 31)), [sm] "s"(signmask)
-                     : "memory");
+                     : [x] "n"(X), [ia] "n"(4 * c), [w] "n"(RBL7 + (c >> 3)), [s0] "n"(31 - ((4 * c) & 31)), [sm] "s"(signmask));
+        if constexpr (CH) clamp_g<X, 4>(S);
     } else {
         asm volatile(PR_RDA(0) PR_RDA(1) PR_RDA(2) PR_RDA(3)
                      "v_add_f32 v[%[x]], v[%[x]], v[%[x]+4]\n\t" "v_add_f32 v[%[x]+1], v[%[x]+1], v[%[x]+5]\n\t"
-                     "v_add_f32 v[%[x]+2], v[%[x]+2], v[%[x]+6]\n\t" "v_add_f32 v[%[x]+3], v[%[x]+3], v[%[x]+7]\n\t"
-                     "ds_write_b128 %[ad], v[%[x]:%[x]+3] offset:%[of]"
+                     "v_add_f32 v[%[x]+2], v[%[x]+2], v[%[x]+6]\n\t" "v_add_f32 v[%[x]+3], v[%[x]+3], v[%[x]+7]"
                      :
-                     : [x] "n"(X), [ia] "n"(4 * c), [ad] "v"(lane16), [of] "n"(4 * LDS_S7 + 1024 * c)
-                     : "memory");
+                     : [x] "n"(X), [ia] "n"(4 * c));
+        if constexpr (CH) clamp_g<X, 4>(S);
     }
 #undef PR_RDA
+    asm volatile("ds_write_b128 %[ad], v[%[x]:%[x]+3] offset:%[of]" ::[x] "n"(X), [ad] "v"(lane16), [of] "n"(4 * LDS_S7 + 1024 * c) : "memory");
     (void)t0; (void)t1; (void)t2; (void)t3;
 }
-template <int KIND>
-__device__ __forceinline__ void op_s8(uint32_t lane16, uint32_t absmask, uint32_t signmask)
+template <bool CH, int KIND>
+__device__ __forceinline__ void op_s8(uint32_t lane16, uint32_t absmask, uint32_t signmask, const Sat& S)
 {
-    static_for<32>([&](auto C) { s8_chunk<KIND, decltype(C)::value>(lane16, absmask, signmask); });
+    static_for<32>([&](auto C) { s8_chunk<CH, KIND, decltype(C)::value>(lane16, absmask, signmask, S); });
 }
 
 // ---- local stage 9 (the channel row) -> stage 8 (AGPRs) -----------------------------------------------------------------
@@ -440,6 +467,132 @@ __device__ __forceinline__ void op_top(const TopAddr& A, const uint32_t* lds, in
         constexpr int l = decltype(Q)::value;
         top_step<KIND, l>(A, w[l >> 1], absmask, signmask);
     });
+}
+
+// ---- the same pass for int8 rows (FastSscFipChar: a row is 1024 bytes = 8 lines) -----------------------------------------
+// Line step LS = lines LS and LS + 4 of every row (positions 128 LS .. and 512 + 128 LS ..) through the same LDS image; BOTH
+// lanes of a pair read the whole 128 bytes of their row (16-byte reads) and convert their own two bytes of every 32-bit word
+// (v_bfe_i32 at bit 16 p / 16 p + 8, v_cvt_f32_i32); a quarter of a line (2 units) gives the local outputs
+// 64 LS + 16 Q .. + 15 -> a[64 LS + 16 Q ..].  TopAddr::rp = byte pointers here (piece (lane & 7) of line 0), ra[u] = unit u.
+constexpr int T8_W = 192, T8_A = 208, T8_B = 224;  // v[192..207] words (A 0..7, B 8..15), v[208..223] / v[224..239] the converted values
+template <int LS>
+__device__ __forceinline__ void top8_load(const TopAddr& A)
+{
+    constexpr int S = 128 + 32 * (LS & 1);
+    const float *r0 = A.rp[0], *r1 = A.rp[1], *r2 = A.rp[2], *r3 = A.rp[3];
+    asm volatile("global_load_dwordx4 v[%[s]:%[s]+3], %[r0], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+4:%[s]+7], %[r1], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+8:%[s]+11], %[r2], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+12:%[s]+15], %[r3], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+16:%[s]+19], %[r0], off offset:%[o]+512\n\t"
+                 "global_load_dwordx4 v[%[s]+20:%[s]+23], %[r1], off offset:%[o]+512\n\t"
+                 "global_load_dwordx4 v[%[s]+24:%[s]+27], %[r2], off offset:%[o]+512\n\t"
+                 "global_load_dwordx4 v[%[s]+28:%[s]+31], %[r3], off offset:%[o]+512"
+                 :
+                 : [s] "n"(S), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [o] "n"(128 * LS)
+                 : "memory");
+}
+template <int KIND, int LS, int Q>
+__device__ __forceinline__ void top8_quarter(const TopAddr& A, uint32_t sh0, uint32_t sh1, uint32_t w, uint32_t absmask, uint32_t signmask, const Sat& S)
+{
+    constexpr int BUF = 8192 * (LS & 1);
+    {
+        const uint32_t ra = A.ra[2 * Q], rb = A.ra[2 * Q + 1];
+        asm volatile("ds_read_b128 v[%[w]:%[w]+3], %[ra] offset:%[b]\n\t"
+                     "ds_read_b128 v[%[w]+4:%[w]+7], %[rb] offset:%[b]\n\t"
+                     "ds_read_b128 v[%[w]+8:%[w]+11], %[ra] offset:%[b]+4096\n\t"
+                     "ds_read_b128 v[%[w]+12:%[w]+15], %[rb] offset:%[b]+4096\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     :
+                     : [w] "n"(T8_W), [b] "n"(BUF), [ra] "v"(ra), [rb] "v"(rb)
+                     : "memory");
+    }
+    static_for<16>([&](auto K) {  // word k (0..7: line LS, 8..15: line LS + 4) -> two values each
+        constexpr int k = decltype(K)::value;
+        constexpr int D = (k < 8 ? T8_A : T8_B) + 2 * (k & 7);
+        const uint32_t a0 = sh0, a1 = sh1;
+        asm volatile("v_bfe_i32 v[%[d]], v[%[s]], %[a0], 8\n\t"
+                     "v_bfe_i32 v[%[d]+1], v[%[s]], %[a1], 8\n\t"
+                     "v_cvt_f32_i32 v[%[d]], v[%[d]]\n\t"
+                     "v_cvt_f32_i32 v[%[d]+1], v[%[d]+1]"
+                     :
+                     : [d] "n"(D), [s] "n"(T8_W + k), [a0] "v"(a0), [a1] "v"(a1));
+    });
+    static_for<4>([&](auto M_) {
+        constexpr int M = decltype(M_)::value;
+        constexpr int X = T8_A + 4 * M, Y = T8_B + 4 * M, O = 64 * LS + 16 * Q + 4 * M;
+        uint32_t t0, t1, t2, t3;
+        const uint32_t am = absmask, sm = signmask, ww = w;
+        if constexpr (KIND == 0) {
+            asm volatile(PR_F4T("%[x]", "%[x]", "%[y]") : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3) : [x] "n"(X), [y] "n"(Y), [am] "s"(am));
+            clamp_f<X, 4>(S, am);
+        } else if constexpr (KIND == 1) {
+            asm volatile("v_lshlrev_b32 %[t0], %[s0], %[w]\n\t"
+                         "v_lshlrev_b32 %[t1], %[s0]-1, %[w]\n\t"
+                         "v_lshlrev_b32 %[t2], %[s0]-2, %[w]\n\t"
+                         "v_lshlrev_b32 %[t3], %[s0]-3, %[w]\n\t"
+                         "v_and_or_b32 %[t0], %[t0], %[sm], 1.0\n\t"
+                         "v_and_or_b32 %[t1], %[t1], %[sm], 1.0\n\t"
+                         "v_and_or_b32 %[t2], %[t2], %[sm], 1.0\n\t"
+                         "v_and_or_b32 %[t3], %[t3], %[sm], 1.0\n\t"
+                         "v_fma_f32 v[%[x]], v[%[x]], %[t0], v[%[y]]\n\t"
+                         "v_fma_f32 v[%[x]+1], v[%[x]+1], %[t1], v[%[y]+1]\n\t"
+                         "v_fma_f32 v[%[x]+2], v[%[x]+2], %[t2], v[%[y]+2]\n\t"
+                         "v_fma_f32 v[%[x]+3], v[%[x]+3], %[t3], v[%[y]+3]"
+                         : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                         : [x] "n"(X), [y] "n"(Y), [w] "v"(ww), [s0] "n"(31 - (16 * (Q & 1) + 4 * M)), [sm] "s"(sm));
+            clamp_g<X, 4>(S);
+        } else {
+            asm volatile("v_add_f32 v[%[x]], v[%[x]], v[%[y]]\n\t" "v_add_f32 v[%[x]+1], v[%[x]+1], v[%[y]+1]\n\t"
+                         "v_add_f32 v[%[x]+2], v[%[x]+2], v[%[y]+2]\n\t" "v_add_f32 v[%[x]+3], v[%[x]+3], v[%[y]+3]" ::[x] "n"(X), [y] "n"(Y));
+            clamp_g<X, 4>(S);
+        }
+        asm volatile("v_accvgpr_write_b32 a[%[o]], v[%[x]]\n\t" "v_accvgpr_write_b32 a[%[o]+1], v[%[x]+1]\n\t"
+                     "v_accvgpr_write_b32 a[%[o]+2], v[%[x]+2]\n\t" "v_accvgpr_write_b32 a[%[o]+3], v[%[x]+3]" ::[o] "n"(O), [x] "n"(X));
+        (void)t0; (void)t1; (void)t2; (void)t3;
+    });
+}
+template <int KIND, int LS>
+__device__ __forceinline__ void top8_step(const TopAddr& A, uint32_t sh0, uint32_t sh1, const uint32_t (&w)[8], uint32_t absmask, uint32_t signmask,
+                                          const Sat& S)
+{
+    constexpr int SL = 128 + 32 * (LS & 1), BUF = 8192 * (LS & 1);
+    {
+        const uint32_t w0 = A.wa[0], w1 = A.wa[1], w2 = A.wa[2], w3 = A.wa[3];
+        asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
+                     "ds_write_b128 %[w0], v[%[s]:%[s]+3] offset:%[b]\n\t"
+                     "ds_write_b128 %[w1], v[%[s]+4:%[s]+7] offset:%[b]\n\t"
+                     "ds_write_b128 %[w2], v[%[s]+8:%[s]+11] offset:%[b]\n\t"
+                     "ds_write_b128 %[w3], v[%[s]+12:%[s]+15] offset:%[b]\n\t"
+                     "ds_write_b128 %[w0], v[%[s]+16:%[s]+19] offset:%[b]+4096\n\t"
+                     "ds_write_b128 %[w1], v[%[s]+20:%[s]+23] offset:%[b]+4096\n\t"
+                     "ds_write_b128 %[w2], v[%[s]+24:%[s]+27] offset:%[b]+4096\n\t"
+                     "ds_write_b128 %[w3], v[%[s]+28:%[s]+31] offset:%[b]+4096"
+                     :
+                     : [s] "n"(SL), [b] "n"(BUF), [wt] "n"(LS < 3 ? 8 : 0), [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3)
+                     : "memory");
+    }
+    if constexpr (LS + 2 <= 3) top8_load<LS + 2>(A);
+    top8_quarter<KIND, LS, 0>(A, sh0, sh1, w[2 * LS], absmask, signmask, S);
+    top8_quarter<KIND, LS, 1>(A, sh0, sh1, w[2 * LS], absmask, signmask, S);
+    top8_quarter<KIND, LS, 2>(A, sh0, sh1, w[2 * LS + 1], absmask, signmask, S);
+    top8_quarter<KIND, LS, 3>(A, sh0, sh1, w[2 * LS + 1], absmask, signmask, S);
+}
+template <int KIND>
+__device__ __forceinline__ void op_top8(const TopAddr& A, const uint32_t* lds, int lane, uint32_t absmask, uint32_t signmask, const Sat& S)
+{
+    top8_load<0>(A);
+    top8_load<1>(A);
+    uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if constexpr (KIND == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = lds[LDS_B8L + i * 64 + lane];
+    }
+    const uint32_t sh0 = 16u * ((uint32_t)lane & 1u), sh1 = sh0 + 8u;
+    top8_step<KIND, 0>(A, sh0, sh1, w, absmask, signmask, S);
+    top8_step<KIND, 1>(A, sh0, sh1, w, absmask, signmask, S);
+    top8_step<KIND, 2>(A, sh0, sh1, w, absmask, signmask, S);
+    top8_step<KIND, 3>(A, sh0, sh1, w, absmask, signmask, S);
 }
 
 // ---- partial sums ---------------------------------------------------------------------------------------------------------
@@ -851,11 +1004,199 @@ __device__ __forceinline__ void leaf_zspc8(const Lane& L, uint32_t side)
     put_bits<2>(L.lds, L.lane, side, w);
 }
 
+// ---- leaves of the int8 decoder (fastssc_fip_char.cpp:196-395; saturating sums in the reference's order) ------------------
+__device__ __forceinline__ float sat8f(float v) { return __builtin_amdgcn_fmed3f(v, -128.0f, 127.0f); }
+// the 32 byte-lane accumulators "LlrSum = adds(LlrSum, load(LlrIn + i))" (:219-234, a block of at most 32 positions is one
+// zero-padded vector): this lane's sixteen -- v[s] belongs to byte lane 4 (s >> 1) + 2 p + (s & 1)
+template <int T>
+__device__ __forceinline__ void lane_sums16(float (&v)[16])
+{
+    constexpr int m = 1 << T;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = 0.0f;
+    static_for<(m < 16 ? m : 16)>([&](auto I) { v[decltype(I)::value] = rdf<RS(T) + decltype(I)::value>(); });
+    if constexpr (m > 16) {
+        static_for<m - 16>([&](auto I) {
+            constexpr int i = 16 + decltype(I)::value;
+            v[i & 15] = sat8f(v[i & 15] + rdf<RS(T) + i>());
+        });
+    }
+}
+// RepetitionDecoder :219-234 / ShortRepetitionDecoder :259-266: the sign of reduce_adds_epi8 (avxconvenience.h:92-101) over the
+// lane sums -- pairs (l, l + 16), (l, l + 8), (l, l + 4) are local (slots s + 8, s + 4, s + 2), (l, l + 2) is the other lane's
+// same slot, (0, 1) local again
+template <int T>
+__device__ __forceinline__ void leaf_rep_ch(const Lane& L, uint32_t side)
+{
+    float v[16];
+    lane_sums16<T>(v);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s] = sat8f(v[s] + v[s + 8]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = sat8f(v[s] + v[s + 4]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) v[s] = sat8f(v[s] + v[s + 2]);
+    const float d0 = sat8f(v[0] + pxf(v[0])), d1 = sat8f(v[1] + pxf(v[1]));
+    const float r = sat8f(d0 + d1);
+    uint32_t w[Words<T>::N];
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) w[i] = sgn(r) ? maskw<T>(i) : 0u;
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// DoubleRepetitionDecoder :242-257 (blocks of 32 positions and more): half_reduce_adds_epi8 (avxconvenience.h:202-210) -- every
+// byte lane ends as the saturating butterfly sum of its parity class; even positions take the even class's sign
+template <int T>
+__device__ __forceinline__ void leaf_drep_ch(const Lane& L, uint32_t side)
+{
+    float v[16], a[16], b[16];
+    lane_sums16<T>(v);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a[s] = sat8f(v[s] + v[s ^ 8]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) b[s] = sat8f(a[s] + a[s ^ 4]);
+    const float c0 = sat8f(b[0] + b[2]), c1 = sat8f(b[1] + b[3]);
+    const float e = sat8f(c0 + pxf(c0)), o = sat8f(c1 + pxf(c1));
+    const uint32_t pat = (sgn(e) ? 0x55555555u : 0u) | (sgn(o) ? 0xAAAAAAAAu : 0u);
+    uint32_t w[Words<T>::N];
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) w[i] = pat & maskw<T>(i);
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// SpcDecoder :268-297 / ShortSpcDecoder :299-313 on the block in v[R ..) (M = log2 of its local length), NREAL = positions of
+// the reference's block: hard decisions, and for odd parity the char negation of the first position of the minimum magnitude
+// (|-128| = 128 sorts last; blocks above 32 positions search vector-wise from 127 -- nothing below 127: position 0; a single
+// padded vector: a minimum above 127 means the 127 of the padding wins, no flip; 0 and -128 keep their sign)
+template <int M, int R, int NREAL>
+__device__ __forceinline__ void spc_core_ch(const Lane& L, uint32_t (&w)[Words<M>::N], uint32_t (&flip)[Words<M>::N])
+{
+    constexpr int m = 1 << M, NW = Words<M>::N;
+    sign_words<M, R>(w);
+    float mn = bitsf(0x7F800000u);
+    static_for<m>([&](auto I) { amin_in<R + decltype(I)::value>(mn); });
+    uint32_t par = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) par ^= (uint32_t)__builtin_popcount(w[i]);
+    par &= 1u;
+    par ^= px(par);
+    const float om = pxf(mn);
+    const float mall = om < mn ? om : mn;
+    uint32_t e[NW];
+    if constexpr (m <= 32) {
+        e[0] = 0;
+        static_for<m>([&](auto I) { eq_in<R + m - 1 - decltype(I)::value>(e[0], mall); });
+    } else {
+        static_for<NW>([&](auto Wd) {
+            constexpr int wd = decltype(Wd)::value;
+            e[wd] = 0;
+            static_for<32>([&](auto I) { eq_in<R + 32 * wd + 31 - decltype(I)::value>(e[wd], mall); });
+        });
+    }
+    uint32_t j = 0xFFFFu;
+    if constexpr (NW == 2) {
+        if (e[1]) j = 32u + (uint32_t)__builtin_ctz(e[1]);
+    }
+    if (e[0]) j = (uint32_t)__builtin_ctz(e[0]);
+    uint32_t mine = j == 0xFFFFu ? 0xFFFFu : real_index(j, L.p);
+    bool doit = par != 0;
+    if constexpr (NREAL > 32) {
+        if (mall >= 127.0f) {  // position 0: local index 0 of the even lane
+            j = 0;
+            mine = L.p ? 0xFFFFu : 0u;
+        }
+    } else {
+        if (mall > 127.0f) doit = false;
+    }
+    const uint32_t other = px(mine);
+    doit = doit && mine < other;
+    // the char negation keeps the sign of 0 and of -128
+    const uint32_t sj = (w[NW == 2 ? (j >> 5) & 1u : 0] >> (j & 31u)) & 1u;
+    float vj = mall;
+    if constexpr (NREAL > 32) vj = (mall >= 127.0f) ? absf(rdf<R>()) : mall;
+    doit = doit && vj != 0.0f && !(vj == 128.0f && sj);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) flip[i] = (doit && (j >> 5) == (uint32_t)i) ? (1u << (j & 31u)) : 0u;
+}
+template <int T>
+__device__ __forceinline__ void leaf_spc_ch(const Lane& L, uint32_t side)
+{
+    uint32_t w[Words<T>::N], f[Words<T>::N];
+    spc_core_ch<T, RS(T), (2 << T)>(L, w, f);
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) w[i] ^= f[i];
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// ZeroSpcDecoder :315-353 / ShortZeroSpcDecoder :355-384: SPC on y = sat(a + b), the result twice
+template <int T>
+__device__ __forceinline__ void leaf_zerospc_ch(const Lane& L, uint32_t side, const Sat& S)
+{
+    constexpr int hl = 1 << (T - 1);
+    g0_reg<T>();
+    clamp_g<RS(T - 1), hl>(S);
+    uint32_t ys[Words<T - 1>::N], f[Words<T - 1>::N], w[Words<T>::N];
+    spc_core_ch<T - 1, RS(T - 1), (2 << T)>(L, ys, f);
+#pragma unroll
+    for (int i = 0; i < Words<T - 1>::N; ++i) ys[i] ^= f[i];
+    if constexpr (T <= 5) {
+        w[0] = ys[0] | (ys[0] << hl);
+    } else {
+        w[0] = ys[0];
+        w[1] = ys[0];
+    }
+    put_bits<T>(L.lds, L.lane, side, w);
+}
+// ShortZeroOneDecoder :386-395 on a block of 4 positions (G0R / RateOne / COMBINE0R of the plain program): both halves =
+// sat(a + b), a and b sit in the two lanes
+__device__ __forceinline__ void leaf_zr1(const Lane& L, uint32_t side)
+{
+    const float x0 = rdf<RS(1)>(), x1 = rdf<RS(1) + 1>();
+    const float y0 = x0 + pxf(x0), y1 = x1 + pxf(x1);  // (the clamp does not change a sign)
+    const uint32_t w[1] = { sgn(y0) | (sgn(y1) << 1) };
+    put_bits<1>(L.lds, L.lane, side, w);
+}
+
+}  // namespace pair
+
+namespace pair {
+// the steps of the way down with the int8 decoder's saturation where CH is set
+template <bool CH, int T>
+__device__ __forceinline__ void dn_f(uint32_t absmask, const Sat& S)
+{
+    f_reg<T>(absmask);
+    if constexpr (CH) clamp_f<RS(T - 1), (1 << (T - 1))>(S, absmask);
+}
+template <bool CH, int T>
+__device__ __forceinline__ void dn_g(uint32_t signmask, const Sat& S)
+{
+    g_reg<T>(signmask);
+    if constexpr (CH) clamp_g<RS(T - 1), (1 << (T - 1))>(S);
+}
+template <bool CH, int T>
+__device__ __forceinline__ void dn_g0(const Sat& S)
+{
+    g0_reg<T>();
+    if constexpr (CH) clamp_g<RS(T - 1), (1 << (T - 1))>(S);
+}
+template <bool CH, int KIND>
+__device__ __forceinline__ void dn_s7(uint32_t lane16, uint32_t absmask, uint32_t signmask, const Sat& S)
+{
+    op_s7<KIND>(lane16, absmask, signmask);
+    if constexpr (CH) {
+        if constexpr (KIND == 0) clamp_f<RS(6), 64>(S, absmask);
+        else clamp_g<RS(6), 64>(S);
+    }
+}
+template <bool CH, int KIND>
+__device__ __forceinline__ void dn_top(const TopAddr& A, const uint32_t* lds, int lane, uint32_t absmask, uint32_t signmask, const Sat& S)
+{
+    if constexpr (CH) op_top8<KIND>(A, lds, lane, absmask, signmask, S);
+    else op_top<KIND>(A, lds, lane, absmask, signmask);
+}
 }  // namespace pair
 
 // =====================================================================================================================
 //  kernel
 // =====================================================================================================================
+template <bool CH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(pair::KV)))
 void sc_pair_kernel(const DecodeParams P)
 {
@@ -873,6 +1214,10 @@ void sc_pair_kernel(const DecodeParams P)
     L.lane = lane;
     L.p = (uint32_t)lane & 1u;
     const uint32_t lane16 = (uint32_t)lane << 4;
+    Sat S;
+    S.c127 = 127.0f;
+    S.m128 = -128.0f;
+    asm volatile("" : "+v"(S.m128));  // (kept in a VGPR: the clamp's scalar operand is the 127)
     TopAddr TA;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -882,7 +1227,7 @@ void sc_pair_kernel(const DecodeParams P)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t r = (uint32_t)lane >> 1;
-        TA.ra[k] = 4u * LDS_S7 + r * 128u + (((uint32_t)k + r + (r >> 3)) & 7u) * 16u + 8u * L.p;
+        TA.ra[k] = 4u * LDS_S7 + r * 128u + (((uint32_t)k + r + (r >> 3)) & 7u) * 16u + (CH ? 0u : 8u * L.p);  // (int8 rows: both lanes read the whole unit)
     }
 
     for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -896,7 +1241,10 @@ void sc_pair_kernel(const DecodeParams P)
             const uint32_t ri = grp * 32u + ((uint32_t)lane >> 3) + 8u * (uint32_t)i;
             const uint32_t rj = ri < P.rows ? ri : grp * 32u;
             const uint32_t rr = P.rowidx ? P.rowidx[rj] : rj;
-            TA.rp[i] = reinterpret_cast<const float*>(P.llr) + (size_t)rr * N + 4u * ((uint32_t)lane & 7u);
+            if constexpr (CH)  // (int8 rows: 16 positions per 16-byte piece)
+                TA.rp[i] = reinterpret_cast<const float*>(reinterpret_cast<const int8_t*>(P.llr) + (size_t)rr * N + 16u * ((uint32_t)lane & 7u));
+            else
+                TA.rp[i] = reinterpret_cast<const float*>(P.llr) + (size_t)rr * N + 4u * ((uint32_t)lane & 7u);
         }
 
         uint64_t nraw = prog[0];
@@ -949,6 +1297,7 @@ void sc_pair_kernel(const DecodeParams P)
                 case 0x35: op_rone<5>(lds, lane, side, signmask); break;
                 case 0x34: op_rone<4>(lds, lane, side, signmask); break;
                 case 0x33: op_rone<3>(lds, lane, side, signmask); break;
+                case 0x32: op_rone<2>(lds, lane, side, signmask); break;
                 default: break;
                 }
             }
@@ -964,37 +1313,61 @@ void sc_pair_kernel(const DecodeParams P)
                 if ((P.ablate & 512u) && d1 - i <= 6u) continue;
 #endif
                 switch ((kind << 4) | (d1 - i)) {
-                case 0x09: op_top<0>(TA, lds, lane, absmask, signmask); break;
-                case 0x08: op_s8<0>(lane16, absmask, signmask); break;
-                case 0x07: op_s7<0>(lane16, absmask, signmask); break;
-                case 0x06: f_reg<6>(absmask); break;
-                case 0x05: f_reg<5>(absmask); break;
-                case 0x04: f_reg<4>(absmask); break;
-                case 0x03: f_reg<3>(absmask); break;
-                case 0x02: f_reg<2>(absmask); break;
-                case 0x19: op_top<1>(TA, lds, lane, absmask, signmask); break;
-                case 0x18: op_s8<1>(lane16, absmask, signmask); break;
-                case 0x17: op_s7<1>(lane16, absmask, signmask); break;
-                case 0x16: g_reg<6>(signmask); break;
-                case 0x15: g_reg<5>(signmask); break;
-                case 0x14: g_reg<4>(signmask); break;
-                case 0x13: g_reg<3>(signmask); break;
-                case 0x12: g_reg<2>(signmask); break;
-                case 0x29: op_top<2>(TA, lds, lane, absmask, signmask); break;
-                case 0x28: op_s8<2>(lane16, absmask, signmask); break;
-                case 0x27: op_s7<2>(lane16, absmask, signmask); break;
-                case 0x26: g0_reg<6>(); break;
-                case 0x25: g0_reg<5>(); break;
-                case 0x24: g0_reg<4>(); break;
-                case 0x23: g0_reg<3>(); break;
-                case 0x22: g0_reg<2>(); break;
+                case 0x09: dn_top<CH, 0>(TA, lds, lane, absmask, signmask, S); break;
+                case 0x08: op_s8<CH, 0>(lane16, absmask, signmask, S); break;
+                case 0x07: dn_s7<CH, 0>(lane16, absmask, signmask, S); break;
+                case 0x06: dn_f<CH, 6>(absmask, S); break;
+                case 0x05: dn_f<CH, 5>(absmask, S); break;
+                case 0x04: dn_f<CH, 4>(absmask, S); break;
+                case 0x03: dn_f<CH, 3>(absmask, S); break;
+                case 0x02: dn_f<CH, 2>(absmask, S); break;
+                case 0x19: dn_top<CH, 1>(TA, lds, lane, absmask, signmask, S); break;
+                case 0x18: op_s8<CH, 1>(lane16, absmask, signmask, S); break;
+                case 0x17: dn_s7<CH, 1>(lane16, absmask, signmask, S); break;
+                case 0x16: dn_g<CH, 6>(signmask, S); break;
+                case 0x15: dn_g<CH, 5>(signmask, S); break;
+                case 0x14: dn_g<CH, 4>(signmask, S); break;
+                case 0x13: dn_g<CH, 3>(signmask, S); break;
+                case 0x12: dn_g<CH, 2>(signmask, S); break;
+                case 0x29: dn_top<CH, 2>(TA, lds, lane, absmask, signmask, S); break;
+                case 0x28: op_s8<CH, 2>(lane16, absmask, signmask, S); break;
+                case 0x27: dn_s7<CH, 2>(lane16, absmask, signmask, S); break;
+                case 0x26: dn_g0<CH, 6>(S); break;
+                case 0x25: dn_g0<CH, 5>(S); break;
+                case 0x24: dn_g0<CH, 4>(S); break;
+                case 0x23: dn_g0<CH, 3>(S); break;
+                case 0x22: dn_g0<CH, 2>(S); break;
                 default: break;
                 }
             }
             if (lk) {  // the leaf the way down ends at: its stage is one below the last step, it is a left child behind an F
                 const uint32_t side = lastk != 0u ? 1u : 0u;
 #define PR_LF(K_, T_) (((K_) - PR_R0 + 1) << 3 | (T_))
-                switch ((lk << 3) | (d1 - ndn)) {
+                const uint32_t lst = d1 - ndn, lsd = side;
+                if constexpr (CH) {
+                    switch ((lk << 3) | lst) {
+                    case PR_LF(PR_R0, 1): leaf_r0<1>(L, lsd); break;
+                    case PR_LF(PR_R0, 2): leaf_r0<2>(L, lsd); break;
+                    case PR_LF(PR_R1, 1): leaf_r1<1>(L, lsd); break;
+                    case PR_LF(PR_R1, 2): leaf_r1<2>(L, lsd); break;
+#define PR_LEAF_1_6(K_, FN) case PR_LF(K_, 1): FN<1>(L, lsd); break; case PR_LF(K_, 2): FN<2>(L, lsd); break; case PR_LF(K_, 3): FN<3>(L, lsd); break; \
+                            case PR_LF(K_, 4): FN<4>(L, lsd); break; case PR_LF(K_, 5): FN<5>(L, lsd); break; case PR_LF(K_, 6): FN<6>(L, lsd); break;
+                    PR_LEAF_1_6(PR_REP, leaf_rep_ch)
+                    PR_LEAF_1_6(PR_SPC, leaf_spc_ch)
+#undef PR_LEAF_1_6
+                    case PR_LF(PR_DREP, 4): leaf_drep_ch<4>(L, lsd); break;
+                    case PR_LF(PR_DREP, 5): leaf_drep_ch<5>(L, lsd); break;
+                    case PR_LF(PR_DREP, 6): leaf_drep_ch<6>(L, lsd); break;
+                    case PR_LF(PR_ZEROSPC, 2): leaf_zerospc_ch<2>(L, lsd, S); break;
+                    case PR_LF(PR_ZEROSPC, 3): leaf_zerospc_ch<3>(L, lsd, S); break;
+                    case PR_LF(PR_ZEROSPC, 4): leaf_zerospc_ch<4>(L, lsd, S); break;
+                    case PR_LF(PR_ZEROSPC, 5): leaf_zerospc_ch<5>(L, lsd, S); break;
+                    case PR_LF(PR_ZEROSPC, 6): leaf_zerospc_ch<6>(L, lsd, S); break;
+                    case PR_LF(PR_ZR1, 1): leaf_zr1(L, lsd); break;
+                    default: break;
+                    }
+                } else {
+                switch ((lk << 3) | lst) {
                 case PR_LF(PR_R0, 1): leaf_r0<1>(L, side); break;
                 case PR_LF(PR_R0, 2): leaf_r0<2>(L, side); break;
                 case PR_LF(PR_R1, 1): leaf_r1<1>(L, side); break;
@@ -1018,6 +1391,7 @@ void sc_pair_kernel(const DecodeParams P)
                 case PR_LF(PR_REPONE8, 2): leaf_type5<2, false>(L, side); break;
                 case PR_LF(PR_ZSPC8, 2): leaf_zspc8(L, side); break;
                 default: break;
+                }
                 }
 #undef PR_LEAF_1_6
 #undef PR_LEAF_3_6
@@ -1150,7 +1524,8 @@ void sc_pair_kernel(const DecodeParams P)
 
 hipError_t launch_sc_pair(const DecodeParams& P, unsigned grid, hipStream_t st)
 {
-    hipLaunchKernelGGL(sc_pair_kernel, dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    if (P.chr) hipLaunchKernelGGL(sc_pair_kernel<true>, dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    else hipLaunchKernelGGL(sc_pair_kernel<false>, dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
     return hipGetLastError();
 }
 
