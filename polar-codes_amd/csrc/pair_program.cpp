@@ -49,7 +49,7 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr)
             break;
         case SC_COMBINE: if (T < 2) return false; put(PR_C, T, side); break;
         case SC_COMBINE0R: if (T < 2) return false; put(PR_C0R, T, side); break;
-        case SC_RONE: if (T < 2 || T > 6) return false; put(PR_RONE, T, side); break;
+        case SC_RONE: if (T < 2) return false; put(PR_RONE, T, side); break;
         case SC_R0: ok = leaf(PR_R0, 1, 2); break;
         case SC_R1: ok = leaf(PR_R1, 1, 2); break;
         case SC_REP: ok = leaf(PR_REP, 1, 6); break;
@@ -71,7 +71,8 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr)
         if (!ok) return false;
     }
     // the root must end in a COMBINE / COMBINE0R of the whole block: that is what fills the code word for the epilogue
-    if (out.ins.empty() || (out.ins.back().op != PR_C && out.ins.back().op != PR_C0R) || out.ins.back().stage != logN - 1) return false;
+    if (out.ins.empty() || (out.ins.back().op != PR_C && out.ins.back().op != PR_C0R && out.ins.back().op != PR_RONE) || out.ins.back().stage != logN - 1)
+        return false;
     // Fuse everything between two leaves into one PR_WALK:
     //   word 0: op | leaf kind (op - PR_R0 + 1, 0 = none) << 8 | c0 << 12 | steps up << 16 | d1 << 20 | steps down << 24 | first step down << 28
     //           (0 F, 1 G, 2 G0R)

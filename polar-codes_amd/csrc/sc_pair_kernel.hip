@@ -694,6 +694,60 @@ __device__ __forceinline__ void op_rone(uint32_t* lds, int lane, uint32_t side, 
     put_bits<T>(lds, lane, side, w);
 }
 
+// ... of a block whose LLRs sit in the LDS (T = 7): lam -> the registers of stage 6
+__device__ __forceinline__ void op_rone7(uint32_t* lds, int lane, uint32_t lane16, uint32_t side, uint32_t absmask, uint32_t signmask)
+{
+    op_s7<1>(lane16, absmask, signmask);
+    uint32_t l[2], r[2], w[4];
+    sign_words<6, RS(6)>(r);
+    get_child<7, 0>(lds, lane, l);
+    join<7>(l, r, w);
+    put_bits<7>(lds, lane, side, w);
+}
+// signs of the 128 values of the LDS column (stage 7), 32 per word: eight chunks at a time through v[128..159]
+__device__ __forceinline__ void sign_words_s7(uint32_t lane16, uint32_t (&w)[4])
+{
+    static_for<4>([&](auto Wd) {
+        constexpr int wd = decltype(Wd)::value;
+        const uint32_t ad = lane16;
+#define PR_RDC(c) "ds_read_b128 v[128+4*" #c ":128+4*" #c "+3], %[ad] offset:%[o]+1024*" #c "\n\t"
+        asm volatile(PR_RDC(0) PR_RDC(1) PR_RDC(2) PR_RDC(3) PR_RDC(4) PR_RDC(5) PR_RDC(6) PR_RDC(7) "s_waitcnt lgkmcnt(0)"
+                     :
+                     : [ad] "v"(ad), [o] "n"(4 * LDS_S7 + 8192 * wd)
+                     : "memory");
+#undef PR_RDC
+        w[wd] = sign_word<128, 32>();
+    });
+}
+// ... in the AGPRs (T = 8): lam goes to the LDS column like the g of that stage, its signs are read back from there
+template <bool CH>
+__device__ __forceinline__ void op_rone8(uint32_t* lds, int lane, uint32_t lane16, uint32_t side, uint32_t absmask, uint32_t signmask, const Sat& S)
+{
+    op_s8<CH, 1>(lane16, absmask, signmask, S);
+    uint32_t l[4], r[4], w[8];
+    sign_words_s7(lane16, r);
+    get_child<8, 0>(lds, lane, l);
+    join<8>(l, r, w);
+    put_bits<8>(lds, lane, side, w);
+}
+// s = (s << 1) | sign(a[I])
+template <int I>
+__device__ __forceinline__ void sgn_in_agpr(uint32_t& s)
+{
+    uint32_t t;
+    asm volatile("v_accvgpr_read_b32 %[t], a[%[i]]\n\tv_alignbit_b32 %[s], %[s], %[t], 31" : [s] "+v"(s), [t] "=&v"(t) : [i] "n"(I));
+}
+// signs of the 256 AGPRs (stage 8)
+__device__ __forceinline__ void sign_words_s8(uint32_t (&w)[8])
+{
+    static_for<8>([&](auto Wd) {
+        constexpr int wd = decltype(Wd)::value;
+        uint32_t s = 0;
+        static_for<32>([&](auto I) { sgn_in_agpr<32 * wd + 31 - decltype(I)::value>(s); });
+        w[wd] = s;
+    });
+}
+
 // ---- leaves (local stage T <= 6: the block sits in v[RS(T) ..)) ----------------------------------------------------------
 struct Lane {
     uint32_t* lds;
@@ -1191,6 +1245,17 @@ __device__ __forceinline__ void dn_top(const TopAddr& A, const uint32_t* lds, in
     if constexpr (CH) op_top8<KIND>(A, lds, lane, absmask, signmask, S);
     else op_top<KIND>(A, lds, lane, absmask, signmask);
 }
+// ROneNode at the root (T = 9): lam = g over the channel row -> the AGPRs, the code word = [left ^ sign(lam) | sign(lam)]
+template <bool CH>
+__device__ __forceinline__ void op_rone9(const TopAddr& A, uint32_t* lds, int lane, uint32_t side, uint32_t absmask, uint32_t signmask, const Sat& S)
+{
+    dn_top<CH, 1>(A, lds, lane, absmask, signmask, S);
+    uint32_t l[8], r[8], w[16];
+    sign_words_s8(r);
+    get_child<9, 0>(lds, lane, l);
+    join<9>(l, r, w);
+    put_bits<9>(lds, lane, side, w);
+}
 }  // namespace pair
 
 // =====================================================================================================================
@@ -1293,6 +1358,9 @@ void sc_pair_kernel(const DecodeParams P)
                 case 0x24: op_combine<4, true>(lds, lane, side); break;
                 case 0x23: op_combine<3, true>(lds, lane, side); break;
                 case 0x22: op_combine<2, true>(lds, lane, side); break;
+                case 0x39: op_rone9<CH>(TA, lds, lane, side, absmask, signmask, S); break;
+                case 0x38: op_rone8<CH>(lds, lane, lane16, side, absmask, signmask, S); break;
+                case 0x37: op_rone7(lds, lane, lane16, side, absmask, signmask); break;
                 case 0x36: op_rone<6>(lds, lane, side, signmask); break;
                 case 0x35: op_rone<5>(lds, lane, side, signmask); break;
                 case 0x34: op_rone<4>(lds, lane, side, signmask); break;
