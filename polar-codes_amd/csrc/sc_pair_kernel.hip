@@ -26,6 +26,7 @@
 // every cross-lane sum the reference takes is a sum of one value per lane (commutative) or is rebuilt in full in both lanes.
 #define PAMD_POLAR_F_MINF 1
 #include "device_common.h"
+#include "pair_runs.inc"
 
 #include <utility>
 
@@ -99,6 +100,79 @@ __device__ __forceinline__ void add_in(float& a)
 {
     asm volatile("v_add_f32 %0, %0, v[%1]" : "+v"(a) : "n"(R));
 }
+// ---- runs over consecutive registers, one asm statement each (pair_runs.inc) ----------------------------------------------------
+// signs of v[R .. R+CNT), element i at bit i
+template <int R, int CNT>
+__device__ __forceinline__ uint32_t sign_run()
+{
+    uint32_t s = 0;
+    if constexpr (CNT == 32) asm volatile(PR_RUN_SGN_32 : [s] "+v"(s) : [r] "n"(R));
+    else if constexpr (CNT == 16) asm volatile(PR_RUN_SGN_16 : [s] "+v"(s) : [r] "n"(R));
+    else if constexpr (CNT == 8) asm volatile(PR_RUN_SGN_8 : [s] "+v"(s) : [r] "n"(R));
+    else if constexpr (CNT == 4) asm volatile(PR_RUN_SGN_4 : [s] "+v"(s) : [r] "n"(R));
+    else asm volatile(PR_RUN_SGN_2 : [s] "+v"(s) : [r] "n"(R));
+    return s;
+}
+// m[k & 3] = min(m[k & 3], |v[R + k]|), k < CNT
+template <int R, int CNT>
+__device__ __forceinline__ void amin_run4(float (&m)[4])
+{
+#define PR_AM_OPS [m0] "+v"(m[0]), [m1] "+v"(m[1]), [m2] "+v"(m[2]), [m3] "+v"(m[3])
+    if constexpr (CNT == 64) asm volatile(PR_RUN_AMIN_64 : PR_AM_OPS : [r] "n"(R));
+    else if constexpr (CNT == 32) asm volatile(PR_RUN_AMIN_32 : PR_AM_OPS : [r] "n"(R));
+    else if constexpr (CNT == 16) asm volatile(PR_RUN_AMIN_16 : PR_AM_OPS : [r] "n"(R));
+    else if constexpr (CNT == 8) asm volatile(PR_RUN_AMIN_8 : PR_AM_OPS : [r] "n"(R));
+    else if constexpr (CNT == 4) asm volatile(PR_RUN_AMIN_4 : PR_AM_OPS : [r] "n"(R));
+    else asm volatile(PR_RUN_AMIN_2 : PR_AM_OPS : [r] "n"(R));
+#undef PR_AM_OPS
+}
+// the minimum magnitude of v[R .. R+CNT) folded into mn
+template <int R, int CNT>
+__device__ __forceinline__ void amin_run(float& mn)
+{
+    float m[4] = { mn, mn, mn, mn };
+    amin_run4<R, CNT>(m);
+    const float a = m[0] < m[1] ? m[0] : m[1], b = m[2] < m[3] ? m[2] : m[3];
+    mn = a < b ? a : b;
+}
+// bit i = (|v[R + i]| == m), i < CNT <= 32
+template <int R, int CNT>
+__device__ __forceinline__ uint32_t eq_run(float m)
+{
+    uint32_t e = 0;
+    if constexpr (CNT == 32) asm volatile(PR_RUN_EQ_32 : [e] "+v"(e) : [m] "v"(m), [r] "n"(R) : "vcc");
+    else if constexpr (CNT == 16) asm volatile(PR_RUN_EQ_16 : [e] "+v"(e) : [m] "v"(m), [r] "n"(R) : "vcc");
+    else if constexpr (CNT == 8) asm volatile(PR_RUN_EQ_8 : [e] "+v"(e) : [m] "v"(m), [r] "n"(R) : "vcc");
+    else if constexpr (CNT == 4) asm volatile(PR_RUN_EQ_4 : [e] "+v"(e) : [m] "v"(m), [r] "n"(R) : "vcc");
+    else asm volatile(PR_RUN_EQ_2 : [e] "+v"(e) : [m] "v"(m), [r] "n"(R) : "vcc");
+    return e;
+}
+// ... against m[i & 3]
+template <int R, int CNT>
+__device__ __forceinline__ uint32_t eq_run4(const float (&m)[4])
+{
+    uint32_t e = 0;
+#define PR_EQ_OPS [m0] "v"(m[0]), [m1] "v"(m[1]), [m2] "v"(m[2]), [m3] "v"(m[3]), [r] "n"(R)
+    if constexpr (CNT == 32) asm volatile(PR_RUN_EQ4_32 : [e] "+v"(e) : PR_EQ_OPS : "vcc");
+    else if constexpr (CNT == 16) asm volatile(PR_RUN_EQ4_16 : [e] "+v"(e) : PR_EQ_OPS : "vcc");
+    else asm volatile(PR_RUN_EQ4_8 : [e] "+v"(e) : PR_EQ_OPS : "vcc");
+#undef PR_EQ_OPS
+    return e;
+}
+// a[k & 3] += v[R + k], k < CNT, ascending
+template <int R, int CNT>
+__device__ __forceinline__ void add_run4(float (&a)[4])
+{
+#define PR_AD_OPS [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3])
+    if constexpr (CNT == 64) asm volatile(PR_RUN_ADD_64 : PR_AD_OPS : [r] "n"(R));
+    else if constexpr (CNT == 32) asm volatile(PR_RUN_ADD_32 : PR_AD_OPS : [r] "n"(R));
+    else if constexpr (CNT == 16) asm volatile(PR_RUN_ADD_16 : PR_AD_OPS : [r] "n"(R));
+    else if constexpr (CNT == 8) asm volatile(PR_RUN_ADD_8 : PR_AD_OPS : [r] "n"(R));
+    else if constexpr (CNT == 4) asm volatile(PR_RUN_ADD_4 : PR_AD_OPS : [r] "n"(R));
+    else asm volatile(PR_RUN_ADD_2 : PR_AD_OPS : [r] "n"(R));
+#undef PR_AD_OPS
+}
+
 // the other lane of the pair
 __device__ __forceinline__ uint32_t px(uint32_t v) { return dpp_u32<0xB1>(v); }
 __device__ __forceinline__ float pxf(float v) { return bitsf(dpp_u32<0xB1>(fbits(v))); }
@@ -667,9 +741,7 @@ __device__ __forceinline__ void op_combine(uint32_t* lds, int lane, uint32_t sid
 template <int R, int CNT>
 __device__ __forceinline__ uint32_t sign_word()
 {
-    uint32_t s = 0;
-    static_for<CNT>([&](auto I) { sgn_in<R + CNT - 1 - decltype(I)::value>(s); });
-    return s;
+    return sign_run<R, CNT>();
 }
 // signs of the block of local stage T held in v[R ..)
 template <int T, int R>
@@ -748,6 +820,9 @@ __device__ __forceinline__ void sign_words_s8(uint32_t (&w)[8])
     });
 }
 
+// (Leaves of 256 / 512 positions -- the block in the LDS column / the AGPRs, worked on 64 values at a time -- were built and are
+//  bit-exact, but their mere presence in the kernel cost the common trees 10-13 % at 2^20 codewords (identical hot loop, different
+//  code placement): such trees keep sc_decode_kernel.  DESIGN.md section 3.6.)
 // ---- leaves (local stage T <= 6: the block sits in v[RS(T) ..)) ----------------------------------------------------------
 struct Lane {
     uint32_t* lds;
@@ -768,10 +843,7 @@ __device__ __forceinline__ void fold4(float (&acc)[4])
     constexpr int m = 1 << T;
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[s] = 0.0f;
-    static_for<m>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        add_in<RS(T) + i>(acc[i & 3]);
-    });
+    add_run4<RS(T), m>(acc);
 }
 // ... all eight, in both lanes, in the reference's order
 __device__ __forceinline__ void gather8(const Lane& L, const float (&acc)[4], float (&a)[8])
@@ -839,7 +911,7 @@ __device__ __forceinline__ void spc_core(const Lane& L, uint32_t (&w)[Words<T>::
     constexpr int m = 1 << T, NW = Words<T>::N;
     sign_words<T, R>(w);
     float mn = bitsf(0x7F800000u);
-    static_for<m>([&](auto I) { amin_in<R + decltype(I)::value>(mn); });
+    amin_run<R, m>(mn);
     uint32_t par = 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) par ^= (uint32_t)__builtin_popcount(w[i]);
@@ -849,14 +921,10 @@ __device__ __forceinline__ void spc_core(const Lane& L, uint32_t (&w)[Words<T>::
     const float mall = om < mn ? om : mn;
     uint32_t e[NW];
     if constexpr (m <= 32) {
-        e[0] = 0;
-        static_for<m>([&](auto I) { eq_in<R + m - 1 - decltype(I)::value>(e[0], mall); });
+        e[0] = eq_run<R, m>(mall);
     } else {
-        static_for<NW>([&](auto Wd) {
-            constexpr int wd = decltype(Wd)::value;
-            e[wd] = 0;
-            static_for<32>([&](auto I) { eq_in<R + 32 * wd + 31 - decltype(I)::value>(e[wd], mall); });
-        });
+        e[0] = eq_run<R, 32>(mall);
+        e[1] = eq_run<R + 32, 32>(mall);
     }
     uint32_t j = 0xFFFFu;
     if constexpr (NW == 2) {
@@ -1126,7 +1194,7 @@ __device__ __forceinline__ void spc_core_ch(const Lane& L, uint32_t (&w)[Words<M
     constexpr int m = 1 << M, NW = Words<M>::N;
     sign_words<M, R>(w);
     float mn = bitsf(0x7F800000u);
-    static_for<m>([&](auto I) { amin_in<R + decltype(I)::value>(mn); });
+    amin_run<R, m>(mn);
     uint32_t par = 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) par ^= (uint32_t)__builtin_popcount(w[i]);
@@ -1136,14 +1204,10 @@ __device__ __forceinline__ void spc_core_ch(const Lane& L, uint32_t (&w)[Words<M
     const float mall = om < mn ? om : mn;
     uint32_t e[NW];
     if constexpr (m <= 32) {
-        e[0] = 0;
-        static_for<m>([&](auto I) { eq_in<R + m - 1 - decltype(I)::value>(e[0], mall); });
+        e[0] = eq_run<R, m>(mall);
     } else {
-        static_for<NW>([&](auto Wd) {
-            constexpr int wd = decltype(Wd)::value;
-            e[wd] = 0;
-            static_for<32>([&](auto I) { eq_in<R + 32 * wd + 31 - decltype(I)::value>(e[wd], mall); });
-        });
+        e[0] = eq_run<R, 32>(mall);
+        e[1] = eq_run<R + 32, 32>(mall);
     }
     uint32_t j = 0xFFFFu;
     if constexpr (NW == 2) {
