@@ -736,7 +736,7 @@ pamd::DecodeParams base_params(const pcd_decoder* d, const void* llr, size_t row
 
 // two-lanes-per-codeword SC kernel: 32 codewords per single-wave workgroup, 4 workgroups per CU (40 KB of LDS and all 512
 // registers of a SIMD lane each)
-int run_sc_pair(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
+int run_sc_pair(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
     P.prog = d->d_pair_prog;
     P.ext = d->d_ext;
@@ -748,13 +748,14 @@ int run_sc_pair(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
     if (const char* e = PAMD_ENV("PCD_PAIR_BLOCKS_PER_CU")) per_cu = (unsigned)std::max(1, std::min(4, std::atoi(e)));  // experiments
     unsigned grid = std::max(1u, std::min(need, (unsigned)d->num_cu * per_cu));
     if (const char* e = PAMD_ENV("PCD_PAIR_GRID")) grid = (unsigned)std::max(1, std::atoi(e));  // experiments
-    HIP_TRY(pamd::launch_sc_pair(P, grid, st));
+    HIP_TRY(pamd::launch_sc_pair(P, i8, grid, st));
     return PCD_OK;
 }
 
 int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
-    if (d->has_pair && i8 == (d->dectype == 0)) return run_sc_pair(d, P, st);  // (fp32 rows for the float decoder, int8 rows for the int8 one)
+    // (fp32 or int8 rows for the float decoder; the int8 decoder sees int8 rows only: float rows were converted by the caller)
+    if (d->has_pair && (i8 || d->dectype != 0)) return run_sc_pair(d, P, i8, st);
     P.prog = d->d_sc_prog;
     P.prog_len = (uint32_t)d->sc_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->sc_wave_words;

@@ -52,9 +52,9 @@ hipError_t launch_scl(const DecodeParams& P, int lpl, bool i8, unsigned grid, un
 // slices of scl_lane_arena_words() 32-bit words
 hipError_t launch_scl_lane(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);
 unsigned scl_lane_arena_words();
-// two-lanes-per-codeword SC kernel (sc_pair_kernel.hip): N = 1024, fp32 rows; P.prog = the PR_* program, P.ext / P.syn_bytes as for
+// two-lanes-per-codeword SC kernel (sc_pair_kernel.hip): N = 1024, fp32 or int8 rows (P.chr: the int8 decoder, int8 rows only); P.prog = the PR_* program, P.ext / P.syn_bytes as for
 // the lane kernel; single-wave workgroups with 40 KB of dynamic LDS
-hipError_t launch_sc_pair(const DecodeParams& P, unsigned grid, hipStream_t st);
+hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, unsigned grid, hipStream_t st);
 // CharContainer::insertLlr(const float*) (bitcontainer.cpp:449-516, N >= 8): round to nearest even, saturate to int8
 hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st);
 hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,

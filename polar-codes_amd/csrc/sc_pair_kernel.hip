@@ -566,7 +566,7 @@ __device__ __forceinline__ void top8_load(const TopAddr& A)
                  : [s] "n"(S), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [o] "n"(128 * LS)
                  : "memory");
 }
-template <int KIND, int LS, int Q>
+template <bool SAT, int KIND, int LS, int Q>
 __device__ __forceinline__ void top8_quarter(const TopAddr& A, uint32_t sh0, uint32_t sh1, uint32_t w, uint32_t absmask, uint32_t signmask, const Sat& S)
 {
     constexpr int BUF = 8192 * (LS & 1);
@@ -599,7 +599,7 @@ __device__ __forceinline__ void top8_quarter(const TopAddr& A, uint32_t sh0, uin
         const uint32_t am = absmask, sm = signmask, ww = w;
         if constexpr (KIND == 0) {
             asm volatile(PR_F4T("%[x]", "%[x]", "%[y]") : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3) : [x] "n"(X), [y] "n"(Y), [am] "s"(am));
-            clamp_f<X, 4>(S, am);
+            if constexpr (SAT) clamp_f<X, 4>(S, am);
         } else if constexpr (KIND == 1) {
             asm volatile("v_lshlrev_b32 %[t0], %[s0], %[w]\n\t"
                          "v_lshlrev_b32 %[t1], %[s0]-1, %[w]\n\t"
@@ -615,18 +615,18 @@ __device__ __forceinline__ void top8_quarter(const TopAddr& A, uint32_t sh0, uin
                          "v_fma_f32 v[%[x]+3], v[%[x]+3], %[t3], v[%[y]+3]"
                          : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
                          : [x] "n"(X), [y] "n"(Y), [w] "v"(ww), [s0] "n"(31 - (16 * (Q & 1) + 4 * M)), [sm] "s"(sm));
-            clamp_g<X, 4>(S);
+            if constexpr (SAT) clamp_g<X, 4>(S);
         } else {
             asm volatile("v_add_f32 v[%[x]], v[%[x]], v[%[y]]\n\t" "v_add_f32 v[%[x]+1], v[%[x]+1], v[%[y]+1]\n\t"
                          "v_add_f32 v[%[x]+2], v[%[x]+2], v[%[y]+2]\n\t" "v_add_f32 v[%[x]+3], v[%[x]+3], v[%[y]+3]" ::[x] "n"(X), [y] "n"(Y));
-            clamp_g<X, 4>(S);
+            if constexpr (SAT) clamp_g<X, 4>(S);
         }
         asm volatile("v_accvgpr_write_b32 a[%[o]], v[%[x]]\n\t" "v_accvgpr_write_b32 a[%[o]+1], v[%[x]+1]\n\t"
                      "v_accvgpr_write_b32 a[%[o]+2], v[%[x]+2]\n\t" "v_accvgpr_write_b32 a[%[o]+3], v[%[x]+3]" ::[o] "n"(O), [x] "n"(X));
         (void)t0; (void)t1; (void)t2; (void)t3;
     });
 }
-template <int KIND, int LS>
+template <bool SAT, int KIND, int LS>
 __device__ __forceinline__ void top8_step(const TopAddr& A, uint32_t sh0, uint32_t sh1, const uint32_t (&w)[8], uint32_t absmask, uint32_t signmask,
                                           const Sat& S)
 {
@@ -647,12 +647,12 @@ __device__ __forceinline__ void top8_step(const TopAddr& A, uint32_t sh0, uint32
                      : "memory");
     }
     if constexpr (LS + 2 <= 3) top8_load<LS + 2>(A);
-    top8_quarter<KIND, LS, 0>(A, sh0, sh1, w[2 * LS], absmask, signmask, S);
-    top8_quarter<KIND, LS, 1>(A, sh0, sh1, w[2 * LS], absmask, signmask, S);
-    top8_quarter<KIND, LS, 2>(A, sh0, sh1, w[2 * LS + 1], absmask, signmask, S);
-    top8_quarter<KIND, LS, 3>(A, sh0, sh1, w[2 * LS + 1], absmask, signmask, S);
+    top8_quarter<SAT, KIND, LS, 0>(A, sh0, sh1, w[2 * LS], absmask, signmask, S);
+    top8_quarter<SAT, KIND, LS, 1>(A, sh0, sh1, w[2 * LS], absmask, signmask, S);
+    top8_quarter<SAT, KIND, LS, 2>(A, sh0, sh1, w[2 * LS + 1], absmask, signmask, S);
+    top8_quarter<SAT, KIND, LS, 3>(A, sh0, sh1, w[2 * LS + 1], absmask, signmask, S);
 }
-template <int KIND>
+template <bool SAT, int KIND>
 __device__ __forceinline__ void op_top8(const TopAddr& A, const uint32_t* lds, int lane, uint32_t absmask, uint32_t signmask, const Sat& S)
 {
     top8_load<0>(A);
@@ -663,10 +663,10 @@ __device__ __forceinline__ void op_top8(const TopAddr& A, const uint32_t* lds, i
         for (int i = 0; i < 8; ++i) w[i] = lds[LDS_B8L + i * 64 + lane];
     }
     const uint32_t sh0 = 16u * ((uint32_t)lane & 1u), sh1 = sh0 + 8u;
-    top8_step<KIND, 0>(A, sh0, sh1, w, absmask, signmask, S);
-    top8_step<KIND, 1>(A, sh0, sh1, w, absmask, signmask, S);
-    top8_step<KIND, 2>(A, sh0, sh1, w, absmask, signmask, S);
-    top8_step<KIND, 3>(A, sh0, sh1, w, absmask, signmask, S);
+    top8_step<SAT, KIND, 0>(A, sh0, sh1, w, absmask, signmask, S);
+    top8_step<SAT, KIND, 1>(A, sh0, sh1, w, absmask, signmask, S);
+    top8_step<SAT, KIND, 2>(A, sh0, sh1, w, absmask, signmask, S);
+    top8_step<SAT, KIND, 3>(A, sh0, sh1, w, absmask, signmask, S);
 }
 
 // ---- partial sums ---------------------------------------------------------------------------------------------------------
@@ -1303,17 +1303,17 @@ __device__ __forceinline__ void dn_s7(uint32_t lane16, uint32_t absmask, uint32_
         else clamp_g<RS(6), 64>(S);
     }
 }
-template <bool CH, int KIND>
+template <bool CH, bool I8, int KIND>
 __device__ __forceinline__ void dn_top(const TopAddr& A, const uint32_t* lds, int lane, uint32_t absmask, uint32_t signmask, const Sat& S)
 {
-    if constexpr (CH) op_top8<KIND>(A, lds, lane, absmask, signmask, S);
+    if constexpr (I8) op_top8<CH, KIND>(A, lds, lane, absmask, signmask, S);  // (int8 rows; CH: with the int8 decoder's saturation)
     else op_top<KIND>(A, lds, lane, absmask, signmask);
 }
 // ROneNode at the root (T = 9): lam = g over the channel row -> the AGPRs, the code word = [left ^ sign(lam) | sign(lam)]
-template <bool CH>
+template <bool CH, bool I8>
 __device__ __forceinline__ void op_rone9(const TopAddr& A, uint32_t* lds, int lane, uint32_t side, uint32_t absmask, uint32_t signmask, const Sat& S)
 {
-    dn_top<CH, 1>(A, lds, lane, absmask, signmask, S);
+    dn_top<CH, I8, 1>(A, lds, lane, absmask, signmask, S);
     uint32_t l[8], r[8], w[16];
     sign_words_s8(r);
     get_child<9, 0>(lds, lane, l);
@@ -1325,7 +1325,9 @@ __device__ __forceinline__ void op_rone9(const TopAddr& A, uint32_t* lds, int la
 // =====================================================================================================================
 //  kernel
 // =====================================================================================================================
-template <bool CH>
+// CH: the int8 decoder's arithmetic (FastSscFipChar); I8: the rows are int8 (always with CH; without it the float decoder fed the
+// decode_vector(const char*) way: the values converted on the way in, float arithmetic)
+template <bool CH, bool I8>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(pair::KV)))
 void sc_pair_kernel(const DecodeParams P)
 {
@@ -1356,7 +1358,7 @@ void sc_pair_kernel(const DecodeParams P)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t r = (uint32_t)lane >> 1;
-        TA.ra[k] = 4u * LDS_S7 + r * 128u + (((uint32_t)k + r + (r >> 3)) & 7u) * 16u + (CH ? 0u : 8u * L.p);  // (int8 rows: both lanes read the whole unit)
+        TA.ra[k] = 4u * LDS_S7 + r * 128u + (((uint32_t)k + r + (r >> 3)) & 7u) * 16u + (I8 ? 0u : 8u * L.p);  // (int8 rows: both lanes read the whole unit)
     }
 
     for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -1370,7 +1372,7 @@ void sc_pair_kernel(const DecodeParams P)
             const uint32_t ri = grp * 32u + ((uint32_t)lane >> 3) + 8u * (uint32_t)i;
             const uint32_t rj = ri < P.rows ? ri : grp * 32u;
             const uint32_t rr = P.rowidx ? P.rowidx[rj] : rj;
-            if constexpr (CH)  // (int8 rows: 16 positions per 16-byte piece)
+            if constexpr (I8)  // (int8 rows: 16 positions per 16-byte piece)
                 TA.rp[i] = reinterpret_cast<const float*>(reinterpret_cast<const int8_t*>(P.llr) + (size_t)rr * N + 16u * ((uint32_t)lane & 7u));
             else
                 TA.rp[i] = reinterpret_cast<const float*>(P.llr) + (size_t)rr * N + 4u * ((uint32_t)lane & 7u);
@@ -1422,7 +1424,7 @@ void sc_pair_kernel(const DecodeParams P)
                 case 0x24: op_combine<4, true>(lds, lane, side); break;
                 case 0x23: op_combine<3, true>(lds, lane, side); break;
                 case 0x22: op_combine<2, true>(lds, lane, side); break;
-                case 0x39: op_rone9<CH>(TA, lds, lane, side, absmask, signmask, S); break;
+                case 0x39: op_rone9<CH, I8>(TA, lds, lane, side, absmask, signmask, S); break;
                 case 0x38: op_rone8<CH>(lds, lane, lane16, side, absmask, signmask, S); break;
                 case 0x37: op_rone7(lds, lane, lane16, side, absmask, signmask); break;
                 case 0x36: op_rone<6>(lds, lane, side, signmask); break;
@@ -1445,7 +1447,7 @@ void sc_pair_kernel(const DecodeParams P)
                 if ((P.ablate & 512u) && d1 - i <= 6u) continue;
 #endif
                 switch ((kind << 4) | (d1 - i)) {
-                case 0x09: dn_top<CH, 0>(TA, lds, lane, absmask, signmask, S); break;
+                case 0x09: dn_top<CH, I8, 0>(TA, lds, lane, absmask, signmask, S); break;
                 case 0x08: op_s8<CH, 0>(lane16, absmask, signmask, S); break;
                 case 0x07: dn_s7<CH, 0>(lane16, absmask, signmask, S); break;
                 case 0x06: dn_f<CH, 6>(absmask, S); break;
@@ -1453,7 +1455,7 @@ void sc_pair_kernel(const DecodeParams P)
                 case 0x04: dn_f<CH, 4>(absmask, S); break;
                 case 0x03: dn_f<CH, 3>(absmask, S); break;
                 case 0x02: dn_f<CH, 2>(absmask, S); break;
-                case 0x19: dn_top<CH, 1>(TA, lds, lane, absmask, signmask, S); break;
+                case 0x19: dn_top<CH, I8, 1>(TA, lds, lane, absmask, signmask, S); break;
                 case 0x18: op_s8<CH, 1>(lane16, absmask, signmask, S); break;
                 case 0x17: dn_s7<CH, 1>(lane16, absmask, signmask, S); break;
                 case 0x16: dn_g<CH, 6>(signmask, S); break;
@@ -1461,7 +1463,7 @@ void sc_pair_kernel(const DecodeParams P)
                 case 0x14: dn_g<CH, 4>(signmask, S); break;
                 case 0x13: dn_g<CH, 3>(signmask, S); break;
                 case 0x12: dn_g<CH, 2>(signmask, S); break;
-                case 0x29: dn_top<CH, 2>(TA, lds, lane, absmask, signmask, S); break;
+                case 0x29: dn_top<CH, I8, 2>(TA, lds, lane, absmask, signmask, S); break;
                 case 0x28: op_s8<CH, 2>(lane16, absmask, signmask, S); break;
                 case 0x27: dn_s7<CH, 2>(lane16, absmask, signmask, S); break;
                 case 0x26: dn_g0<CH, 6>(S); break;
@@ -1654,10 +1656,11 @@ void sc_pair_kernel(const DecodeParams P)
     }
 }
 
-hipError_t launch_sc_pair(const DecodeParams& P, unsigned grid, hipStream_t st)
+hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, unsigned grid, hipStream_t st)
 {
-    if (P.chr) hipLaunchKernelGGL(sc_pair_kernel<true>, dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
-    else hipLaunchKernelGGL(sc_pair_kernel<false>, dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    if (P.chr) hipLaunchKernelGGL((sc_pair_kernel<true, true>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    else if (i8rows) hipLaunchKernelGGL((sc_pair_kernel<false, true>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    else hipLaunchKernelGGL((sc_pair_kernel<false, false>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
     return hipGetLastError();
 }
 

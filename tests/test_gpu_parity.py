@@ -357,6 +357,28 @@ def test_pair_kernel_codes(built_library, K, dsnr, kind):
             assert np.array_equal(ok.astype(np.uint8), e_ok[:cnt])
 
 
+def test_pair_kernel_int8_rows_into_the_float_decoder(built_library):
+    """decode_vector(const char*) of the float decoder (the values converted, float arithmetic; fastssc_avx_float.cpp:940-955 via
+    FloatContainer::insertCharLlr): int8 rows must decode like the same values as fp32 rows, here on the two-lanes-per-codeword
+    kernel's third instantiation (int8 rows fetched as whole lines, float f / g), and like the oracle"""
+    import pypolar_amd
+    N, K = 1024, 512
+    rng = np.random.default_rng(99)
+    frozen = np.asarray(pypolar_amd.frozen_bits(N, K, 0.0, "BB"), dtype=np.uint32)
+    rows = 333
+    q = np.clip(np.round(8.0 * (1.0 + 0.9 * rng.standard_normal((rows, N)))), -128, 127).astype(np.int8)
+    q[:40] = rng.integers(-3, 4, (40, N)).astype(np.int8)
+    for systematic, det in ((True, 8), (False, 0)):
+        d = pypolar_amd.PolarDecoder(N, 1, frozen, "float")
+        d.setErrorDetection(det, "crc")
+        d.setSystematic(systematic)
+        o8, k8 = d.decode_batch(q)
+        of, kf = d.decode_batch(q.astype(np.float32))
+        e_out, e_ok, _ = ob.decode_batch(N, 1, frozen, det, q.astype(np.float32), systematic, "float")
+        assert np.array_equal(o8, of) and np.array_equal(k8, kf)
+        assert np.array_equal(o8, e_out) and np.array_equal(k8.astype(np.uint8), e_ok)
+
+
 def test_cpp_shim_decodes_on_gpu(built_library):
     """C++ host side (polar_decoder.hpp over the C ABI): N=8 known answer of decodingtest.cpp:1143-1173"""
     import subprocess
@@ -578,7 +600,7 @@ def test_mixed_decoder_grid(built_library, N, L):
 
 
 FUSE_SWITCHES = ["PCD_NO_FUSE", "PCD_NO_FUSE_C", "PCD_NO_FUSE_R0", "PCD_NO_FUSE_G0", "PCD_NO_FUSE_GRAND", "PCD_NO_FUSE_CW",
-                 "PCD_NO_FUSE_F", "PCD_NO_FUSE_G", "PCD_SC_NO_SKEW", "PCD_NO_VTOP", "PCD_NO_VIRTUAL", "PCD_NO_WFG", "PCD_VG2", "PCD_NO_LANE", "PCD_FORCE_LANE"]
+                 "PCD_NO_FUSE_F", "PCD_NO_FUSE_G", "PCD_SC_NO_SKEW", "PCD_NO_VTOP", "PCD_NO_VIRTUAL", "PCD_NO_WFG", "PCD_VG2", "PCD_NO_LANE", "PCD_FORCE_LANE", "PCD_NO_PAIR"]
 
 
 @pytest.mark.parametrize("switch", FUSE_SWITCHES)
