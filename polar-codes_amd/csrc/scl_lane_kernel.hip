@@ -948,20 +948,11 @@ __device__ __forceinline__ void fork_tail(Path& p, uint32_t T, uint32_t side, We
         fl[2] = fl[3] = 0;
     }
     constexpr int NF = SPC ? 4 : 2;
+    uint32_t w[4] = { s0.x, s0.w, 0u, 0u };
     if (T <= 5u) {  // one word
-        uint32_t w0 = s0.x;
 #pragma unroll
-        for (int k = 0; k < NF; ++k) w0 ^= fl[k] << ((spk >> (8 * k)) & 31u);
-        const uint32_t o[1] = { w0 };
-        switch (T) {
-        case 5: put_bits<5>(p, side, o); break;
-        case 4: put_bits<4>(p, side, o); break;
-        case 3: put_bits<3>(p, side, o); break;
-        case 2: put_bits<2>(p, side, o); break;
-        default: put_bits<1>(p, side, o); break;
-        }
+        for (int k = 0; k < NF; ++k) w[0] ^= fl[k] << ((spk >> (8 * k)) & 31u);
     } else {
-        uint32_t w[4] = { s0.x, s0.w, 0u, 0u };
         if (T == 7u) {
             const uint4 s1 = sr[1];
             w[2] = s1.x;
@@ -973,13 +964,25 @@ __device__ __forceinline__ void fork_tail(Path& p, uint32_t T, uint32_t side, We
 #pragma unroll
             for (int i = 0; i < 4; ++i) w[i] ^= ((ix >> 5) == (uint32_t)i) ? (fl[k] << (ix & 31u)) : 0u;
         }
-        if (T == 7u) {
-            const uint32_t o[4] = { w[0], w[1], w[2], w[3] };
-            put_bits<7>(p, side, o);
-        } else {
-            const uint32_t o[2] = { w[0], w[1] };
-            put_bits<6>(p, side, o);
-        }
+    }
+    // (one flat switch over (stage, side): a switch over the stage around put_bits' branch on the side made the compiler thread
+    //  flag registers through the structured control flow -- see the G step of the walk)
+    switch ((T << 1) | side) {
+    case 2: wru<RB(0, 1)>(w[0]); break;
+    case 3: wru<RB(1, 1)>(w[0]); break;
+    case 4: wru<RB(0, 2)>(w[0]); break;
+    case 5: wru<RB(1, 2)>(w[0]); break;
+    case 6: wru<RB(0, 3)>(w[0]); break;
+    case 7: wru<RB(1, 3)>(w[0]); break;
+    case 8: wru<RB(0, 4)>(w[0]); break;
+    case 9: wru<RB(1, 4)>(w[0]); break;
+    case 10: wru<RB(0, 5)>(w[0]); break;
+    case 11: wru<RB(1, 5)>(w[0]); break;
+    case 12: wru<RBL6>(w[0]); wru<RBL6 + 1>(w[1]); break;
+    case 13: wru<RBR6>(w[0]); wru<RBR6 + 1>(w[1]); break;
+    case 14: wru<RBL7>(w[0]); wru<RBL7 + 1>(w[1]); wru<RBL7 + 2>(w[2]); wru<RBL7 + 3>(w[3]); break;
+    case 15: wru<RBR7>(w[0]); wru<RBR7 + 1>(w[1]); wru<RBR7 + 2>(w[2]); wru<RBR7 + 3>(w[3]); break;
+    default: break;
     }
 }
 
@@ -1412,28 +1415,24 @@ void scl_lane_kernel(const DecodeParams P)
                     if (c1 >= 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 sm.mark(1);
-                if (gk) {
-                    if (gk == 1u) {
-                        switch (gs) {
-                        case 8: op_fg8(p, 1, absmask, signmask); break;
-                        case 7: op_fg7<1>(p, absmask, signmask); break;
-                        case 6: op_fg_reg<1, 6>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
-                        case 5: op_fg_reg<1, 5>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
-                        case 4: op_fg_reg<1, 4>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
-                        case 3: op_fg_reg<1, 3>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
-                        default: op_fg_reg<1, 2>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
-                        }
-                    } else {
-                        switch (gs) {
-                        case 8: op_fg8(p, 2, absmask, signmask); break;
-                        case 7: op_fg7<2>(p, absmask, signmask); break;
-                        case 6: op_fg_reg<2, 6>(p, absmask, signmask); break;
-                        case 5: op_fg_reg<2, 5>(p, absmask, signmask); break;
-                        case 4: op_fg_reg<2, 4>(p, absmask, signmask); break;
-                        case 3: op_fg_reg<2, 3>(p, absmask, signmask); break;
-                        default: op_fg_reg<2, 2>(p, absmask, signmask); break;
-                        }
-                    }
+                // (ONE flat switch per step: nested if / switch ladders make the compiler thread flag registers through a structured
+                //  control flow graph -- dozens of scalar instructions per step; found on the SC pair kernel, where it was worth 16 %)
+                switch ((gk << 4) | gs) {
+                case 0x18: op_fg8(p, 1, absmask, signmask); break;
+                case 0x17: op_fg7<1>(p, absmask, signmask); break;
+                case 0x16: op_fg_reg<1, 6>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                case 0x15: op_fg_reg<1, 5>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                case 0x14: op_fg_reg<1, 4>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                case 0x13: op_fg_reg<1, 3>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                case 0x12: op_fg_reg<1, 2>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                case 0x28: op_fg8(p, 2, absmask, signmask); break;
+                case 0x27: op_fg7<2>(p, absmask, signmask); break;
+                case 0x26: op_fg_reg<2, 6>(p, absmask, signmask); break;
+                case 0x25: op_fg_reg<2, 5>(p, absmask, signmask); break;
+                case 0x24: op_fg_reg<2, 4>(p, absmask, signmask); break;
+                case 0x23: op_fg_reg<2, 3>(p, absmask, signmask); break;
+                case 0x22: op_fg_reg<2, 2>(p, absmask, signmask); break;
+                default: break;
                 }
                 sm.mark(2);
                 if (f1) {
@@ -1465,38 +1464,36 @@ void scl_lane_kernel(const DecodeParams P)
             }
             if (lk) {  // the leaf of this instruction (its own op, or the end of a walk): one instance of each leaf routine
                 is_leaf = true;
-                if (lk == 1u) {
-                    if (!(DIAG && (P.ablate & 32u))) {
-                        switch (lst) {
-                        case 8: leaf_r0<8>(p, lside); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                        case 7: leaf_r0<7>(p, lside); break;
-                        case 6: leaf_r0<6>(p, lside); break;
-                        case 5: leaf_r0<5>(p, lside); break;
-                        case 4: leaf_r0<4>(p, lside); break;
-                        case 3: leaf_r0<3>(p, lside); break;
-                        case 2: leaf_r0<2>(p, lside); break;
-                        default: leaf_r0<1>(p, lside); break;
-                        }
-                    }
-                } else if (lk == 4u) {
-                    if (!(DIAG && (P.ablate & 16u))) {
-                        if (lst == 2) leaf_rep<2>(p, lside, sm);
-                        else leaf_rep<1>(p, lside, sm);
-                    }
-                } else if (!(DIAG && (P.ablate & 8u))) {
-                    fkind = lk == 3u ? 2u : 1u;
-#pragma unroll 1
-                    for (uint32_t rep = 0; rep < ((DIAG && (P.ablate & 4096u)) ? 2u : 1u); ++rep)
-                        switch (lst) {
-                        case 7: leaf_scan<7>(p, ws); break;
-                        case 6: leaf_scan<6>(p, ws); break;
-                        case 5: leaf_scan<5>(p, ws); break;
-                        case 4: leaf_scan<4>(p, ws); break;
-                        case 3: leaf_scan<3>(p, ws); break;
-                        case 2: leaf_scan<2>(p, ws); break;
-                        default: leaf_scan<1>(p, ws); break;
-                        }
+                // class of the leaf: 1 all-frozen, 2 repetition, 3 RateOne / SPC (one scan serves both, the tails differ)
+                const uint32_t cls = lk == 1u ? 1u : (lk == 4u ? 2u : 3u);
+                fkind = cls == 3u ? (lk == 3u ? 2u : 1u) : 0u;
+                uint32_t lcode = (cls << 4) | lst;
+                if (DIAG && (((P.ablate & 32u) && cls == 1u) || ((P.ablate & 16u) && cls == 2u) || ((P.ablate & 8u) && cls == 3u))) {
+                    lcode = 0;
+                    fkind = 0;
                 }
+#pragma unroll 1
+                for (uint32_t rep = 0; rep < ((DIAG && (P.ablate & 4096u) && cls == 3u) ? 2u : 1u); ++rep)
+                    switch (lcode) {  // (flat: see the G step)
+                    case 0x18: leaf_r0<8>(p, lside); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 0x17: leaf_r0<7>(p, lside); break;
+                    case 0x16: leaf_r0<6>(p, lside); break;
+                    case 0x15: leaf_r0<5>(p, lside); break;
+                    case 0x14: leaf_r0<4>(p, lside); break;
+                    case 0x13: leaf_r0<3>(p, lside); break;
+                    case 0x12: leaf_r0<2>(p, lside); break;
+                    case 0x11: leaf_r0<1>(p, lside); break;
+                    case 0x22: leaf_rep<2>(p, lside, sm); break;
+                    case 0x21: leaf_rep<1>(p, lside, sm); break;
+                    case 0x37: leaf_scan<7>(p, ws); break;
+                    case 0x36: leaf_scan<6>(p, ws); break;
+                    case 0x35: leaf_scan<5>(p, ws); break;
+                    case 0x34: leaf_scan<4>(p, ws); break;
+                    case 0x33: leaf_scan<3>(p, ws); break;
+                    case 0x32: leaf_scan<2>(p, ws); break;
+                    case 0x31: leaf_scan<1>(p, ws); break;
+                    default: break;
+                    }
             }
             sm.mark(0);
             if (DIAG && (P.ablate & 4u)) fkind = 0;
