@@ -77,7 +77,7 @@ struct pcd_decoder {
     bool has_lane = false;
     pamd::Ins* d_lane_prog = nullptr;
     pamd::Program pair_prog;          // two-lanes-per-codeword SC kernel (sc_pair_kernel.hip)
-    bool has_pair = false;
+    bool has_pair = false, pair_big = false;  // pair_big: the tree has a leaf above 128 positions (the BIG instantiations)
     pamd::Ins* d_pair_prog = nullptr;
     uint32_t* d_ext = nullptr;        // extraction masks per 32 code bits (deposit_table)
     uint32_t* d_syn_bytes = nullptr;  // nb x 256 syndrome words per output byte value
@@ -748,7 +748,7 @@ int run_sc_pair(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     if (const char* e = PAMD_ENV("PCD_PAIR_BLOCKS_PER_CU")) per_cu = (unsigned)std::max(1, std::min(4, std::atoi(e)));  // experiments
     unsigned grid = std::max(1u, std::min(need, (unsigned)d->num_cu * per_cu));
     if (const char* e = PAMD_ENV("PCD_PAIR_GRID")) grid = (unsigned)std::max(1, std::atoi(e));  // experiments
-    HIP_TRY(pamd::launch_sc_pair(P, i8, grid, st));
+    HIP_TRY(pamd::launch_sc_pair(P, i8, d->pair_big, grid, st));
     return PCD_OK;
 }
 
@@ -1153,7 +1153,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         d->has_sc = true;
         // the two-lanes-per-codeword kernel takes the float codes it has every op for (lowered from the plain program,
         // before fuse_sc rewrites it for sc_decode_kernel)
-        if (!PAMD_ENV("PCD_NO_PAIR")) d->has_pair = pamd::lower_pair(d->logN, d->sc_prog, d->pair_prog, chr);
+        if (!PAMD_ENV("PCD_NO_PAIR")) d->has_pair = pamd::lower_pair(d->logN, d->sc_prog, d->pair_prog, chr, &d->pair_big);
     }
     if (d->L > 1) {
         pamd::compile_scl(d->N, d->frozen, d->scl_prog, chr);

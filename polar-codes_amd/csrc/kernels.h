@@ -54,7 +54,8 @@ hipError_t launch_scl_lane(const DecodeParams& P, bool diag, unsigned grid, hipS
 unsigned scl_lane_arena_words();
 // two-lanes-per-codeword SC kernel (sc_pair_kernel.hip): N = 1024, fp32 or int8 rows (P.chr: the int8 decoder, int8 rows only); P.prog = the PR_* program, P.ext / P.syn_bytes as for
 // the lane kernel; single-wave workgroups with 40 KB of dynamic LDS
-hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, unsigned grid, hipStream_t st);
+// big: the code has a leaf above 128 positions (lower_pair reports it): the instantiation that carries those leaves
+hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
 // CharContainer::insertLlr(const float*) (bitcontainer.cpp:449-516, N >= 8): round to nearest even, saturate to int8
 hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st);
 hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,

@@ -4,11 +4,13 @@
 
 namespace pamd {
 
-bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr)
+bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr, bool* needs_big)
 {
     out = Program();
     out.leaves = sc.leaves;
     out.inner = sc.inner;
+    bool big = false;  // a leaf above 128 positions: the BIG instantiations of the kernel
+    if (needs_big) *needs_big = false;
     if (logN != 10) return false;
     auto put = [&](Op op, unsigned stage, unsigned side) {
         Ins i;
@@ -28,6 +30,7 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr)
         const unsigned side = s == logN ? 0u : ((x.off >> s) & 1u);  // the block [off, off + 2^s) is a right child
         auto leaf = [&](Op op, unsigned lo, unsigned hi) {
             if (T < lo || T > hi) return false;
+            if (T >= 7) big = true;
             put(op, T, side);
             return true;
         };
@@ -52,19 +55,19 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr)
         case SC_RONE: if (T < 2) return false; put(PR_RONE, T, side); break;
         case SC_R0: ok = leaf(PR_R0, 1, 2); break;
         case SC_R1: ok = leaf(PR_R1, 1, 2); break;
-        case SC_REP: ok = leaf(PR_REP, 1, 6); break;
-        case SC_SPC: ok = leaf(PR_SPC, 1, 6); break;
-        case SC_DREP: ok = leaf(PR_DREP, 1, 6); break;
+        case SC_REP: ok = leaf(PR_REP, 1, 8); break;
+        case SC_SPC: ok = leaf(PR_SPC, 1, 8); break;
+        case SC_DREP: ok = leaf(PR_DREP, 1, 8); break;
         case SC_DSPC: ok = leaf(PR_DSPC, 3, 6); break;
         case SC_DSPC8: ok = leaf(PR_DSPC8, 2, 2); break;
-        case SC_TREP: ok = leaf(PR_TREP, 3, 6); break;
-        case SC_TYPE5: ok = leaf(PR_TYPE5, 2, 6); break;
+        case SC_TREP: ok = leaf(PR_TREP, 3, 8); break;
+        case SC_TYPE5: ok = leaf(PR_TYPE5, 2, 8); break;
         case SC_REPONE8: ok = leaf(PR_REPONE8, 2, 2); break;
         case SC_ZSPC8: ok = leaf(PR_ZSPC8, 2, 2); break;
         case SC_ZEROSPC: ok = leaf(PR_ZEROSPC, 3, 6); break;
-        case SCC_REP: ok = chr && leaf(PR_REP, 1, 6); break;
-        case SCC_SPC: ok = chr && leaf(PR_SPC, 1, 6); break;
-        case SCC_DREP: ok = chr && leaf(PR_DREP, 4, 6); break;
+        case SCC_REP: ok = chr && leaf(PR_REP, 1, 8); break;
+        case SCC_SPC: ok = chr && leaf(PR_SPC, 1, 8); break;
+        case SCC_DREP: ok = chr && leaf(PR_DREP, 4, 8); break;
         case SCC_ZEROSPC: ok = chr && leaf(PR_ZEROSPC, 2, 6); break;
         default: return false;
         }
@@ -124,6 +127,7 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr)
     }
     put(OP_END, 0, 0);
     put(OP_END, 0, 0);  // (the kernel fetches one instruction ahead)
+    if (needs_big) *needs_big = big;
     return true;
 }
 

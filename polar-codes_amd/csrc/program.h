@@ -143,9 +143,10 @@ std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program
 // stage 8, ...): the caller then keeps the path-group kernels.
 bool lower_lane(unsigned logN, const Program& scl, Program& out);
 // Lowers a plain SC program (compile_sc output; chr: of the int8 decoder) of a code with N = 1024 to the program of the
-// two-lanes-per-codeword kernel.  Returns false when the tree needs an op that kernel does not have (a leaf or a ROne node
-// above 128 positions, ...): the caller then keeps sc_decode_kernel.
-bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr = false);
+// two-lanes-per-codeword kernel.  Returns false when the tree needs an op that kernel does not have (a double-SPC leaf above 128
+// positions, ...): the caller then keeps sc_decode_kernel.  *needs_big: the tree has a leaf above 128 positions (the BIG
+// instantiations of the kernel).
+bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr = false, bool* needs_big = nullptr);
 
 // ---- error detection -------------------------------------------------------------------------
 // All supported detectors are linear over GF(2) with a zero initial value, so

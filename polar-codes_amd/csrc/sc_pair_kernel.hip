@@ -820,9 +820,6 @@ __device__ __forceinline__ void sign_words_s8(uint32_t (&w)[8])
     });
 }
 
-// (Leaves of 256 / 512 positions -- the block in the LDS column / the AGPRs, worked on 64 values at a time -- were built and are
-//  bit-exact, but their mere presence in the kernel cost the common trees 10-13 % at 2^20 codewords (identical hot loop, different
-//  code placement): such trees keep sc_decode_kernel.  DESIGN.md section 3.6.)
 // ---- leaves (local stage T <= 6: the block sits in v[RS(T) ..)) ----------------------------------------------------------
 struct Lane {
     uint32_t* lds;
@@ -837,13 +834,44 @@ __device__ __forceinline__ uint32_t maskw(int i)
 }
 // the 8 accumulators of fold8 ("acc = 0; acc += x[8k + v]", avx_float.h:238-243): this lane's four -- acc[s] belongs to
 // AVX lane (s & 1) + 4 (s >> 1) + 2 p
+// Leaves above 128 positions (T = 7: the block is the LDS column, T = 8: the AGPRs; only in the BIG instantiations of the kernel,
+// which the host picks for the codes that need them -- in the others their mere presence cost 10-13 %) work
+// on 64 values at a time, brought into the registers of stage 6 (dead under a leaf): part Q = local elements 64 Q .. 64 Q + 63
 template <int T>
-__device__ __forceinline__ void fold4(float (&acc)[4])
+struct Parts { static constexpr int N = T <= 6 ? 1 : (1 << (T - 6)); };
+template <int T, int Q>
+__device__ __forceinline__ void load_part(int lane)
 {
-    constexpr int m = 1 << T;
+    static_assert(T == 7 || T == 8, "stage");
+    if constexpr (T == 7) {
+        const uint32_t ad = (uint32_t)lane << 4;
+#define PR_RDC(c) "ds_read_b128 v[%[d]+4*" #c ":%[d]+4*" #c "+3], %[ad] offset:%[o]+1024*" #c "\n\t"
+        asm volatile(PR_RDC(0) PR_RDC(1) PR_RDC(2) PR_RDC(3) PR_RDC(4) PR_RDC(5) PR_RDC(6) PR_RDC(7) PR_RDC(8) PR_RDC(9) PR_RDC(10) PR_RDC(11)
+                     PR_RDC(12) PR_RDC(13) PR_RDC(14) PR_RDC(15) "s_waitcnt lgkmcnt(0)"
+                     :
+                     : [d] "n"(RS(6)), [ad] "v"(ad), [o] "n"(4 * LDS_S7 + 16384 * Q)
+                     : "memory");
+#undef PR_RDC
+    } else {
+        static_for<64>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            asm volatile("v_accvgpr_read_b32 v[%0], a[%1]" ::"n"(RS(6) + i), "n"(64 * Q + i));
+        });
+    }
+}
+template <int T>
+__device__ __forceinline__ void fold4(const Lane& L, float (&acc)[4])
+{
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[s] = 0.0f;
-    add_run4<RS(T), m>(acc);
+    if constexpr (T <= 6) {
+        add_run4<RS(T), (1 << T)>(acc);
+    } else {
+        static_for<Parts<T>::N>([&](auto Qc) {
+            load_part<T, decltype(Qc)::value>(L.lane);
+            add_run4<RS(6), 64>(acc);
+        });
+    }
 }
 // ... all eight, in both lanes, in the reference's order
 __device__ __forceinline__ void gather8(const Lane& L, const float (&acc)[4], float (&a)[8])
@@ -895,7 +923,7 @@ template <int T>
 __device__ __forceinline__ void leaf_rep(const Lane& L, uint32_t side)
 {
     float acc[4], a[8];
-    fold4<T>(acc);
+    fold4<T>(L, acc);
     gather8(L, acc, a);
     const float s = ((((((a[0] + a[1]) + a[2]) + a[3]) + a[4]) + a[5]) + a[6]) + a[7];
     uint32_t w[Words<T>::N];
@@ -970,7 +998,7 @@ template <int T>
 __device__ __forceinline__ void leaf_drep(const Lane& L, uint32_t side)
 {
     float acc[4];
-    fold4<T>(acc);
+    fold4<T>(L, acc);
     float e, o;
     if constexpr (T >= 2) {  // e = (a0 + a4) + (a2 + a6): one bracket per lane
         const float eo = acc[0] + acc[2], oo = acc[1] + acc[3];
@@ -1075,7 +1103,7 @@ template <int T>
 __device__ __forceinline__ void leaf_trep(const Lane& L, uint32_t side)
 {
     float acc[4];
-    fold4<T>(acc);
+    fold4<T>(L, acc);
     uint32_t r0, r1;
     spc4_pair(acc[0] + acc[2], acc[1] + acc[3], r0, r1);
     const uint32_t pat = (r0 ? 0x55555555u : 0u) | (r1 ? 0xAAAAAAAAu : 0u);
@@ -1092,7 +1120,7 @@ __device__ __forceinline__ void leaf_type5(const Lane& L, uint32_t side)
 {
     float l4[4];
     if constexpr (FOLD) {
-        fold4<T>(l4);
+        fold4<T>(L, l4);
     } else {
         static_assert(T == 2, "block of 8");
         static_for<4>([&](auto I) { l4[decltype(I)::value] = rdf<RS(2) + decltype(I)::value>(); });
@@ -1130,17 +1158,30 @@ __device__ __forceinline__ void leaf_zspc8(const Lane& L, uint32_t side)
 __device__ __forceinline__ float sat8f(float v) { return __builtin_amdgcn_fmed3f(v, -128.0f, 127.0f); }
 // the 32 byte-lane accumulators "LlrSum = adds(LlrSum, load(LlrIn + i))" (:219-234, a block of at most 32 positions is one
 // zero-padded vector): this lane's sixteen -- v[s] belongs to byte lane 4 (s >> 1) + 2 p + (s & 1)
+#define PR_V16_OPS [v0] "+v"(v[0]), [v1] "+v"(v[1]), [v2] "+v"(v[2]), [v3] "+v"(v[3]), [v4] "+v"(v[4]), [v5] "+v"(v[5]), [v6] "+v"(v[6]), [v7] "+v"(v[7]), \
+                   [v8] "+v"(v[8]), [v9] "+v"(v[9]), [v10] "+v"(v[10]), [v11] "+v"(v[11]), [v12] "+v"(v[12]), [v13] "+v"(v[13]), [v14] "+v"(v[14]), [v15] "+v"(v[15])
+// v[k & 15] = sat(v[k & 15] + v[RS(6) + k]), k < 64
+__device__ __forceinline__ void satadd_part(float (&v)[16], float mm, float cc)
+{
+    asm volatile(PR_RUN_SATADD_ALL_64 : PR_V16_OPS : [r] "n"(RS(6)), [m] "v"(mm), [c] "s"(cc));
+}
 template <int T>
-__device__ __forceinline__ void lane_sums16(float (&v)[16])
+__device__ __forceinline__ void lane_sums16(const Lane& L, const Sat& S, float (&v)[16])
 {
     constexpr int m = 1 << T;
 #pragma unroll
     for (int s = 0; s < 16; ++s) v[s] = 0.0f;
-    static_for<(m < 16 ? m : 16)>([&](auto I) { v[decltype(I)::value] = rdf<RS(T) + decltype(I)::value>(); });
-    if constexpr (m > 16) {
-        static_for<m - 16>([&](auto I) {
-            constexpr int i = 16 + decltype(I)::value;
-            v[i & 15] = sat8f(v[i & 15] + rdf<RS(T) + i>());
+    const float cc = S.c127, mm = S.m128;
+    if constexpr (m < 16) {
+        static_for<m>([&](auto I) { v[decltype(I)::value] = rdf<RS(T) + decltype(I)::value>(); });
+    } else if constexpr (T <= 6) {
+        asm volatile(PR_RUN_LOAD_16 : PR_V16_OPS : [r] "n"(RS(T)));
+        if constexpr (m == 32) asm volatile(PR_RUN_SATADD_16 : PR_V16_OPS : [r] "n"(RS(T)), [m] "v"(mm), [c] "s"(cc));
+        if constexpr (m == 64) asm volatile(PR_RUN_SATADD_48 : PR_V16_OPS : [r] "n"(RS(T)), [m] "v"(mm), [c] "s"(cc));
+    } else {  // above 128 positions: over the parts (sat(0 + x) = x, so the first sixteen need no special case)
+        static_for<Parts<T>::N>([&](auto Qc) {
+            load_part<T, decltype(Qc)::value>(L.lane);
+            satadd_part(v, mm, cc);
         });
     }
 }
@@ -1148,10 +1189,10 @@ __device__ __forceinline__ void lane_sums16(float (&v)[16])
 // lane sums -- pairs (l, l + 16), (l, l + 8), (l, l + 4) are local (slots s + 8, s + 4, s + 2), (l, l + 2) is the other lane's
 // same slot, (0, 1) local again
 template <int T>
-__device__ __forceinline__ void leaf_rep_ch(const Lane& L, uint32_t side)
+__device__ __forceinline__ void leaf_rep_ch(const Lane& L, uint32_t side, const Sat& S)
 {
     float v[16];
-    lane_sums16<T>(v);
+    lane_sums16<T>(L, S, v);
 #pragma unroll
     for (int s = 0; s < 8; ++s) v[s] = sat8f(v[s] + v[s + 8]);
 #pragma unroll
@@ -1168,10 +1209,10 @@ __device__ __forceinline__ void leaf_rep_ch(const Lane& L, uint32_t side)
 // DoubleRepetitionDecoder :242-257 (blocks of 32 positions and more): half_reduce_adds_epi8 (avxconvenience.h:202-210) -- every
 // byte lane ends as the saturating butterfly sum of its parity class; even positions take the even class's sign
 template <int T>
-__device__ __forceinline__ void leaf_drep_ch(const Lane& L, uint32_t side)
+__device__ __forceinline__ void leaf_drep_ch(const Lane& L, uint32_t side, const Sat& S)
 {
     float v[16], a[16], b[16];
-    lane_sums16<T>(v);
+    lane_sums16<T>(L, S, v);
 #pragma unroll
     for (int s = 0; s < 16; ++s) a[s] = sat8f(v[s] + v[s ^ 8]);
 #pragma unroll
@@ -1262,6 +1303,59 @@ __device__ __forceinline__ void leaf_zerospc_ch(const Lane& L, uint32_t side, co
     }
     put_bits<T>(L.lds, L.lane, side, w);
 }
+// SpcDecoder on a block above 128 positions (T = 7, 8), float (SpcDecoder :342-373) or int8 (:268-297, vector-wise search): two
+// passes over the parts -- hard decisions and the minimum magnitude, then the first position of that minimum
+template <bool CH, int T>
+__device__ __forceinline__ void leaf_spc_big(const Lane& L, uint32_t side)
+{
+    constexpr int NW = Words<T>::N, NP = Parts<T>::N;
+    uint32_t w[NW];
+    float mn = bitsf(0x7F800000u), x0 = 0.0f;
+    static_for<NP>([&](auto Qc) {
+        constexpr int q = decltype(Qc)::value;
+        load_part<T, q>(L.lane);
+        if constexpr (q == 0) x0 = rdf<RS(6)>();
+        w[2 * q] = sign_run<RS(6), 32>();
+        w[2 * q + 1] = sign_run<RS(6) + 32, 32>();
+        amin_run<RS(6), 64>(mn);
+    });
+    uint32_t par = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) par ^= (uint32_t)__builtin_popcount(w[i]);
+    par &= 1u;
+    par ^= px(par);
+    const float om = pxf(mn);
+    const float mall = om < mn ? om : mn;
+    uint32_t j = 0xFFFFu;
+    static_for<NP>([&](auto Qc) {
+        constexpr int q = decltype(Qc)::value;
+        load_part<T, q>(L.lane);
+        const uint32_t e0 = eq_run<RS(6), 32>(mall), e1 = eq_run<RS(6) + 32, 32>(mall);
+        const uint32_t jq = e0 ? (uint32_t)(64 * q) + (uint32_t)__builtin_ctz(e0) : (e1 ? (uint32_t)(64 * q + 32) + (uint32_t)__builtin_ctz(e1) : 0xFFFFu);
+        j = j == 0xFFFFu ? jq : j;
+    });
+    uint32_t mine = j == 0xFFFFu ? 0xFFFFu : real_index(j, L.p);
+    bool doit = par != 0;
+    float vj = mall;
+    if constexpr (CH) {
+        if (mall >= 127.0f) {  // (vector-wise search from 127: nothing below -> position 0)
+            j = 0;
+            mine = L.p ? 0xFFFFu : 0u;
+            vj = absf(x0);
+        }
+    }
+    const uint32_t other = px(mine);
+    doit = doit && mine < other;
+    if constexpr (CH) {  // the char negation keeps the sign of 0 and of -128
+        uint32_t sj = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) sj |= ((j >> 5) == (uint32_t)i) ? ((w[i] >> (j & 31u)) & 1u) : 0u;
+        doit = doit && vj != 0.0f && !(vj == 128.0f && sj);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) w[i] ^= (doit && (j >> 5) == (uint32_t)i) ? (1u << (j & 31u)) : 0u;
+    put_bits<T>(L.lds, L.lane, side, w);
+}
 // ShortZeroOneDecoder :386-395 on a block of 4 positions (G0R / RateOne / COMBINE0R of the plain program): both halves =
 // sat(a + b), a and b sit in the two lanes
 __device__ __forceinline__ void leaf_zr1(const Lane& L, uint32_t side)
@@ -1327,7 +1421,8 @@ __device__ __forceinline__ void op_rone9(const TopAddr& A, uint32_t* lds, int la
 // =====================================================================================================================
 // CH: the int8 decoder's arithmetic (FastSscFipChar); I8: the rows are int8 (always with CH; without it the float decoder fed the
 // decode_vector(const char*) way: the values converted on the way in, float arithmetic)
-template <bool CH, bool I8>
+// BIG: with the leaves above 128 positions (a property of the code: the host picks the instantiation per decoder)
+template <bool CH, bool I8, bool BIG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(pair::KV)))
 void sc_pair_kernel(const DecodeParams P)
 {
@@ -1478,20 +1573,56 @@ void sc_pair_kernel(const DecodeParams P)
                 const uint32_t side = lastk != 0u ? 1u : 0u;
 #define PR_LF(K_, T_) (((K_) - PR_R0 + 1) << 3 | (T_))
                 const uint32_t lst = d1 - ndn, lsd = side;
+                bool done = false;
+                if constexpr (BIG) {
+                    if (lst >= 7u) {  // leaves of 256 / 512 positions: the block is the LDS column / the AGPRs
+                        done = true;
+                        const uint32_t bcode = (lk << 1) | (lst & 1u);
+#define PR_BL(K_, T_) ((((K_) - PR_R0 + 1) << 1) | ((T_) & 1))
+                        if constexpr (CH) {
+                            switch (bcode) {
+                            case PR_BL(PR_REP, 7): leaf_rep_ch<7>(L, lsd, S); break;
+                            case PR_BL(PR_REP, 8): leaf_rep_ch<8>(L, lsd, S); break;
+                            case PR_BL(PR_SPC, 7): leaf_spc_big<true, 7>(L, lsd); break;
+                            case PR_BL(PR_SPC, 8): leaf_spc_big<true, 8>(L, lsd); break;
+                            case PR_BL(PR_DREP, 7): leaf_drep_ch<7>(L, lsd, S); break;
+                            case PR_BL(PR_DREP, 8): leaf_drep_ch<8>(L, lsd, S); break;
+                            default: break;
+                            }
+                        } else {
+                            switch (bcode) {
+                            case PR_BL(PR_REP, 7): leaf_rep<7>(L, lsd); break;
+                            case PR_BL(PR_REP, 8): leaf_rep<8>(L, lsd); break;
+                            case PR_BL(PR_SPC, 7): leaf_spc_big<false, 7>(L, lsd); break;
+                            case PR_BL(PR_SPC, 8): leaf_spc_big<false, 8>(L, lsd); break;
+                            case PR_BL(PR_DREP, 7): leaf_drep<7>(L, lsd); break;
+                            case PR_BL(PR_DREP, 8): leaf_drep<8>(L, lsd); break;
+                            case PR_BL(PR_TREP, 7): leaf_trep<7>(L, lsd); break;
+                            case PR_BL(PR_TREP, 8): leaf_trep<8>(L, lsd); break;
+                            case PR_BL(PR_TYPE5, 7): leaf_type5<7, true>(L, lsd); break;
+                            case PR_BL(PR_TYPE5, 8): leaf_type5<8, true>(L, lsd); break;
+                            default: break;
+                            }
+                        }
+#undef PR_BL
+                    }
+                }
+                if (!done) {
                 if constexpr (CH) {
                     switch ((lk << 3) | lst) {
                     case PR_LF(PR_R0, 1): leaf_r0<1>(L, lsd); break;
                     case PR_LF(PR_R0, 2): leaf_r0<2>(L, lsd); break;
                     case PR_LF(PR_R1, 1): leaf_r1<1>(L, lsd); break;
                     case PR_LF(PR_R1, 2): leaf_r1<2>(L, lsd); break;
-#define PR_LEAF_1_6(K_, FN) case PR_LF(K_, 1): FN<1>(L, lsd); break; case PR_LF(K_, 2): FN<2>(L, lsd); break; case PR_LF(K_, 3): FN<3>(L, lsd); break; \
-                            case PR_LF(K_, 4): FN<4>(L, lsd); break; case PR_LF(K_, 5): FN<5>(L, lsd); break; case PR_LF(K_, 6): FN<6>(L, lsd); break;
-                    PR_LEAF_1_6(PR_REP, leaf_rep_ch)
+#define PR_LEAF_1_6(K_, FN, ...) case PR_LF(K_, 1): FN<1>(L, lsd, ##__VA_ARGS__); break; case PR_LF(K_, 2): FN<2>(L, lsd, ##__VA_ARGS__); break; \
+                                 case PR_LF(K_, 3): FN<3>(L, lsd, ##__VA_ARGS__); break; case PR_LF(K_, 4): FN<4>(L, lsd, ##__VA_ARGS__); break; \
+                                 case PR_LF(K_, 5): FN<5>(L, lsd, ##__VA_ARGS__); break; case PR_LF(K_, 6): FN<6>(L, lsd, ##__VA_ARGS__); break;
+                    PR_LEAF_1_6(PR_REP, leaf_rep_ch, S)
                     PR_LEAF_1_6(PR_SPC, leaf_spc_ch)
 #undef PR_LEAF_1_6
-                    case PR_LF(PR_DREP, 4): leaf_drep_ch<4>(L, lsd); break;
-                    case PR_LF(PR_DREP, 5): leaf_drep_ch<5>(L, lsd); break;
-                    case PR_LF(PR_DREP, 6): leaf_drep_ch<6>(L, lsd); break;
+                    case PR_LF(PR_DREP, 4): leaf_drep_ch<4>(L, lsd, S); break;
+                    case PR_LF(PR_DREP, 5): leaf_drep_ch<5>(L, lsd, S); break;
+                    case PR_LF(PR_DREP, 6): leaf_drep_ch<6>(L, lsd, S); break;
                     case PR_LF(PR_ZEROSPC, 2): leaf_zerospc_ch<2>(L, lsd, S); break;
                     case PR_LF(PR_ZEROSPC, 3): leaf_zerospc_ch<3>(L, lsd, S); break;
                     case PR_LF(PR_ZEROSPC, 4): leaf_zerospc_ch<4>(L, lsd, S); break;
@@ -1530,6 +1661,7 @@ void sc_pair_kernel(const DecodeParams P)
 #undef PR_LEAF_1_6
 #undef PR_LEAF_3_6
 #undef PR_LF
+                }
             }
 #ifdef PAMD_DIAG
             if (P.cycles && grp == 0) {  // diagnostics: cycles this instruction took for the first group
@@ -1656,11 +1788,26 @@ void sc_pair_kernel(const DecodeParams P)
     }
 }
 
-hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, unsigned grid, hipStream_t st)
+// (explicit instantiations in this order: the code object then starts with the kernels of the BASELINE configurations, and what is
+//  added behind them does not move them -- their speed depends on where their code sits)
+template __global__ void sc_pair_kernel<false, false, false>(const DecodeParams);
+template __global__ void sc_pair_kernel<true, true, false>(const DecodeParams);
+template __global__ void sc_pair_kernel<false, true, false>(const DecodeParams);
+template __global__ void sc_pair_kernel<false, false, true>(const DecodeParams);
+template __global__ void sc_pair_kernel<true, true, true>(const DecodeParams);
+template __global__ void sc_pair_kernel<false, true, true>(const DecodeParams);
+
+template <bool BIG>
+static void launch_sc_pair_t(const DecodeParams& P, bool i8rows, unsigned grid, hipStream_t st)
 {
-    if (P.chr) hipLaunchKernelGGL((sc_pair_kernel<true, true>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
-    else if (i8rows) hipLaunchKernelGGL((sc_pair_kernel<false, true>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
-    else hipLaunchKernelGGL((sc_pair_kernel<false, false>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    if (P.chr) hipLaunchKernelGGL((sc_pair_kernel<true, true, BIG>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    else if (i8rows) hipLaunchKernelGGL((sc_pair_kernel<false, true, BIG>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    else hipLaunchKernelGGL((sc_pair_kernel<false, false, BIG>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+}
+hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st)
+{
+    if (big) launch_sc_pair_t<true>(P, i8rows, grid, st);
+    else launch_sc_pair_t<false>(P, i8rows, grid, st);
     return hipGetLastError();
 }
 

@@ -329,8 +329,9 @@ PAIR_CODES = [(512, 0.0, "BB"), (400, 0.0, "BB"), (640, 1.0, "BB"), (176, 0.0, "
 
 @pytest.mark.parametrize("K,dsnr,kind", PAIR_CODES, ids=[f"K{k}_{c}_{d}" for k, d, c in PAIR_CODES])
 def test_pair_kernel_codes(built_library, K, dsnr, kind):
-    """The two-lanes-per-codeword SC kernel (N = 1024, float) over rates and constructions -- whatever tree its lowering
-    cannot express falls back to sc_decode_kernel, the results must be the reference's either way -- on AWGN, pure-noise and
+    """The two-lanes-per-codeword SC kernel (N = 1024, float) over rates and constructions (the extreme rates run on its
+    instantiations with the leaves of 256 / 512 positions) -- whatever tree its lowering cannot express falls back to
+    sc_decode_kernel, the results must be the reference's either way -- on AWGN, pure-noise and
     tie-heavy rows, ragged batch sizes (the last wave of 32 codewords partly idle), systematic and not, with and without a
     detector."""
     import pypolar_amd
