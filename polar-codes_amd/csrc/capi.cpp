@@ -1158,14 +1158,13 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
     if (d->L > 1) {
         pamd::compile_scl(d->N, d->frozen, d->scl_prog, chr);
         d->has_scl = true;
-        // the lane-per-path kernel takes the codes it has every op for (its program is lowered from the plain one)
-        // (measured on one box, DESIGN.md section 3.5: cfg 3 -- 60 forking leaves -- 30.1 against 27.8 M cw/s, cfg 4 -- 40 forking
-        //  leaves, 35 all-frozen ones -- 38.2 against 40.2: its fixed cost per pass, four passes over the channel row, pays off
-        //  from about 48 forking leaves on)
+        // the lane-per-path kernel takes the codes it has every op for (its program is lowered from the plain one) from 48 leaves
+        // on: its fixed cost per pass (four passes over the channel row, the epilogue) wants a tree to spread over.  Measured at the
+        // end of round 3 (tools/lane_threshold.py, N = 1024, L = 8, 2^18 rows, lane against path-group kernels): 44 leaves (K = 64)
+        // 59.5 against 63.7 M cw/s, 50 leaves (K = 100) 55.4 against 48.9, cfg 4 (75 leaves) 45.0 against 40.2, cfg 3 (95) 34.0
+        // against 27.8.  (Until the leaves rode on the walks the line was 48 FORKING leaves and cfg 4 stayed on the path groups.)
         if (!chr && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) {
-            unsigned forks = 0;
-            for (const auto& in : d->scl_prog.ins) forks += (in.op == pamd::SCL_R1 || in.op == pamd::SCL_SPC || in.op == pamd::SCL_REP) ? 1u : 0u;
-            if (forks >= 48u || PAMD_ENV("PCD_FORCE_LANE")) d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog);
+            if (d->scl_prog.leaves >= 48u || PAMD_ENV("PCD_FORCE_LANE")) d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog);
         }
     }
     compute_geometry(d);
