@@ -113,6 +113,8 @@ struct pcd_decoder {
     size_t ring_bytes = 0;
     hipStream_t s_in = nullptr, s_run = nullptr;
     hipEvent_t ev_h2d[kRing] = { nullptr, nullptr, nullptr }, ev_run[kRing] = { nullptr, nullptr, nullptr };
+    float* d_f32 = nullptr;  // int8 list decoder on the lane kernel: its int8 rows widened to fp32
+    size_t d_f32_cap = 0;
     int8_t* d_i8 = nullptr;  // int8 decoders called with float rows: CharContainer::insertLlr(const float*) on the device
     size_t d_i8_cap = 0;
     uint8_t* d_out = nullptr;
@@ -810,7 +812,16 @@ int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
 
 int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
-    if (d->has_lane && !i8) return run_scl_lane(d, P, st);
+    if (d->has_lane && i8 == (d->dectype == 0)) {
+        if (i8) {  // int8 decoder: its lane kernel reads fp32 rows (exact widening; 4 bytes per LLR of scratch)
+            int rc = grow(d->d_f32, d->d_f32_cap, (size_t)P.rows * d->N * sizeof(float));
+            if (rc) return rc;
+            if (P.rowidx) return PCD_ERR_UNSUPPORTED;
+            HIP_TRY(pamd::launch_i8_to_f32(reinterpret_cast<const int8_t*>(P.llr), d->d_f32, (size_t)P.rows * d->N, st));
+            P.llr = d->d_f32;
+        }
+        return run_scl_lane(d, P, st);
+    }
     P.prog = d->d_scl_prog;
     if (!P.prog_len) P.prog_len = (uint32_t)d->scl_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->scl_wave_words;
@@ -1163,8 +1174,12 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         // end of round 3 (tools/lane_threshold.py, N = 1024, L = 8, 2^18 rows, lane against path-group kernels): 44 leaves (K = 64)
         // 59.5 against 63.7 M cw/s, 50 leaves (K = 100) 55.4 against 48.9, cfg 4 (75 leaves) 45.0 against 40.2, cfg 3 (95) 34.0
         // against 27.8.  (Until the leaves rode on the walks the line was 48 FORKING leaves and cfg 4 stayed on the path groups.)
-        if (!chr && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) {
-            if (d->scl_prog.leaves >= 48u || PAMD_ENV("PCD_FORCE_LANE")) d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog);
+        // (The int8 decoder SclFipChar runs on the same kernel -- saturating f / g, repetition leaves at every size, int8 rows
+        //  widened to fp32 on the way in -- and is exact there, but SLOWER than on the path-group kernels: 20.3 against 23.4 M cw/s
+        //  on cfg3_i8.  Integer metrics tie all the time and every tie sends the selection through the literal emulation of the
+        //  reference's sort.  Diagnostic build only, behind PCD_FORCE_LANE.)
+        if ((!chr || PAMD_ENV("PCD_FORCE_LANE")) && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) {
+            if (d->scl_prog.leaves >= 48u || PAMD_ENV("PCD_FORCE_LANE")) d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr);
         }
     }
     compute_geometry(d);
@@ -1212,6 +1227,7 @@ void pcd_destroy(pcd_decoder* d)
     }
     if (d->d_in) (void)hipFree(d->d_in);
     if (d->d_i8) (void)hipFree(d->d_i8);
+    if (d->d_f32) (void)hipFree(d->d_f32);
     for (int b = 0; b < pcd_decoder::kRing; ++b) {
         if (d->h_ring[b]) (void)hipHostFree(d->h_ring[b]);
         if (d->d_ring[b]) (void)hipFree(d->d_ring[b]);

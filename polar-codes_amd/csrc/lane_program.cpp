@@ -5,7 +5,7 @@
 
 namespace pamd {
 
-bool lower_lane(unsigned logN, const Program& scl, Program& out)
+bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr)
 {
     out = Program();
     out.leaves = scl.leaves;
@@ -70,7 +70,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out)
             put(LN_SPC, x.stage, x.side, 0);
             break;
         case SCL_REP:
-            if (x.stage > 2 || x.stage < 1) return false;
+            if (x.stage > (chr ? 8u : 2u) || x.stage < 1) return false;  // (int8 decoder: repetition leaves at every size)
             put(LN_REP, x.stage, x.side, 0);
             break;
         default: return false;

@@ -875,6 +875,16 @@ __global__ void f32_to_i8_kernel(const float* in, int8_t* out, size_t n)
     }
 }
 
+// int8 rows for the lane-per-path list kernel of the int8 decoder, which reads fp32 rows like its float twin
+__global__ void i8_to_f32_kernel(const int8_t* in, float* out, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t w = reinterpret_cast<const uint32_t*>(in)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4((float)(int8_t)(w & 0xFFu), (float)(int8_t)((w >> 8) & 0xFFu), (float)(int8_t)((w >> 16) & 0xFFu),
+                                                        (float)(int8_t)(w >> 24));
+    }
+}
+
 // =============================================================================================
 //  launchers
 // =============================================================================================
@@ -982,6 +992,14 @@ hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t 
     if (n == 0) return hipSuccess;
     const size_t blocks = std::min<size_t>((n + 255) / 256, (size_t)1 << 20);  // (grid-stride loop: any n)
     hipLaunchKernelGGL(f32_to_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_i8_to_f32(const int8_t* in, float* out, size_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;  // (n: a multiple of 4 -- rows of at least 8 positions)
+    const size_t n4 = n / 4, blocks = std::min<size_t>((n4 + 255) / 256, (size_t)1 << 20);
+    hipLaunchKernelGGL(i8_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n4);
     return hipGetLastError();
 }
 

@@ -224,6 +224,30 @@ __device__ __forceinline__ void g_reg(uint32_t addr, uint32_t signmask)
     });
 }
 
+// ---- int8 list decoder (SclFipChar scl_fip_char.cpp, primitives fip_char.h:45-74): an int8 LLR is the float of the same value, ----
+// saturation is a clamp: f = the float f with its magnitude clamped to [1, 127] (sign kept, also of a -0), g / a + b clamped
+// to [-128, 127].  c127 travels as a scalar operand, -128 in a VGPR (a VALU instruction of gfx9 takes one scalar operand).
+template <int R, int CNT>
+__device__ __forceinline__ void clamp_f(float c127, uint32_t absmask)
+{
+    static_for<CNT>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        uint32_t t;
+        const float cc = c127;
+        const uint32_t am = absmask;
+        asm volatile("v_med3_f32 %[t], |v[%[r]]|, 1.0, %[c]\n\tv_bfi_b32 v[%[r]], %[am], %[t], v[%[r]]" : [t] "=&v"(t) : [r] "n"(R + i), [c] "s"(cc), [am] "s"(am));
+    });
+}
+template <int R, int CNT>
+__device__ __forceinline__ void clamp_g(float c127, float m128)
+{
+    static_for<CNT>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const float cc = c127, mm = m128;
+        asm volatile("v_med3_f32 v[%[r]], v[%[r]], %[m], %[c]" ::[r] "n"(R + i), [c] "s"(cc), [m] "v"(mm));
+    });
+}
+
 // ---- stage 7 (LDS column, 16-byte chunks 1 KB apart) -> stage 6 (registers) ----------------------------------------------
 // Round r loads the chunks 8r .. 8r+7 into v[D .. D+31] and their partners 16+8r .. into v[T .. T+31] (the registers of
 // stage 5, dead while stage 6 is being produced), then works on them in place as they arrive.
@@ -346,6 +370,7 @@ struct Path {
     int lane, q, g0;
     uint32_t self4;  // lane * 4 (ds_bpermute address of the own lane)
     uint32_t* lds;   // this wave's LDS
+    float c127, m128;  // int8 decoder: 127.0 (used as a scalar operand) and -128.0 (kept in a VGPR)
     uint32_t* arena; // this wave's arena slice
     __device__ __forceinline__ uint32_t owner(uint32_t t) const { return (uint32_t)g0 | ((slot >> (3u * (t - 2u))) & 7u); }
     __device__ __forceinline__ void set_field(uint32_t t)
@@ -835,11 +860,56 @@ __device__ __forceinline__ void leaf_rep(Path& p, uint32_t side, const Stamps& s
     put_bits<T>(p, side, w);
 }
 
+// RepetitionDecoder of the int8 decoder (scl_fip_char.cpp:497-547): at EVERY block length, exact sums (int8-valued floats: any order
+// gives the same result) -- candidate 0 = all bits 0 at metric + sum of min(x, 0), candidate 1 = all bits 1 at metric - sum of max(x, 0)
+template <int T>
+__device__ __forceinline__ void leaf_rep_any(Path& p, uint32_t side, const Stamps& sm)
+{
+    constexpr int n = 1 << T;
+    float zs = 0.0f, xs = 0.0f;  // sum of min(x, 0), sum of x (sum of max(x, 0) = xs - zs)
+    if constexpr (T <= 6) {
+        float z4[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, x4[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        static_for<n>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const float x = rdf<RS(T) + i>();
+            z4[i & 3] += min0(x);
+            x4[i & 3] += x;
+        });
+        zs = (z4[0] + z4[1]) + (z4[2] + z4[3]);
+        xs = (x4[0] + x4[1]) + (x4[2] + x4[3]);
+    } else {
+        const ChunkSrc<T> x(p);
+#pragma unroll 2
+        for (uint32_t c = 0; c < (uint32_t)n / 4; ++c) {
+            const float4 a = x.chunk(c);
+            zs += (min0(a.x) + min0(a.y)) + (min0(a.z) + min0(a.w));
+            xs += (a.x + a.y) + (a.z + a.w);
+        }
+    }
+    float cm[2];
+    cm[0] = p.metric + zs;
+    cm[1] = p.metric - (xs - zs);
+    sm.mark(1);
+    uint32_t src, cand;
+    select_fork<2>(p, cm, src, cand, sm);
+    sm.mark(3);
+    uint32_t w[T <= 5 ? 1 : (1 << (T - 5))];
+#pragma unroll
+    for (int i = 0; i < (T <= 5 ? 1 : (1 << (T - 5))); ++i) w[i] = cand ? (n >= 32 ? 0xFFFFFFFFu : ((1u << (n & 31)) - 1u)) : 0u;
+    put_bits<T>(p, side, w);
+}
+
 // RateOneDecoder::decode :353-413 and SpcDecoder::decode :498-621, first half: hard decisions and the weak-LLR scan of
 // the block (what follows -- findWeakLlrs' iterations, candidates, selection, bits -- is shared: fork_tail)
-template <int T>
+// CH (int8 decoder): magnitudes are abs(max(x, -127)) (scl_fip_char.cpp:413-417, 587-590)
+template <int T, bool CH = false>
 __device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
 {
+    auto mag = [](uint32_t b) {
+        const uint32_t a = b & 0x7FFFFFFFu;
+        if constexpr (CH) return a < 0x42FE0000u ? a : 0x42FE0000u;  // 127.0f
+        else return a;
+    };
     constexpr int n = 1 << T;
     ws.init();
     if constexpr (T <= 6) {  // straight from the registers (stages 5 and 6 used to go through a dump in the arena: a store -> load round trip)
@@ -850,8 +920,8 @@ __device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
                 constexpr int i = 32 * wd + decltype(I)::value;
                 const uint32_t b = rdu<RS(T) + i>();
                 s |= (b >> 31) << (i & 31);
-                if constexpr (i < 4) ws.hv[i] = b & 0x7FFFFFFFu;
-                else ws.tail(b & 0x7FFFFFFFu, (uint32_t)i);
+                if constexpr (i < 4) ws.hv[i] = mag(b);
+                else ws.tail(mag(b), (uint32_t)i);
             });
             ws.sg[wd] = s;
         });
@@ -864,7 +934,7 @@ __device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ws.sg[0] |= (e[i] >> 31) << i;
-                ws.hv[i] = e[i] & 0x7FFFFFFFu;
+                ws.hv[i] = mag(e[i]);
             }
         }
         static_for<(n + 31) / 32>([&](auto Wd) {
@@ -878,7 +948,7 @@ __device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     s |= (e[i] >> 31) << (4u * c + (uint32_t)i);
-                    ws.tail(e[i] & 0x7FFFFFFFu, 4u * ch + (uint32_t)i);
+                    ws.tail(mag(e[i]), 4u * ch + (uint32_t)i);
                 }
             }
             ws.sg[wd] = s;
@@ -1053,9 +1123,10 @@ __device__ __forceinline__ void vt_load(const float* rowp)
 }
 // one step on set SET.  wa..wd: the root's left-child bits for the four stage-9 chunks, ue / uf: the stage-9 node's
 // left-child bits for the two stage-8 chunks -- each word shifted so that the chunk's four bits are bits 0 .. 3.
-template <int SET, bool R9, bool ISG, bool F8>
+template <int SET, bool R9, bool ISG, bool F8, bool CH = false>
 __device__ __forceinline__ void vt_step(uint32_t wa, uint32_t wb, uint32_t wc, uint32_t wd, uint32_t ue, uint32_t uf, uint32_t absmask,
-                                        uint32_t signmask, uint32_t s8off, const uint32_t* s8base, uint32_t s7addr)
+                                        uint32_t signmask, uint32_t s8off, const uint32_t* s8base, uint32_t s7addr, float c127 = 0.0f,
+                                        float m128 = 0.0f)
 {
     uint32_t t0, t1, t2, t3;
 #define LN_VG(D_, B_, W_)                                          \
@@ -1085,6 +1156,15 @@ __device__ __forceinline__ void vt_step(uint32_t wa, uint32_t wb, uint32_t wc, u
                      : [r] "n"(SET), [am] "s"(absmask)
                      : "memory");
     }
+    if constexpr (CH) {  // (int8 decoder: the values of stage 9 are clamped like stored ones)
+        if constexpr (R9) {
+            clamp_g<SET, 8>(c127, m128);
+            clamp_g<SET + 16, 8>(c127, m128);
+        } else {
+            clamp_f<SET, 8>(c127, absmask);
+            clamp_f<SET + 16, 8>(c127, absmask);
+        }
+    }
     // stage 8 (in place): x = op(a, b) -> +0, y = op(c, d) -> +16; stage 7: f(x, y) -> +4
     if constexpr (ISG) {
         asm volatile(LN_VG("%[r]", "%[r]+4", "%[ue]") LN_VG("%[r]+16", "%[r]+20", "%[uf]")
@@ -1095,7 +1175,27 @@ __device__ __forceinline__ void vt_step(uint32_t wa, uint32_t wb, uint32_t wc, u
                      : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
                      : [r] "n"(SET), [am] "s"(absmask));
     }
-    if constexpr (F8) {
+    if constexpr (CH) {
+        if constexpr (ISG) {
+            clamp_g<SET, 4>(c127, m128);
+            clamp_g<SET + 16, 4>(c127, m128);
+        } else {
+            clamp_f<SET, 4>(c127, absmask);
+            clamp_f<SET + 16, 4>(c127, absmask);
+        }
+    }
+    if constexpr (F8 && CH) {  // (the f of stage 8 is clamped before it goes to the LDS)
+        asm volatile(LN_F4T("%[r]+4", "%[r]", "%[r]+16")
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [r] "n"(SET), [am] "s"(absmask));
+        clamp_f<SET + 4, 4>(c127, absmask);
+        asm volatile("global_store_dwordx4 %[o], v[%[r]:%[r]+3], %[sb]\n\t"
+                     "global_store_dwordx4 %[o2], v[%[r]+16:%[r]+19], %[sb]\n\t"
+                     "ds_write_b128 %[la], v[%[r]+4:%[r]+7]"
+                     :
+                     : [r] "n"(SET), [o] "v"(s8off), [o2] "v"(s8off + 32768u), [sb] "s"(s8base), [la] "v"(s7addr)
+                     : "memory");
+    } else if constexpr (F8) {
         asm volatile(LN_F4T("%[r]+4", "%[r]", "%[r]+16")
                      "global_store_dwordx4 %[o], v[%[r]:%[r]+3], %[sb]\n\t"
                      "global_store_dwordx4 %[o2], v[%[r]+16:%[r]+19], %[sb]\n\t"
@@ -1138,7 +1238,7 @@ __device__ __forceinline__ void vt_words(const uint32_t* bl9, const uint32_t* bl
                      : "memory");
     }
 }
-template <bool R9, bool ISG, bool F8>
+template <bool R9, bool ISG, bool F8, bool CH>
 __device__ __forceinline__ void op_vt_t(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
 {
     if (R9 && !ISG) p.set_field(10);  // the G of the root directly follows its left child: the bits are this lane's own
@@ -1166,16 +1266,16 @@ __device__ __forceinline__ void op_vt_t(Path& p, const float* chan, uint32_t abs
 #pragma unroll 1
         for (uint32_t ji = 0; ji < 8; ji += 4) {
             vt_load<VT_SET3>(rowp < rowend ? rowp : rowend);
-            vt_step<VT_SET0, R9, ISG, F8>(wa, wb, wc, wd, ue, uf, absmask, signmask, s8off, s8base, s7addr);
+            vt_step<VT_SET0, R9, ISG, F8, CH>(wa, wb, wc, wd, ue, uf, absmask, signmask, s8off, s8base, s7addr, p.c127, p.m128);
             vt_load<VT_SET0>(rowp + 4 < rowend ? rowp + 4 : rowend);
-            vt_step<VT_SET1, R9, ISG, F8>(wa >> 4, wb >> 4, wc >> 4, wd >> 4, ue >> 4, uf >> 4, absmask, signmask, s8off + 1024u, s8base,
-                                          s7addr + 1024u);
+            vt_step<VT_SET1, R9, ISG, F8, CH>(wa >> 4, wb >> 4, wc >> 4, wd >> 4, ue >> 4, uf >> 4, absmask, signmask, s8off + 1024u, s8base,
+                                          s7addr + 1024u, p.c127, p.m128);
             vt_load<VT_SET1>(rowp + 8 < rowend ? rowp + 8 : rowend);
-            vt_step<VT_SET2, R9, ISG, F8>(wa >> 8, wb >> 8, wc >> 8, wd >> 8, ue >> 8, uf >> 8, absmask, signmask, s8off + 2048u, s8base,
-                                          s7addr + 2048u);
+            vt_step<VT_SET2, R9, ISG, F8, CH>(wa >> 8, wb >> 8, wc >> 8, wd >> 8, ue >> 8, uf >> 8, absmask, signmask, s8off + 2048u, s8base,
+                                          s7addr + 2048u, p.c127, p.m128);
             vt_load<VT_SET2>(rowp + 12 < rowend ? rowp + 12 : rowend);
-            vt_step<VT_SET3, R9, ISG, F8>(wa >> 12, wb >> 12, wc >> 12, wd >> 12, ue >> 12, uf >> 12, absmask, signmask, s8off + 3072u,
-                                          s8base, s7addr + 3072u);
+            vt_step<VT_SET3, R9, ISG, F8, CH>(wa >> 12, wb >> 12, wc >> 12, wd >> 12, ue >> 12, uf >> 12, absmask, signmask, s8off + 3072u,
+                                          s8base, s7addr + 3072u, p.c127, p.m128);
             wa >>= 16; wb >>= 16; wc >>= 16; wd >>= 16; ue >>= 16; uf >>= 16;
             rowp += 16;
             s8off += 4096u;
@@ -1192,6 +1292,7 @@ __device__ __forceinline__ void op_vt_t(Path& p, const float* chan, uint32_t abs
 // The first pass of a codeword (F of the root, F of its left child): one live path, whose lane would do 32 steps while
 // the other seven of the codeword idle.  The steps do not depend on the path, so lane q does the steps j = q, q + 8,
 // q + 16, q + 24 and stores into the column of the codeword's first lane, where the path lives.
+template <bool CH>
 __device__ __forceinline__ void op_vt_first(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
 {
     const uint32_t* s8base = p.arena + AR_S8;
@@ -1206,26 +1307,27 @@ __device__ __forceinline__ void op_vt_first(Path& p, const float* chan, uint32_t
     // (vt_step's counted wait assumes the next set's loads are issued in front of every step; here nothing follows the
     //  four sets, so everything is waited for first)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    vt_step<VT_SET0, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off, s8base, s7addr);
-    vt_step<VT_SET1, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 8192u, s8base, s7addr + 8192u);
-    vt_step<VT_SET2, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 16384u, s8base, s7addr + 16384u);
-    vt_step<VT_SET3, false, false, true>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 24576u, s8base, s7addr + 24576u);
+    vt_step<VT_SET0, false, false, true, CH>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off, s8base, s7addr, p.c127, p.m128);
+    vt_step<VT_SET1, false, false, true, CH>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 8192u, s8base, s7addr + 8192u, p.c127, p.m128);
+    vt_step<VT_SET2, false, false, true, CH>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 16384u, s8base, s7addr + 16384u, p.c127, p.m128);
+    vt_step<VT_SET3, false, false, true, CH>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 24576u, s8base, s7addr + 24576u, p.c127, p.m128);
     p.set_field(8);
     p.set_field(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+template <bool CH>
 __device__ __forceinline__ void op_vt(Path& p, uint32_t off, const float* chan, uint32_t absmask, uint32_t signmask)
 {
     // (bit 2 of off -- "the F of stage 8 follows" -- needs no variant of its own: stage 7 is dead whenever it is clear, so the
     //  F is computed and stored regardless)
     switch (off & 3u) {
     case 0:
-        if (p.P == 1u) op_vt_first(p, chan, absmask, signmask);  // (always: the program starts with this op)
-        else op_vt_t<false, false, true>(p, chan, absmask, signmask);
+        if (p.P == 1u) op_vt_first<CH>(p, chan, absmask, signmask);  // (always: the program starts with this op)
+        else op_vt_t<false, false, true, CH>(p, chan, absmask, signmask);
         break;
-    case 1: op_vt_t<true, false, true>(p, chan, absmask, signmask); break;
-    case 2: op_vt_t<false, true, true>(p, chan, absmask, signmask); break;
-    default: op_vt_t<true, true, true>(p, chan, absmask, signmask); break;
+    case 1: op_vt_t<true, false, true, CH>(p, chan, absmask, signmask); break;
+    case 2: op_vt_t<false, true, true, CH>(p, chan, absmask, signmask); break;
+    default: op_vt_t<true, true, true, CH>(p, chan, absmask, signmask); break;
     }
 }
 
@@ -1236,12 +1338,47 @@ __device__ __forceinline__ void op_vt(Path& p, uint32_t off, const float* chan, 
                   "global_load_dwordx4 v[%[t]+4*" #c ":%[t]+4*" #c "+3], %[ob], %[sb]\n\t" \
                   "v_add_u32 %[oa], 0x400, %[oa]\n\t" "v_add_u32 %[ob], 0x400, %[ob]\n\t"
 #define LN_ST(c) "s_nop 0\n\tds_write_b128 %[la], v[%[d]+4*" #c ":%[d]+4*" #c "+3] offset:1024*" #c "\n\t"
-template <bool ISF>
+// clamps of the int8 decoder on four results in place (see clamp_f / clamp_g)
+#define LN_CF4(D_)                                                                                                   \
+    "v_med3_f32 %[t0], |v[" D_ "]|, 1.0, %[c]\n\t"   "v_med3_f32 %[t1], |v[" D_ "+1]|, 1.0, %[c]\n\t"                  \
+    "v_med3_f32 %[t2], |v[" D_ "+2]|, 1.0, %[c]\n\t" "v_med3_f32 %[t3], |v[" D_ "+3]|, 1.0, %[c]\n\t"                  \
+    "v_bfi_b32 v[" D_ "], %[am], %[t0], v[" D_ "]\n\t"     "v_bfi_b32 v[" D_ "+1], %[am], %[t1], v[" D_ "+1]\n\t"       \
+    "v_bfi_b32 v[" D_ "+2], %[am], %[t2], v[" D_ "+2]\n\t" "v_bfi_b32 v[" D_ "+3], %[am], %[t3], v[" D_ "+3]\n\t"
+#define LN_CG4(D_)                                                                                                   \
+    "v_med3_f32 v[" D_ "], v[" D_ "], %[m], %[c]\n\t"     "v_med3_f32 v[" D_ "+1], v[" D_ "+1], %[m], %[c]\n\t"          \
+    "v_med3_f32 v[" D_ "+2], v[" D_ "+2], %[m], %[c]\n\t" "v_med3_f32 v[" D_ "+3], v[" D_ "+3], %[m], %[c]\n\t"
+template <bool ISF, bool CH = false>
 __device__ __forceinline__ void fg8_batch(uint32_t& oa, uint32_t& ob, const uint32_t* s8base, uint32_t la, uint32_t w, uint32_t absmask,
-                                          uint32_t signmask)
+                                          uint32_t signmask, float c127 = 0.0f, float m128 = 0.0f)
 {
     uint32_t t0, t1, t2, t3;
-    if constexpr (ISF) {
+    if constexpr (ISF && CH) {
+        asm volatile(LN_LD2(0) LN_LD2(1) LN_LD2(2) LN_LD2(3) LN_LD2(4) LN_LD2(5) LN_LD2(6) LN_LD2(7)
+                     "s_waitcnt vmcnt(14)\n\t" LN_F4T("%[d]", "%[d]", "%[t]") LN_CF4("%[d]") LN_ST(0)
+                     "s_waitcnt vmcnt(12)\n\t" LN_F4T("%[d]+4", "%[d]+4", "%[t]+4") LN_CF4("%[d]+4") LN_ST(1)
+                     "s_waitcnt vmcnt(10)\n\t" LN_F4T("%[d]+8", "%[d]+8", "%[t]+8") LN_CF4("%[d]+8") LN_ST(2)
+                     "s_waitcnt vmcnt(8)\n\t" LN_F4T("%[d]+12", "%[d]+12", "%[t]+12") LN_CF4("%[d]+12") LN_ST(3)
+                     "s_waitcnt vmcnt(6)\n\t" LN_F4T("%[d]+16", "%[d]+16", "%[t]+16") LN_CF4("%[d]+16") LN_ST(4)
+                     "s_waitcnt vmcnt(4)\n\t" LN_F4T("%[d]+20", "%[d]+20", "%[t]+20") LN_CF4("%[d]+20") LN_ST(5)
+                     "s_waitcnt vmcnt(2)\n\t" LN_F4T("%[d]+24", "%[d]+24", "%[t]+24") LN_CF4("%[d]+24") LN_ST(6)
+                     "s_waitcnt vmcnt(0)\n\t" LN_F4T("%[d]+28", "%[d]+28", "%[t]+28") LN_CF4("%[d]+28") LN_ST(7)
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [oa] "+v"(oa), [ob] "+v"(ob)
+                     : [d] "n"(128), [t] "n"(160), [sb] "s"(s8base), [la] "v"(la), [am] "s"(absmask), [c] "s"(c127)
+                     : "memory");
+    } else if constexpr (CH) {
+        asm volatile(LN_LD2(0) LN_LD2(1) LN_LD2(2) LN_LD2(3) LN_LD2(4) LN_LD2(5) LN_LD2(6) LN_LD2(7)
+                     "s_waitcnt vmcnt(14)\n\t" LN_G4T("%[d]", "%[t]", 31, 30, 29, 28) LN_CG4("%[d]") LN_ST(0)
+                     "s_waitcnt vmcnt(12)\n\t" LN_G4T("%[d]+4", "%[t]+4", 27, 26, 25, 24) LN_CG4("%[d]+4") LN_ST(1)
+                     "s_waitcnt vmcnt(10)\n\t" LN_G4T("%[d]+8", "%[t]+8", 23, 22, 21, 20) LN_CG4("%[d]+8") LN_ST(2)
+                     "s_waitcnt vmcnt(8)\n\t" LN_G4T("%[d]+12", "%[t]+12", 19, 18, 17, 16) LN_CG4("%[d]+12") LN_ST(3)
+                     "s_waitcnt vmcnt(6)\n\t" LN_G4T("%[d]+16", "%[t]+16", 15, 14, 13, 12) LN_CG4("%[d]+16") LN_ST(4)
+                     "s_waitcnt vmcnt(4)\n\t" LN_G4T("%[d]+20", "%[t]+20", 11, 10, 9, 8) LN_CG4("%[d]+20") LN_ST(5)
+                     "s_waitcnt vmcnt(2)\n\t" LN_G4T("%[d]+24", "%[t]+24", 7, 6, 5, 4) LN_CG4("%[d]+24") LN_ST(6)
+                     "s_waitcnt vmcnt(0)\n\t" LN_G4T("%[d]+28", "%[t]+28", 3, 2, 1, 0) LN_CG4("%[d]+28") LN_ST(7)
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [oa] "+v"(oa), [ob] "+v"(ob)
+                     : [d] "n"(128), [t] "n"(160), [sb] "s"(s8base), [la] "v"(la), [w] "v"(w), [sm] "s"(signmask), [c] "s"(c127), [m] "v"(m128)
+                     : "memory");
+    } else if constexpr (ISF) {
         asm volatile(LN_LD2(0) LN_LD2(1) LN_LD2(2) LN_LD2(3) LN_LD2(4) LN_LD2(5) LN_LD2(6) LN_LD2(7)
                      "s_waitcnt vmcnt(14)\n\t" LN_F4T("%[d]", "%[d]", "%[t]") LN_ST(0)
                      "s_waitcnt vmcnt(12)\n\t" LN_F4T("%[d]+4", "%[d]+4", "%[t]+4") LN_ST(1)
@@ -1271,6 +1408,9 @@ __device__ __forceinline__ void fg8_batch(uint32_t& oa, uint32_t& ob, const uint
 }
 #undef LN_LD2
 #undef LN_ST
+#undef LN_CF4
+#undef LN_CG4
+template <bool CH>
 __device__ __forceinline__ void op_fg8(Path& p, uint32_t kind, uint32_t absmask, uint32_t signmask)
 {
     const uint32_t col = kind == 1u ? p.owner(8) : (uint32_t)p.lane;
@@ -1282,15 +1422,15 @@ __device__ __forceinline__ void op_fg8(Path& p, uint32_t kind, uint32_t absmask,
 #pragma unroll 1
     for (uint32_t b = 0; b < 4; ++b) {
         const uint32_t w = kind != 1u ? 0u : (b == 0 ? w0 : (b == 1 ? w1 : (b == 2 ? w2 : w3)));
-        if (kind == 0u) fg8_batch<true>(oa, ob, s8base, la + b * 8192u, w, absmask, signmask);
-        else fg8_batch<false>(oa, ob, s8base, la + b * 8192u, w, absmask, signmask);
+        if (kind == 0u) fg8_batch<true, CH>(oa, ob, s8base, la + b * 8192u, w, absmask, signmask, p.c127, p.m128);
+        else fg8_batch<false, CH>(oa, ob, s8base, la + b * 8192u, w, absmask, signmask, p.c127, p.m128);
     }
     if (kind != 0u) p.set_field(8);
     p.set_field(7);
 }
 
 // stage 7 (LDS column) -> stage 6 (registers)
-template <int KIND>
+template <int KIND, bool CH>
 __device__ __forceinline__ void op_fg7(Path& p, uint32_t absmask, uint32_t signmask)
 {
     const uint32_t col = KIND == 1 ? p.owner(7) : (uint32_t)p.lane;
@@ -1306,11 +1446,15 @@ __device__ __forceinline__ void op_fg7(Path& p, uint32_t absmask, uint32_t signm
         g7_round<0, false>(addr, 0, signmask);
         g7_round<1, false>(addr, 0, signmask);
     }
+    if constexpr (CH) {
+        if constexpr (KIND == 0) clamp_f<RS(6), 64>(p.c127, absmask);
+        else clamp_g<RS(6), 64>(p.c127, p.m128);
+    }
     if (KIND != 0) p.set_field(7);
     p.set_field(6);
 }
 
-template <int KIND, int T>
+template <int KIND, int T, bool CH>
 __device__ __forceinline__ void op_fg_reg(Path& p, uint32_t absmask, uint32_t signmask, bool twice = false)
 {
     if constexpr (KIND == 0) f_reg<T>(absmask);
@@ -1319,6 +1463,10 @@ __device__ __forceinline__ void op_fg_reg(Path& p, uint32_t absmask, uint32_t si
         if (twice) g_reg<T>(p.owner(T) << 2, signmask);  // (diagnostics: the op is idempotent until its slot field is set)
     }
     else g0_reg<T>();
+    if constexpr (CH) {
+        if constexpr (KIND == 0) clamp_f<RS(T - 1), (1 << (T - 1))>(p.c127, absmask);
+        else clamp_g<RS(T - 1), (1 << (T - 1))>(p.c127, p.m128);
+    }
     if (KIND != 0) p.set_field(T);
     p.set_field(T - 1);
 }
@@ -1328,7 +1476,8 @@ __device__ __forceinline__ void op_fg_reg(Path& p, uint32_t absmask, uint32_t si
 // =====================================================================================================================
 //  kernel
 // =====================================================================================================================
-template <bool DIAG>
+// CH: the int8 list decoder SclFipChar (rows arrive as fp32 all the same: the host converts int8 rows first)
+template <bool DIAG, bool CH = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(lane::KV)))
 void scl_lane_kernel(const DecodeParams P)
 {
@@ -1351,6 +1500,9 @@ void scl_lane_kernel(const DecodeParams P)
     p.lds = lds;
     p.arena = reinterpret_cast<uint32_t*>(P.arena) + (size_t)blockIdx.x * AR_WORDS;
     p.L = P.L;
+    p.c127 = 127.0f;
+    p.m128 = -128.0f;
+    asm volatile("" : "+v"(p.m128));  // (kept in a VGPR: the clamp's scalar operand is the 127)
 
     for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const uint32_t ci = grp * 8u + ((uint32_t)lane >> 3);
@@ -1384,8 +1536,8 @@ void scl_lane_kernel(const DecodeParams P)
           for (uint32_t again = 0; again < ((DIAG && (P.ablate & 32768u)) ? 2u : 1u); ++again, opx = 0xFFu)  // (PCD_ABLATE=32768: every dispatch twice, the second one of nothing)
             switch (opx) {
             case LN_VT:
-                if (!(DIAG && (P.ablate & 1u))) op_vt(p, off, chan, absmask, signmask);
-                if (DIAG && (P.ablate & 1024u)) op_vt(p, off, chan, absmask, signmask);  // (idempotent: costed by doing it twice)
+                if (!(DIAG && (P.ablate & 1u))) op_vt<CH>(p, off, chan, absmask, signmask);
+                if (DIAG && (P.ablate & 1024u)) op_vt<CH>(p, off, chan, absmask, signmask);  // (idempotent: costed by doing it twice)
                 break;
             case LN_WALK: {
                 if (DIAG && (P.ablate & 2u)) break;
@@ -1418,20 +1570,20 @@ void scl_lane_kernel(const DecodeParams P)
                 // (ONE flat switch per step: nested if / switch ladders make the compiler thread flag registers through a structured
                 //  control flow graph -- dozens of scalar instructions per step; found on the SC pair kernel, where it was worth 16 %)
                 switch ((gk << 4) | gs) {
-                case 0x18: op_fg8(p, 1, absmask, signmask); break;
-                case 0x17: op_fg7<1>(p, absmask, signmask); break;
-                case 0x16: op_fg_reg<1, 6>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
-                case 0x15: op_fg_reg<1, 5>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
-                case 0x14: op_fg_reg<1, 4>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
-                case 0x13: op_fg_reg<1, 3>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
-                case 0x12: op_fg_reg<1, 2>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
-                case 0x28: op_fg8(p, 2, absmask, signmask); break;
-                case 0x27: op_fg7<2>(p, absmask, signmask); break;
-                case 0x26: op_fg_reg<2, 6>(p, absmask, signmask); break;
-                case 0x25: op_fg_reg<2, 5>(p, absmask, signmask); break;
-                case 0x24: op_fg_reg<2, 4>(p, absmask, signmask); break;
-                case 0x23: op_fg_reg<2, 3>(p, absmask, signmask); break;
-                case 0x22: op_fg_reg<2, 2>(p, absmask, signmask); break;
+                case 0x18: op_fg8<CH>(p, 1, absmask, signmask); break;
+                case 0x17: op_fg7<1, CH>(p, absmask, signmask); break;
+                case 0x16: op_fg_reg<1, 6, CH>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                case 0x15: op_fg_reg<1, 5, CH>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                case 0x14: op_fg_reg<1, 4, CH>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                case 0x13: op_fg_reg<1, 3, CH>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                case 0x12: op_fg_reg<1, 2, CH>(p, absmask, signmask, DIAG && (P.ablate & 8192u)); break;
+                case 0x28: op_fg8<CH>(p, 2, absmask, signmask); break;
+                case 0x27: op_fg7<2, CH>(p, absmask, signmask); break;
+                case 0x26: op_fg_reg<2, 6, CH>(p, absmask, signmask); break;
+                case 0x25: op_fg_reg<2, 5, CH>(p, absmask, signmask); break;
+                case 0x24: op_fg_reg<2, 4, CH>(p, absmask, signmask); break;
+                case 0x23: op_fg_reg<2, 3, CH>(p, absmask, signmask); break;
+                case 0x22: op_fg_reg<2, 2, CH>(p, absmask, signmask); break;
                 default: break;
                 }
                 sm.mark(2);
@@ -1441,13 +1593,13 @@ void scl_lane_kernel(const DecodeParams P)
 #pragma unroll 1
                     for (uint32_t t = f1; t >= f0; --t) {
                         switch (t) {
-                        case 8: op_fg8(p, 0, absmask, signmask); break;
-                        case 7: op_fg7<0>(p, absmask, signmask); break;
-                        case 6: op_fg_reg<0, 6>(p, absmask, signmask); break;
-                        case 5: op_fg_reg<0, 5>(p, absmask, signmask); break;
-                        case 4: op_fg_reg<0, 4>(p, absmask, signmask); break;
-                        case 3: op_fg_reg<0, 3>(p, absmask, signmask); break;
-                        default: op_fg_reg<0, 2>(p, absmask, signmask); break;
+                        case 8: op_fg8<CH>(p, 0, absmask, signmask); break;
+                        case 7: op_fg7<0, CH>(p, absmask, signmask); break;
+                        case 6: op_fg_reg<0, 6, CH>(p, absmask, signmask); break;
+                        case 5: op_fg_reg<0, 5, CH>(p, absmask, signmask); break;
+                        case 4: op_fg_reg<0, 4, CH>(p, absmask, signmask); break;
+                        case 3: op_fg_reg<0, 3, CH>(p, absmask, signmask); break;
+                        default: op_fg_reg<0, 2, CH>(p, absmask, signmask); break;
                         }
                     }
                 }
@@ -1483,15 +1635,27 @@ void scl_lane_kernel(const DecodeParams P)
                     case 0x13: leaf_r0<3>(p, lside); break;
                     case 0x12: leaf_r0<2>(p, lside); break;
                     case 0x11: leaf_r0<1>(p, lside); break;
-                    case 0x22: leaf_rep<2>(p, lside, sm); break;
-                    case 0x21: leaf_rep<1>(p, lside, sm); break;
-                    case 0x37: leaf_scan<7>(p, ws); break;
-                    case 0x36: leaf_scan<6>(p, ws); break;
-                    case 0x35: leaf_scan<5>(p, ws); break;
-                    case 0x34: leaf_scan<4>(p, ws); break;
-                    case 0x33: leaf_scan<3>(p, ws); break;
-                    case 0x32: leaf_scan<2>(p, ws); break;
-                    case 0x31: leaf_scan<1>(p, ws); break;
+                    case 0x28: if constexpr (CH) leaf_rep_any<8>(p, lside, sm); break;  // (int8 decoder: repetition leaves at every size)
+                    case 0x27: if constexpr (CH) leaf_rep_any<7>(p, lside, sm); break;
+                    case 0x26: if constexpr (CH) leaf_rep_any<6>(p, lside, sm); break;
+                    case 0x25: if constexpr (CH) leaf_rep_any<5>(p, lside, sm); break;
+                    case 0x24: if constexpr (CH) leaf_rep_any<4>(p, lside, sm); break;
+                    case 0x23: if constexpr (CH) leaf_rep_any<3>(p, lside, sm); break;
+                    case 0x22:
+                        if constexpr (CH) leaf_rep_any<2>(p, lside, sm);
+                        else leaf_rep<2>(p, lside, sm);
+                        break;
+                    case 0x21:
+                        if constexpr (CH) leaf_rep_any<1>(p, lside, sm);
+                        else leaf_rep<1>(p, lside, sm);
+                        break;
+                    case 0x37: leaf_scan<7, CH>(p, ws); break;
+                    case 0x36: leaf_scan<6, CH>(p, ws); break;
+                    case 0x35: leaf_scan<5, CH>(p, ws); break;
+                    case 0x34: leaf_scan<4, CH>(p, ws); break;
+                    case 0x33: leaf_scan<3, CH>(p, ws); break;
+                    case 0x32: leaf_scan<2, CH>(p, ws); break;
+                    case 0x31: leaf_scan<1, CH>(p, ws); break;
                     default: break;
                     }
             }
@@ -1610,17 +1774,29 @@ void scl_lane_kernel(const DecodeParams P)
     }
 }
 
+// (explicit instantiation first: the float kernel of the headline configuration opens the code object, see sc_pair_kernel.hip)
+template __global__ void scl_lane_kernel<false, false>(const DecodeParams);
+
 hipError_t launch_scl_lane(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
 {
 #ifdef PAMD_DIAG
     if (diag) {
-        hipLaunchKernelGGL(scl_lane_kernel<true>, dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+        if (P.chr) hipLaunchKernelGGL((scl_lane_kernel<true, true>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+        else hipLaunchKernelGGL((scl_lane_kernel<true, false>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
         return hipGetLastError();
     }
 #else
     if (diag) return hipErrorInvalidValue;
 #endif
-    hipLaunchKernelGGL(scl_lane_kernel<false>, dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+#ifdef PAMD_DIAG
+    if (P.chr) {  // (the int8 decoder on this kernel: an experiment of the diagnostic build, see capi.cpp)
+        hipLaunchKernelGGL((scl_lane_kernel<false, true>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+        return hipGetLastError();
+    }
+#else
+    if (P.chr) return hipErrorInvalidValue;
+#endif
+    hipLaunchKernelGGL((scl_lane_kernel<false, false>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
     return hipGetLastError();
 }
 unsigned scl_lane_arena_words() { return lane::AR_WORDS; }
