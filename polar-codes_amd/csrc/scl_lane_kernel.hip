@@ -26,6 +26,7 @@
 // selection falls back to a literal emulation whenever two keys that matter agree in their upper 26 bits).
 #define PAMD_POLAR_F_MINF 1  // (device_common.h: the 3-instruction f)
 #include "device_common.h"
+#include "lane_runs.inc"
 
 #include <utility>
 
@@ -803,16 +804,19 @@ __device__ __forceinline__ void leaf_r0(Path& p, uint32_t side)
 {
     constexpr int n = 1 << T;
     float sum;
-    if constexpr (T <= 3) {
-        sum = min0_reg<RS(T)>();
-        static_for<n - 1>([&](auto I) { sum = sum + min0_reg<RS(T) + 1 + decltype(I)::value>(); });
+    if constexpr (T <= 3) {  // (one asm statement: chained single-instruction statements cost an s_nop each)
+        float t0, t1;
+        if constexpr (T == 3) asm volatile(LN_RUN_MIN0SUM_8 : [s] "=&v"(sum), [t0] "=&v"(t0), [t1] "=&v"(t1) : [r] "n"(RS(T)));
+        else if constexpr (T == 2) asm volatile(LN_RUN_MIN0SUM_4 : [s] "=&v"(sum), [t0] "=&v"(t0), [t1] "=&v"(t1) : [r] "n"(RS(T)));
+        else asm volatile(LN_RUN_MIN0SUM_2 : [s] "=&v"(sum), [t0] "=&v"(t0), [t1] "=&v"(t1) : [r] "n"(RS(T)));
     } else if constexpr (T <= 6) {
-        float acc[8];
-        static_for<8>([&](auto J) { acc[decltype(J)::value] = min0_reg<RS(T) + decltype(J)::value>(); });
-        static_for<n - 8>([&](auto I) {
-            constexpr int i = 8 + decltype(I)::value;
-            acc[i & 7] = acc[i & 7] + min0_reg<RS(T) + i>();
-        });
+        float acc[8], t0, t1, t2, t3;
+#define LN_ACC_OPS [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2]), [a3] "=&v"(acc[3]), [a4] "=&v"(acc[4]), [a5] "=&v"(acc[5]), \
+                   [a6] "=&v"(acc[6]), [a7] "=&v"(acc[7]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        if constexpr (T == 6) asm volatile(LN_RUN_MIN0ACC_64 : LN_ACC_OPS : [r] "n"(RS(T)));
+        else if constexpr (T == 5) asm volatile(LN_RUN_MIN0ACC_32 : LN_ACC_OPS : [r] "n"(RS(T)));
+        else asm volatile(LN_RUN_MIN0ACC_16 : LN_ACC_OPS : [r] "n"(RS(T)));
+#undef LN_ACC_OPS
         sum = ((((((acc[0] + acc[1]) + acc[2]) + acc[3]) + acc[4]) + acc[5]) + acc[6]) + acc[7];
     } else {
         const ChunkSrc<T> x(p);
