@@ -74,7 +74,7 @@ struct pcd_decoder {
     bool has_sc = false, has_scl = false;
     // lane-per-path list kernel (scl_lane_kernel.hip): N = 1024, 4 < L <= 8, float arithmetic, fp32 rows
     pamd::Program lane_prog;
-    bool has_lane = false;
+    bool has_lane = false, lane_big = false;  // lane_big: a forking leaf of 256 LLRs (the BIG instantiation of the lane kernel)
     pamd::Ins* d_lane_prog = nullptr;
     pamd::Program pair_prog;          // two-lanes-per-codeword SC kernel (sc_pair_kernel.hip)
     bool has_pair = false, pair_big = false;  // pair_big: the tree has a leaf above 128 positions (the BIG instantiations)
@@ -806,7 +806,9 @@ int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
     int rc = grow(d->d_arena, d->d_arena_cap, (size_t)grid * pamd::scl_lane_arena_words() * sizeof(uint32_t));
     if (rc) return rc;
     P.arena = d->d_arena;
-    HIP_TRY(pamd::launch_scl_lane(P, P.trace != nullptr || P.cycles != nullptr || P.ablate != 0, grid, st));
+    const bool diag_k = P.trace != nullptr || P.cycles != nullptr || P.ablate != 0;
+    if (d->lane_big) HIP_TRY(pamd::launch_scl_lane_big(P, diag_k, grid, st));
+    else HIP_TRY(pamd::launch_scl_lane(P, diag_k, grid, st));
     return PCD_OK;
 }
 
@@ -1179,7 +1181,12 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         //  on cfg3_i8.  Integer metrics tie all the time and every tie sends the selection through the literal emulation of the
         //  reference's sort.  Diagnostic build only, behind PCD_FORCE_LANE.)
         if ((!chr || PAMD_ENV("PCD_FORCE_LANE")) && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) {
-            if (d->scl_prog.leaves >= 48u || PAMD_ENV("PCD_FORCE_LANE")) d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr);
+            // (... or from 30 FORKING leaves on: the high-rate trees have few leaves, but large RateOne / SPC ones -- K = 900: 46 leaves, 35 of
+            //  them forking, 35.1 against 24.9 M cw/s)
+            unsigned forks = 0;
+            for (const auto& in : d->scl_prog.ins) forks += (in.op == pamd::SCL_R1 || in.op == pamd::SCL_SPC || in.op == pamd::SCL_REP) ? 1u : 0u;
+            if (d->scl_prog.leaves >= 48u || forks >= 30u || PAMD_ENV("PCD_FORCE_LANE"))
+                d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr, &d->lane_big);
         }
     }
     compute_geometry(d);

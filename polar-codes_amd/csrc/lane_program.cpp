@@ -5,11 +5,12 @@
 
 namespace pamd {
 
-bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr)
+bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool* needs_big)
 {
     out = Program();
     out.leaves = scl.leaves;
     out.inner = scl.inner;
+    if (needs_big) *needs_big = false;
     if (logN != 10) return false;
     const std::vector<Ins>& v = scl.ins;
     auto put = [&](Op op, unsigned stage, unsigned side, unsigned off) {
@@ -62,11 +63,13 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr)
             put(LN_R0, x.stage, x.side, 0);
             break;
         case SCL_R1:
-            if (x.stage > 7 || x.stage < 1) return false;
+            if (x.stage > 8 || x.stage < 1) return false;
+            if (x.stage == 8 && needs_big) *needs_big = true;  // (a forking leaf of 256 LLRs: the BIG instantiation of the kernel)
             put(LN_R1, x.stage, x.side, 0);
             break;
         case SCL_SPC:
-            if (x.stage > 7 || x.stage < 2) return false;
+            if (x.stage > 8 || x.stage < 2) return false;
+            if (x.stage == 8 && needs_big) *needs_big = true;
             put(LN_SPC, x.stage, x.side, 0);
             break;
         case SCL_REP:

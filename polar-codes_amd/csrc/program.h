@@ -141,7 +141,7 @@ std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program
 // Lowers a plain SCL program (compile_scl output: SCL_F / SCL_G / SCL_COMBINE + leaves) of a code with N = 1024 to the
 // program of the lane-per-path kernel.  Returns false when the tree needs an op that kernel does not have (a leaf above
 // stage 8, ...): the caller then keeps the path-group kernels.
-bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr = false);
+bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr = false, bool* needs_big = nullptr);
 // Lowers a plain SC program (compile_sc output; chr: of the int8 decoder) of a code with N = 1024 to the program of the
 // two-lanes-per-codeword kernel.  Returns false when the tree needs an op that kernel does not have (a double-SPC leaf above 128
 // positions, ...): the caller then keeps sc_decode_kernel.  *needs_big: the tree has a leaf above 128 positions (the BIG

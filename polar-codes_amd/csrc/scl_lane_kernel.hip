@@ -24,6 +24,16 @@
 // metric sums follow the reference's 8-accumulator order (avxconvenience.h:256-272); findWeakLlrs and
 // simplePartialSortDescending (arrayfuncs.h:161-231) are reproduced including their swap-order tie behaviour (the merge
 // selection falls back to a literal emulation whenever two keys that matter agree in their upper 26 bits).
+// LN_BIG (scl_lane_big.hip includes this file with it set): the same kernel with the RateOne / SPC leaves of 256 LLRs (high rates),
+// under another name.  A property of the code -- the host picks the kernel per decoder.  As a SECOND translation unit on purpose:
+// with those leaves in the one kernel cfg 3 lost 3.8 %, as a template flag of the one source still 2 % (the lean kernel came out
+// with another register allocation); guarded by the preprocessor the lean kernel's token stream is what it was.
+#ifndef LN_BIG
+#define LN_BIG 0
+#endif
+#if LN_BIG
+#define scl_lane_kernel scl_lane_big_kernel
+#endif
 #define PAMD_POLAR_F_MINF 1  // (device_common.h: the 3-instruction f)
 #include "device_common.h"
 #include "lane_runs.inc"
@@ -943,7 +953,11 @@ __device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
         }
         static_for<(n + 31) / 32>([&](auto Wd) {
             constexpr int wd = decltype(Wd)::value;
+#if LN_BIG
+            uint32_t s = wd < 4 ? ws.sg[wd < 4 ? wd : 0] : 0u;  // (a block of 256 LLRs: the sign words 4 .. 7 go to the LDS)
+#else
             uint32_t s = ws.sg[wd];
+#endif
 #pragma unroll 1
             for (uint32_t c = (wd == 0 ? 1u : 0u); c < 8; ++c) {
                 const uint32_t ch = (uint32_t)wd * 8u + c;
@@ -955,7 +969,12 @@ __device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
                     ws.tail(mag(e[i]), 4u * ch + (uint32_t)i);
                 }
             }
+#if LN_BIG
+            if constexpr (wd < 4) ws.sg[wd] = s;
+            else p.lds[SCR_SEL + 128 + p.lane * 4 + (wd - 4)] = s;  // ([lane][4] behind the selection scratch)
+#else
             ws.sg[wd] = s;
+#endif
         });
     }
 }
@@ -979,6 +998,12 @@ __device__ __forceinline__ void fork_tail(Path& p, uint32_t T, uint32_t side, We
     uint32_t par = 0;
     if constexpr (SPC) {
         par = (uint32_t)__builtin_popcount(ws.sg[0] ^ ws.sg[1] ^ ws.sg[2] ^ ws.sg[3]) & 1u;
+#if LN_BIG
+        if (T == 8u) {  // (a block of 256 LLRs: the upper four sign words sit in the LDS)
+            const uint4 sx = reinterpret_cast<const uint4*>(p.lds + SCR_SEL + 128)[p.lane];
+            par ^= (uint32_t)__builtin_popcount(sx.x ^ sx.y ^ sx.z ^ sx.w) & 1u;
+        }
+#endif
         const float v0 = bitsf(wv[0]), v1 = bitsf(wv[1]), v2 = bitsf(wv[2]), v3 = bitsf(wv[3]);
         const float t = m - v0;        // m' - pinv * v0 (par: m' = m - v0, pinv = 0; else m' = m, pinv = 1)
         const float mp = par ? t : m;  // m'
@@ -1001,7 +1026,11 @@ __device__ __forceinline__ void fork_tail(Path& p, uint32_t T, uint32_t side, We
     uint4* rec = reinterpret_cast<uint4*>(p.lds + SCR_FORK + p.lane * 8);
     const uint32_t packed = (wi[0] & 0xFFu) | ((wi[1] & 0xFFu) << 8) | ((wi[2] & 0xFFu) << 16) | ((wi[3] & 0xFFu) << 24);
     rec[0] = make_uint4(ws.sg[0], packed, par, ws.sg[1]);
+#if LN_BIG
+    if (T >= 7u) rec[1] = make_uint4(ws.sg[2], ws.sg[3], 0u, 0u);
+#else
     if (T == 7u) rec[1] = make_uint4(ws.sg[2], ws.sg[3], 0u, 0u);
+#endif
     sm.mark(1);
     uint32_t src, cand;
     select_fork<C>(p, cm, src, cand, sm);
@@ -1023,6 +1052,21 @@ __device__ __forceinline__ void fork_tail(Path& p, uint32_t T, uint32_t side, We
     }
     constexpr int NF = SPC ? 4 : 2;
     uint32_t w[4] = { s0.x, s0.w, 0u, 0u };
+#if LN_BIG
+    if (T == 8u) {  // a block of 256 LLRs: eight words, to the arena like the other bits of that stage
+        const uint4 s1 = sr[1];
+        const uint4 s2 = reinterpret_cast<const uint4*>(p.lds + SCR_SEL + 128)[src];
+        uint32_t w8[8] = { s0.x, s0.w, s1.x, s1.y, s2.x, s2.y, s2.z, s2.w };
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            const uint32_t ix = (spk >> (8 * k)) & 0xFFu;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w8[i] ^= ((ix >> 5) == (uint32_t)i) ? (fl[k] << (ix & 31u)) : 0u;
+        }
+        put_bits<8>(p, side, w8);
+        return;
+    }
+#endif
     if (T <= 5u) {  // one word
 #pragma unroll
         for (int k = 0; k < NF; ++k) w[0] ^= fl[k] << ((spk >> (8 * k)) & 31u);
@@ -1653,6 +1697,9 @@ void scl_lane_kernel(const DecodeParams P)
                         if constexpr (CH) leaf_rep_any<1>(p, lside, sm);
                         else leaf_rep<1>(p, lside, sm);
                         break;
+#if LN_BIG
+                    case 0x38: leaf_scan<8, CH>(p, ws); break;
+#endif
                     case 0x37: leaf_scan<7, CH>(p, ws); break;
                     case 0x36: leaf_scan<6, CH>(p, ws); break;
                     case 0x35: leaf_scan<5, CH>(p, ws); break;
@@ -1778,31 +1825,29 @@ void scl_lane_kernel(const DecodeParams P)
     }
 }
 
+#if LN_BIG
+hipError_t launch_scl_lane_big(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
+#else
 // (explicit instantiation first: the float kernel of the headline configuration opens the code object, see sc_pair_kernel.hip)
 template __global__ void scl_lane_kernel<false, false>(const DecodeParams);
 
 hipError_t launch_scl_lane(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
+#endif
 {
 #ifdef PAMD_DIAG
-    if (diag) {
+    if (diag || P.chr) {  // (the int8 decoder on this kernel: an experiment of the diagnostic build, see capi.cpp)
         if (P.chr) hipLaunchKernelGGL((scl_lane_kernel<true, true>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
         else hipLaunchKernelGGL((scl_lane_kernel<true, false>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
         return hipGetLastError();
     }
 #else
-    if (diag) return hipErrorInvalidValue;
-#endif
-#ifdef PAMD_DIAG
-    if (P.chr) {  // (the int8 decoder on this kernel: an experiment of the diagnostic build, see capi.cpp)
-        hipLaunchKernelGGL((scl_lane_kernel<false, true>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
-        return hipGetLastError();
-    }
-#else
-    if (P.chr) return hipErrorInvalidValue;
+    if (diag || P.chr) return hipErrorInvalidValue;
 #endif
     hipLaunchKernelGGL((scl_lane_kernel<false, false>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
     return hipGetLastError();
 }
+#if !LN_BIG
 unsigned scl_lane_arena_words() { return lane::AR_WORDS; }
+#endif
 
 }  // namespace pamd
