@@ -570,58 +570,67 @@ __device__ __forceinline__ void merge_level(uint32_t (&k)[8])
         bitonic_clean<2 * M>(k);
     }
 }
-// number of the eight keys of k[] that are smaller than x
-__device__ __forceinline__ uint32_t rank_in(const uint32_t (&k)[8], uint32_t x)
-{
-    uint32_t r = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r += (k[i] < x) ? 1u : 0u;
-    return r;
-}
-
 // Literal emulation of the selection sort on the exact metrics: every candidate carries its CURRENT position in the
-// reference's array (pl * C + c at the start); round i takes the largest value at positions >= i (first position on
-// ties), the candidate sitting at position i moves to the winner's old position.  Returns the winners as keys in rank
-// order in k[] (the same form the merge network delivers: low 6 bits = (lane, candidate), upper bits = rank, so that
-// they are ascending and pairwise different).
+// reference's array (rank * C + c at the start); round i takes the largest value at positions >= i (first position on
+// ties), the candidate sitting at position i moves to the winner's old position.  Two reductions over the codeword per
+// round (best value, then first position holding it); a lane notes the round in which a candidate of its own wins and
+// posts (lane, candidate) under that rank in the scratch.  Returns the entry of this lane's rank.
 template <int C>
-__device__ __forceinline__ void select_literal(const Path& p, const float (&cm)[C], uint32_t np, uint32_t (&k)[8])
+__device__ __forceinline__ uint32_t select_literal(const Path& p, const float (&cm)[C], uint32_t np)
 {
     constexpr uint32_t INF = 0xFFFFFFFFu;
     const bool live = p.pl < p.P;
-    uint32_t pos[C], key[C];
+    const uint32_t cwbase = SCR_SEL + (uint32_t)(p.lane >> 3) * 8u;  // ranks [codeword][8]
+    const uint32_t dummy = SCR_SEL + 64u + (uint32_t)p.lane;          // where the losers post
+    uint32_t pos[C], key[C], rec[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        pos[c] = live ? p.pl * (uint32_t)C + (uint32_t)c : INF;
+        pos[c] = live ? (uint32_t)p.q * (uint32_t)C + (uint32_t)c : INF;
         key[c] = live ? fbits(cm[c]) : INF;
+        rec[c] = dummy;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        k[i] = INF;
         if ((uint32_t)i < np) {
-            uint32_t bk = INF;
+            uint32_t bk = key[0];
 #pragma unroll
-            for (int c = 0; c < C; ++c) bk = umin(bk, pos[c] != INF ? key[c] : INF);
+            for (int c = 1; c < C; ++c) bk = umin(bk, key[c]);
             const uint32_t gk = cw_min(bk);
             uint32_t bp = INF;
 #pragma unroll
-            for (int c = 0; c < C; ++c) bp = umin(bp, (pos[c] != INF && key[c] == gk) ? pos[c] : INF);
+            for (int c = 0; c < C; ++c) bp = umin(bp, key[c] == gk ? pos[c] : INF);
             const uint32_t gp = cw_min(bp);
-            uint32_t mine = INF;
+            const uint32_t here = cwbase + (uint32_t)i;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const bool win = pos[c] == gp;
-                mine = win ? (((uint32_t)i << 6) | ((uint32_t)p.q << 3) | (uint32_t)c) : mine;
                 const bool at_i = pos[c] == (uint32_t)i;
+                rec[c] = win ? here : rec[c];
+                key[c] = win ? INF : key[c];
                 pos[c] = win ? INF : (at_i ? gp : pos[c]);
             }
-            k[i] = cw_min(mine);
         }
     }
+    const uint32_t tag = (uint32_t)p.q << 3;
+#pragma unroll
+    for (int c = 0; c < C; ++c) p.lds[rec[c]] = tag | (uint32_t)c;
+    return p.lds[cwbase + (uint32_t)p.q];
 }
 
-// Chooses the np = min(L, P * C) best candidates of every codeword and re-seats the paths: on return this lane hosts
-// the path of rank p.pl (or none), taken from lane `src` (absolute), candidate `cand`; p.metric is the candidate's.
+// k[q] for q = 0 .. 7
+__device__ __forceinline__ uint32_t pick8(const uint32_t (&k)[8], uint32_t q)
+{
+    const bool b0 = (q & 1u) != 0, b1 = (q & 2u) != 0, b2 = (q & 4u) != 0;
+    const uint32_t a0 = b0 ? k[1] : k[0], a1 = b0 ? k[3] : k[2], a2 = b0 ? k[5] : k[4], a3 = b0 ? k[7] : k[6];
+    const uint32_t c0 = b1 ? a1 : a0, c1 = b1 ? a3 : a2;
+    return b2 ? c1 : c0;
+}
+
+// Chooses the np = min(L, P * C) best candidates of every codeword and re-seats the paths BY RANK: lane q of the codeword
+// hosts the path at position q of the reference's list afterwards (p.pl == q for the np live lanes; what a path owns is
+// found through its slot word, so a path changes lanes at the price of one ds_bpermute), taken from lane `src`
+// (absolute), candidate `cand`; p.metric is the candidate's.  With lane == list position the payload (lane, candidate) of
+// the keys orders equal values the way their positions in the reference's candidate array do.
 // cm[]: this lane's candidate metrics, in an order whose keys ascend except where `fix` says otherwise (fix: SPC's
 // {c3, c4} pair and the two repetition candidates are put in order here).
 template <int C>
@@ -664,7 +673,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     merge_level<(2 * C < 8 ? 2 * C : 8), 0x4E>(k);
     merge_level<(4 * C < 8 ? 4 * C : 8), 0x141>(k);
     // exactness: neighbours among the np chosen differ above the payload bits, and nobody outside them is at or below
-    // the last one.  nme = number of this lane's candidates among the chosen.
+    // the last one (nme = number of this lane's candidates at or below it).
     uint32_t dmin = INF;
 #pragma unroll
     for (int i = 0; i < 7; ++i) dmin = umin(dmin, ((uint32_t)(i + 1) < np) ? (k[i] ^ k[i + 1]) : INF);
@@ -676,55 +685,10 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
 #pragma unroll
     for (int c = 0; c < C; ++c) nme += (own[c] <= kc63) ? 1u : 0u;
     const bool tie = (dmin < 64u) || (cw_add(nme) != np);
-    if (ballot64(tie) != 0) {  // (wave uniform; rare on real-valued input)
-        uint32_t ex[8];
-        select_literal<C>(p, cm, np, ex);
-        nme = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            k[i] = ex[i];
-            nme += ((uint32_t)i < np && ((ex[i] >> 3) & 7u) == (uint32_t)p.q) ? 1u : 0u;
-        }
-        // own[] in rank order: the lane's winners first
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int c = 0; c < C; ++c) own[c] = INF;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bool mine = (uint32_t)i < np && ((ex[i] >> 3) & 7u) == (uint32_t)p.q;
-#pragma unroll
-            for (int c = 0; c < C; ++c) own[c] = (mine && cnt == (uint32_t)c) ? ex[i] : own[c];
-            cnt += mine ? 1u : 0u;
-        }
-        if (!live) nme = 0;
-    }
+    uint32_t mykey = pick8(k, (uint32_t)p.q);
+    if (ballot64(tie) != 0) mykey = select_literal<C>(p, cm, np);  // (wave uniform; rare on real-valued input)
     sm.mark(2);
-    // Seats.  A lane whose path has candidates among the chosen keeps the best of them (own[0]); its further chosen
-    // candidates ("extras": own[1 .. nme)) go to the lanes whose path has none ("free": dead lanes included), matched in
-    // lane order through the scratch -- which lane hosts which path is invisible outside, only the rank (p.pl) matters.
-    const uint64_t freem = ballot64(nme == 0) >> p.g0;  // (bits 0 .. 7: the lanes of this codeword)
-    const uint32_t fidx = (uint32_t)__builtin_popcount((uint32_t)freem & ((1u << p.q) - 1u));  // my number among the free lanes
-    uint32_t mykey = nme ? own[0] : INF;
-    if (ballot64(nme > 1u) != 0) {  // (somebody forks)
-        const uint32_t ex = nme ? nme - 1u : 0u;
-        uint32_t sc = ex;  // inclusive prefix sum over the lanes of the codeword
-        const uint32_t t1 = dpp_u32<0x111>(sc);
-        sc += p.q >= 1 ? t1 : 0u;
-        const uint32_t t2 = dpp_u32<0x112>(sc);
-        sc += p.q >= 2 ? t2 : 0u;
-        const uint32_t t4 = dpp_u32<0x114>(sc);
-        sc += p.q >= 4 ? t4 : 0u;
-        uint32_t* tab = p.lds + SCR_SEL + (uint32_t)(p.lane >> 3) * 8u;
-        const uint32_t base = sc - ex;
-#pragma unroll
-        for (int e = 1; e < C; ++e)
-            if ((uint32_t)e < nme) tab[base + (uint32_t)e - 1u] = own[e];
-        const uint32_t got = tab[fidx < 8u ? fidx : 0u];
-        const uint32_t nextra = np - (8u - (uint32_t)__builtin_popcount((uint32_t)freem & 0xFFu));
-        mykey = (nme == 0 && fidx < nextra) ? got : mykey;
-    }
-    const bool seated = mykey != INF;
-    const uint32_t myj = rank_in(k, mykey);
+    const bool seated = (uint32_t)p.q < np;
     src = seated ? ((uint32_t)p.g0 | ((mykey >> 3) & 7u)) : (uint32_t)p.lane;
     cand = mykey & 7u;
     // the path's state: metric from the scratch, slot word from the source lane
@@ -732,7 +696,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     const uint32_t nslot = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)p.slot);
     p.metric = seated ? nm : p.metric;
     p.slot = nslot;
-    p.pl = seated ? myj : 15u;
+    p.pl = seated ? (uint32_t)p.q : 15u;
     p.P = np;
 }
 

@@ -7,12 +7,17 @@ sys.path[:0] = [os.path.join(_R, 'polar-codes_amd'), os.path.join(_R, 'tests')]
 os.environ.setdefault('PYPOLAR_AMD_LIB', os.path.join(_R, 'polar-codes_amd', 'lib', 'libpolar_amd_diag.so'))
 import golden_io as gio
 import pypolar_amd
+os.environ.setdefault('PCD_ABLATE', '256')
 names = {73: "WALK", 64: 'VT', 65: 'F', 66: 'G', 67: 'G0', 68: 'C', 69: 'R0', 70: 'R1', 71: 'REP', 72: 'SPC', 0: 'END'}
 fx = gio.load_named(sys.argv[1] if len(sys.argv) > 1 else "cfg3_n1024_k512_l8_crc24_awgn.bin")
 d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, "float")
 d.setErrorDetection(fx.crc_size, fx.crc_type)
 os.environ['PCD_SUBPROFILE'] = '/tmp/lane_sub.txt'
-ops, st, cyc = d.scl_profile(fx.llr[3])
+row = fx.llr[3]
+if len(sys.argv) > 2:  # second argument q: the row rounded to multiples of 1/q (equal magnitudes and metrics: the exact-tie paths)
+    import numpy as np
+    row = (np.round(row * float(sys.argv[2])) / float(sys.argv[2])).astype(np.float32)
+ops, st, cyc = d.scl_profile(row)
 agg = defaultdict(lambda: [0, 0])
 for o, s, c in zip(ops, st, cyc):
     k = (names.get(int(o), str(int(o))), int(s))
@@ -28,17 +33,14 @@ sub = defaultdict(lambda: [0, 0, 0, 0, 0, 0])
 for line in open('/tmp/lane_sub.txt'):
     o, s_, c, a, b, c2, d2 = (int(x) for x in line.split())
     k = names.get(o, str(o))
-    if k == 'WALK':
-        seg = [a if False else 0, b, c2 - b, c - c2, 0]
-        seg = [b, c2 - b, c - c2, 0, 0]
+    if d2 == 0:  # no forking leaf behind this dispatch (needs PCD_ABLATE=256 for the phase stamps)
+        seg = [c, 0, 0, 0, 0]
+        k += ' (no fork)'
     else:
-        if b == 0:
-            seg = [c, 0, 0, 0, 0]
-        else:
-            seg = [a, b - a, c2 - b, d2 - c2, c - d2]
+        seg = [a, b - a, c2 - b, d2 - c2, c - d2]
     sub[k][5] += 1
     for i in range(5):
         sub[k][i] += seg[i]
-print("segments (cycles summed over the pass): leaves = scan | weak+cands | merge+tie | seats+state | bits ; WALK = combines | G | F")
+print("segments (cycles summed over the pass; PCD_ABLATE=256): walk + leaf scan | weak search + candidates | merge + ties | seats + state | bits")
 for k, v in sub.items():
     print(f"{k:5s} n={v[5]:3d} ", " ".join(f"{x:8d}" for x in v[:5]))
