@@ -814,11 +814,11 @@ int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
 
 int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
-    if (d->has_lane && i8 == (d->dectype == 0)) {
-        if (i8) {  // int8 decoder: its lane kernel reads fp32 rows (exact widening; 4 bytes per LLR of scratch)
+    // (int8 rows addressed through a row list -- the list pass of "mixed" -- stay on the path-group kernel, which widens in place)
+    if (d->has_lane && !(i8 && P.rowidx)) {
+        if (i8) {  // the lane kernel reads fp32 rows: int8 rows are widened first (exact: bitcontainer.cpp:202-207; 4 bytes per LLR of scratch)
             int rc = grow(d->d_f32, d->d_f32_cap, (size_t)P.rows * d->N * sizeof(float));
             if (rc) return rc;
-            if (P.rowidx) return PCD_ERR_UNSUPPORTED;
             HIP_TRY(pamd::launch_i8_to_f32(reinterpret_cast<const int8_t*>(P.llr), d->d_f32, (size_t)P.rows * d->N, st));
             P.llr = d->d_f32;
         }

@@ -684,11 +684,26 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     uint32_t nme = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) nme += (own[c] <= kc63) ? 1u : 0u;
-    const bool tie = (dmin < 64u) || (cw_add(nme) != np);
+    const bool cut_tie = cw_add(nme) != np;
     uint32_t mykey = pick8(k, (uint32_t)p.q);
-    if (ballot64(tie) != 0) mykey = select_literal<C>(p, cm, np);  // (wave uniform; rare on real-valued input)
-    sm.mark(2);
     const bool seated = (uint32_t)p.q < np;
+    if (ballot64((dmin < 64u) || cut_tie) != 0) {  // (wave uniform; rare on real-valued input)
+        // Equal metrics.  The merge order is the stable one (value, then position in the candidate array); the reference's
+        // selection sort leaves it only where a swap carries a candidate past its equals: a chosen candidate that has an
+        // equal (among the chosen, or left out at the cut) and sits at a position below its rank -- round `position` moves
+        // it away before its own turn.  Nobody like that in the wave, and keys that are the whole metric (low bits
+        // clear, as with quantised LLRs): the merge result stands.  Otherwise the literal emulation decides.
+        uint32_t low = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) low |= fbits(cm[c]);
+        const uint32_t q = (uint32_t)p.q;
+        const uint32_t prev = dpp_u32<0x111>(mykey), next = dpp_u32<0x101>(mykey);  // ranks q - 1 and q + 1 (row_shr / row_shl)
+        const bool equal = (q > 0u && (mykey ^ prev) < 64u) || (q + 1u < np && (mykey ^ next) < 64u) || (cut_tie && (mykey | 63u) == kc63);
+        const uint32_t at = C == 8 ? (mykey & 63u) : C == 4 ? (((mykey >> 1) & 0x1Cu) | (mykey & 3u)) : (((mykey >> 2) & 0xEu) | (mykey & 1u));
+        const bool moved = seated && equal && at < q;
+        if (ballot64(moved || (live && (low & 63u) != 0u)) != 0) mykey = select_literal<C>(p, cm, np);
+    }
+    sm.mark(2);
     src = seated ? ((uint32_t)p.g0 | ((mykey >> 3) & 7u)) : (uint32_t)p.lane;
     cand = mykey & 7u;
     // the path's state: metric from the scratch, slot word from the source lane
