@@ -1406,12 +1406,14 @@ int pcd_scl_profile(pcd_decoder* d, const float* llr_row, uint8_t* ops, uint8_t*
     const unsigned n = (unsigned)prog.ins.size();
     *count = n;
     uint32_t* dcyc = nullptr;
-    if ((rc = grow(d->d_in, d->d_in_cap, (size_t)d->N * 4))) return rc;
-    if ((rc = grow(d->d_out, d->d_out_cap, d->nb))) return rc;
+    size_t prows = 1;  // (PCD_PROFILE_ROWS = 8: llr_row holds 8 rows, one per codeword of the profiled wave)
+    if (const char* e = PAMD_ENV("PCD_PROFILE_ROWS")) prows = (size_t)std::max(1, std::min(8, std::atoi(e)));
+    if ((rc = grow(d->d_in, d->d_in_cap, prows * d->N * 4))) return rc;
+    if ((rc = grow(d->d_out, d->d_out_cap, prows * d->nb))) return rc;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dcyc), (size_t)n * 5 * 4));
     HIP_TRY(hipMemset(dcyc, 0, (size_t)n * 5 * 4));
-    HIP_TRY(hipMemcpy(d->d_in, llr_row, (size_t)d->N * 4, hipMemcpyHostToDevice));
-    pamd::DecodeParams P = base_params(d, d->d_in, 1, d->d_out, nullptr, nullptr);
+    HIP_TRY(hipMemcpy(d->d_in, llr_row, prows * d->N * 4, hipMemcpyHostToDevice));
+    pamd::DecodeParams P = base_params(d, d->d_in, prows, d->d_out, nullptr, nullptr);
     P.cycles = dcyc;
     P.prog_len = n - 1;  // (the kernel's loop count and the offset of the phase stamps; the OP_END word is not executed)
     for (int rep = 0; rep < 2 && !rc; ++rep) rc = run_scl(d, P, false, nullptr);  // second run: warm caches

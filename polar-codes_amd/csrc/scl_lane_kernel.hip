@@ -589,9 +589,10 @@ __device__ __forceinline__ uint32_t select_literal(const Path& p, const float (&
         key[c] = live ? fbits(cm[c]) : INF;
         rec[c] = dummy;
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if ((uint32_t)i < np) {
+    const uint32_t rounds = (uint32_t)__builtin_amdgcn_readfirstlane((int)np);  // (np is the same in every lane)
+#pragma unroll 1
+    for (uint32_t i = 0; i < rounds; ++i) {
+        {
             uint32_t bk = key[0];
 #pragma unroll
             for (int c = 1; c < C; ++c) bk = umin(bk, key[c]);
@@ -614,6 +615,46 @@ __device__ __forceinline__ uint32_t select_literal(const Path& p, const float (&
     const uint32_t tag = (uint32_t)p.q << 3;
 #pragma unroll
     for (int c = 0; c < C; ++c) p.lds[rec[c]] = tag | (uint32_t)c;
+    return p.lds[cwbase + (uint32_t)p.q];
+}
+
+// position in the reference's candidate array (rank * C + candidate) of the candidate a key's payload (lane << 3 | candidate) names
+template <int C>
+__device__ __forceinline__ uint32_t array_pos(uint32_t key)
+{
+    if constexpr (C == 8) return key & 63u;
+    else if constexpr (C == 4) return ((key >> 1) & 0x1Cu) | (key & 3u);
+    else return ((key >> 2) & 0xEu) | (key & 1u);
+}
+
+// The same emulation over the candidates that can win a round, at most two per lane: the one the merge ranked q (lane q
+// holds it: `key`, at array position `at`) and one that was left out AT the cut (equal to the last chosen one: `zkey`,
+// INF if the lane has none).  Candidates below the cut never win, so this is exact when the keys are the whole metric
+// and no lane has two left out at the cut (the caller checks both).
+template <int C>
+__device__ __forceinline__ uint32_t select_chosen(const Path& p, uint32_t key, uint32_t at, bool seated, uint32_t np, uint32_t zkey)
+{
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+    const uint32_t cwbase = SCR_SEL + (uint32_t)(p.lane >> 3) * 8u;
+    uint32_t rec = SCR_SEL + 64u + (uint32_t)p.lane, zrec = rec;
+    uint32_t comb = seated ? ((key & ~63u) | at) : INF;
+    uint32_t zcomb = zkey != INF ? ((zkey & ~63u) | array_pos<C>(zkey)) : INF;
+    const uint32_t rounds = (uint32_t)__builtin_amdgcn_readfirstlane((int)np);  // (np is the same in every lane)
+#pragma unroll 1
+    for (uint32_t i = 0; i < rounds; ++i) {
+        {
+            const uint32_t g = cw_min(umin(comb, zcomb));
+            const uint32_t gp = g & 63u;
+            const bool win = comb == g, zwin = zcomb == g;
+            const bool at_i = (comb & 63u) == (uint32_t)i, zat_i = (zcomb & 63u) == (uint32_t)i;
+            rec = win ? cwbase + (uint32_t)i : rec;
+            zrec = zwin ? cwbase + (uint32_t)i : zrec;
+            comb = win ? INF : (at_i ? ((comb & ~63u) | gp) : comb);
+            zcomb = zwin ? INF : (zat_i ? ((zcomb & ~63u) | gp) : zcomb);
+        }
+    }
+    p.lds[zrec] = zkey & 63u;  // (a loser posts at the lane's spare word -- first, so that a winner of the same lane overwrites nothing)
+    p.lds[rec] = key & 63u;
     return p.lds[cwbase + (uint32_t)p.q];
 }
 
@@ -692,16 +733,32 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
         // selection sort leaves it only where a swap carries a candidate past its equals: a chosen candidate that has an
         // equal (among the chosen, or left out at the cut) and sits at a position below its rank -- round `position` moves
         // it away before its own turn.  Nobody like that in the wave, and keys that are the whole metric (low bits
-        // clear, as with quantised LLRs): the merge result stands.  Otherwise the literal emulation decides.
+        // clear, as with quantised LLRs): the merge result stands.  Otherwise the literal emulation decides -- over the
+        // chosen candidates alone where that is exact (select_chosen), over all of them where not.
         uint32_t low = 0;
 #pragma unroll
         for (int c = 0; c < C; ++c) low |= fbits(cm[c]);
         const uint32_t q = (uint32_t)p.q;
         const uint32_t prev = dpp_u32<0x111>(mykey), next = dpp_u32<0x101>(mykey);  // ranks q - 1 and q + 1 (row_shr / row_shl)
         const bool equal = (q > 0u && (mykey ^ prev) < 64u) || (q + 1u < np && (mykey ^ next) < 64u) || (cut_tie && (mykey | 63u) == kc63);
-        const uint32_t at = C == 8 ? (mykey & 63u) : C == 4 ? (((mykey >> 1) & 0x1Cu) | (mykey & 3u)) : (((mykey >> 2) & 0xEu) | (mykey & 1u));
+        const uint32_t at = array_pos<C>(mykey);
         const bool moved = seated && equal && at < q;
-        if (ballot64(moved || (live && (low & 63u) != 0u)) != 0) mykey = select_literal<C>(p, cm, np);
+        bool all = live && (low & 63u) != 0u;  // (keys that are not the whole metric: the emulation over all candidates)
+        if (ballot64(moved || all) != 0) {
+            uint32_t zkey = INF;
+            if (ballot64(cut_tie) != 0) {  // candidates left out at the cut
+                uint32_t nz = 0;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const bool z = (own[c] | 63u) == kc63 && own[c] > kcut;
+                    zkey = umin(zkey, z ? own[c] : INF);
+                    nz += z ? 1u : 0u;
+                }
+                all = all || nz > 1u;
+            }
+            if (ballot64(all) != 0) mykey = select_literal<C>(p, cm, np);
+            else mykey = select_chosen<C>(p, mykey, at, seated, np, zkey);
+        }
     }
     sm.mark(2);
     src = seated ? ((uint32_t)p.g0 | ((mykey >> 3) & 7u)) : (uint32_t)p.lane;

@@ -5,6 +5,7 @@ from collections import defaultdict
 _R = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path[:0] = [os.path.join(_R, 'polar-codes_amd'), os.path.join(_R, 'tests')]
 os.environ.setdefault('PYPOLAR_AMD_LIB', os.path.join(_R, 'polar-codes_amd', 'lib', 'libpolar_amd_diag.so'))
+import numpy as np
 import golden_io as gio
 import pypolar_amd
 os.environ.setdefault('PCD_ABLATE', '256')
@@ -13,9 +14,9 @@ fx = gio.load_named(sys.argv[1] if len(sys.argv) > 1 else "cfg3_n1024_k512_l8_cr
 d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, "float")
 d.setErrorDetection(fx.crc_size, fx.crc_type)
 os.environ['PCD_SUBPROFILE'] = '/tmp/lane_sub.txt'
-row = fx.llr[3]
+nrows = int(os.environ.get('PCD_PROFILE_ROWS', '1'))  # (8: a full wave of different codewords)
+row = np.ascontiguousarray(fx.llr[3:3 + nrows]).reshape(-1)
 if len(sys.argv) > 2:  # second argument q: the row rounded to multiples of 1/q (equal magnitudes and metrics: the exact-tie paths)
-    import numpy as np
     row = (np.round(row * float(sys.argv[2])) / float(sys.argv[2])).astype(np.float32)
 ops, st, cyc = d.scl_profile(row)
 agg = defaultdict(lambda: [0, 0])
