@@ -952,6 +952,9 @@ __device__ __forceinline__ void leaf_rep_any(Path& p, uint32_t side, const Stamp
 // RateOneDecoder::decode :353-413 and SpcDecoder::decode :498-621, first half: hard decisions and the weak-LLR scan of
 // the block (what follows -- findWeakLlrs' iterations, candidates, selection, bits -- is shared: fork_tail)
 // CH (int8 decoder): magnitudes are abs(max(x, -127)) (scl_fip_char.cpp:413-417, 587-590)
+#ifndef LN_SCAN_REGS
+#define LN_SCAN_REGS 5
+#endif
 template <int T, bool CH = false>
 __device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
 {
@@ -962,7 +965,7 @@ __device__ __forceinline__ void leaf_scan(const Path& p, WeakScan& ws)
     };
     constexpr int n = 1 << T;
     ws.init();
-    if constexpr (T <= 6) {  // straight from the registers (stages 5 and 6 used to go through a dump in the arena: a store -> load round trip)
+    if constexpr (T <= LN_SCAN_REGS) {  // straight from the registers (stage 6: through a dump in the arena -- 64 unrolled insertions are 12 KB of code that runs once per pass)
         static_for<(n + 31) / 32>([&](auto Wd) {
             constexpr int wd = decltype(Wd)::value;
             uint32_t s = 0;

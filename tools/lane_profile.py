@@ -11,13 +11,18 @@ import pypolar_amd
 os.environ.setdefault('PCD_ABLATE', '256')
 names = {73: "WALK", 64: 'VT', 65: 'F', 66: 'G', 67: 'G0', 68: 'C', 69: 'R0', 70: 'R1', 71: 'REP', 72: 'SPC', 0: 'END'}
 fx = gio.load_named(sys.argv[1] if len(sys.argv) > 1 else "cfg3_n1024_k512_l8_crc24_awgn.bin")
-d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, "float")
+dectype = os.environ.get('LANE_PROFILE_TYPE', 'float')  # char: the int8 decoder (PCD_FORCE_LANE=1), the row is rounded to int8 values (x 8)
+if dectype == 'char':
+    os.environ['PCD_FORCE_LANE'] = '1'
+d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, dectype)
 d.setErrorDetection(fx.crc_size, fx.crc_type)
 os.environ['PCD_SUBPROFILE'] = '/tmp/lane_sub.txt'
 nrows = int(os.environ.get('PCD_PROFILE_ROWS', '1'))  # (8: a full wave of different codewords)
 row = np.ascontiguousarray(fx.llr[3:3 + nrows]).reshape(-1)
 if len(sys.argv) > 2:  # second argument q: the row rounded to multiples of 1/q (equal magnitudes and metrics: the exact-tie paths)
     row = (np.round(row * float(sys.argv[2])) / float(sys.argv[2])).astype(np.float32)
+if dectype == 'char':
+    row = np.clip(np.rint(row * 8.0), -128, 127).astype(np.float32)
 ops, st, cyc = d.scl_profile(row)
 agg = defaultdict(lambda: [0, 0])
 for o, s, c in zip(ops, st, cyc):
