@@ -807,7 +807,8 @@ int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
     if (rc) return rc;
     P.arena = d->d_arena;
     const bool diag_k = P.trace != nullptr || P.cycles != nullptr || P.ablate != 0;
-    if (d->lane_big) HIP_TRY(pamd::launch_scl_lane_big(P, diag_k, grid, st));
+    if (P.chr) HIP_TRY(pamd::launch_scl_lane_char(P, diag_k, grid, st));
+    else if (d->lane_big) HIP_TRY(pamd::launch_scl_lane_big(P, diag_k, grid, st));
     else HIP_TRY(pamd::launch_scl_lane(P, diag_k, grid, st));
     return PCD_OK;
 }
@@ -1180,13 +1181,14 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         //  widened to fp32 on the way in -- and is exact there, but SLOWER than on the path-group kernels: 20.3 against 23.4 M cw/s
         //  on cfg3_i8.  Integer metrics tie all the time and every tie sends the selection through the literal emulation of the
         //  reference's sort.  Diagnostic build only, behind PCD_FORCE_LANE.)
-        if ((!chr || PAMD_ENV("PCD_FORCE_LANE")) && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) {
+        if ((!chr || !PAMD_ENV("PCD_NO_CHAR_LANE")) && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) {
             // (... or from 30 FORKING leaves on: the high-rate trees have few leaves, but large RateOne / SPC ones -- K = 900: 46 leaves, 35 of
             //  them forking, 35.1 against 24.9 M cw/s)
             unsigned forks = 0;
             for (const auto& in : d->scl_prog.ins) forks += (in.op == pamd::SCL_R1 || in.op == pamd::SCL_SPC || in.op == pamd::SCL_REP) ? 1u : 0u;
             if (d->scl_prog.leaves >= 48u || forks >= 30u || PAMD_ENV("PCD_FORCE_LANE"))
                 d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr, &d->lane_big);
+            if (chr && d->lane_big) d->has_lane = d->lane_big = false;  // (no int8 instantiation with the leaves of 256 LLRs)
         }
     }
     compute_geometry(d);

@@ -28,11 +28,17 @@
 // under another name.  A property of the code -- the host picks the kernel per decoder.  As a SECOND translation unit on purpose:
 // with those leaves in the one kernel cfg 3 lost 3.8 %, as a template flag of the one source still 2 % (the lean kernel came out
 // with another register allocation); guarded by the preprocessor the lean kernel's token stream is what it was.
+// LN_CHAR (scl_lane_char.hip): the int8 decoder's instantiation (CH = true), a third translation unit for the same reason.
 #ifndef LN_BIG
 #define LN_BIG 0
 #endif
+#ifndef LN_CHAR
+#define LN_CHAR 0
+#endif
 #if LN_BIG
 #define scl_lane_kernel scl_lane_big_kernel
+#elif LN_CHAR
+#define scl_lane_kernel scl_lane_char_kernel
 #endif
 #define PAMD_POLAR_F_MINF 1  // (device_common.h: the 3-instruction f)
 #include "device_common.h"
@@ -1864,6 +1870,24 @@ void scl_lane_kernel(const DecodeParams P)
     }
 }
 
+#if LN_CHAR
+// SclFipChar on the lane kernel: saturating f / g, repetition leaves at every size; the rows arrive widened to fp32
+template __global__ void scl_lane_kernel<false, true>(const DecodeParams);
+
+hipError_t launch_scl_lane_char(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
+{
+#ifdef PAMD_DIAG
+    if (diag) {
+        hipLaunchKernelGGL((scl_lane_kernel<true, true>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+        return hipGetLastError();
+    }
+#else
+    if (diag) return hipErrorInvalidValue;
+#endif
+    hipLaunchKernelGGL((scl_lane_kernel<false, true>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+    return hipGetLastError();
+}
+#else
 #if LN_BIG
 hipError_t launch_scl_lane_big(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
 #else
@@ -1873,14 +1897,14 @@ template __global__ void scl_lane_kernel<false, false>(const DecodeParams);
 hipError_t launch_scl_lane(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
 #endif
 {
+    if (P.chr) return hipErrorInvalidValue;  // (launch_scl_lane_char)
 #ifdef PAMD_DIAG
-    if (diag || P.chr) {  // (the int8 decoder on this kernel: an experiment of the diagnostic build, see capi.cpp)
-        if (P.chr) hipLaunchKernelGGL((scl_lane_kernel<true, true>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
-        else hipLaunchKernelGGL((scl_lane_kernel<true, false>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+    if (diag) {
+        hipLaunchKernelGGL((scl_lane_kernel<true, false>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
         return hipGetLastError();
     }
 #else
-    if (diag || P.chr) return hipErrorInvalidValue;
+    if (diag) return hipErrorInvalidValue;
 #endif
     hipLaunchKernelGGL((scl_lane_kernel<false, false>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
     return hipGetLastError();
@@ -1888,5 +1912,6 @@ hipError_t launch_scl_lane(const DecodeParams& P, bool diag, unsigned grid, hipS
 #if !LN_BIG
 unsigned scl_lane_arena_words() { return lane::AR_WORDS; }
 #endif
+#endif  // LN_CHAR
 
 }  // namespace pamd

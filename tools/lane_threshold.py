@@ -7,14 +7,16 @@ sys.path.insert(0, os.path.join(R, "polar-codes_amd"))
 import torch, pypolar_amd
 from pypolar_amd.construction import frozen_bits
 B = 1 << 18
+DT = sys.argv[1] if len(sys.argv) > 1 else "float"  # "char": the int8 decoder on int8 rows
 for K, kind in ((32, "BB"), (64, "BB"), (100, "BB"), (176, "5G"), (256, "BB"), (400, "BB"), (512, "BB"), (640, "BB"), (768, "BB"), (900, "BB"), (980, "BB")):
     F = frozen_bits(1024, K, 0.0, kind)
     x = torch.randn(B, 1024, device="cuda") * 2 + 1
+    if DT == "char": x = torch.clamp(torch.round(x * 8), -128, 127).to(torch.int8)
     res = []
     for sw in ("PCD_FORCE_LANE", "PCD_NO_LANE"):
         for k in ("PCD_FORCE_LANE", "PCD_NO_LANE"): os.environ.pop(k, None)
         os.environ[sw] = "1"
-        d = pypolar_amd.PolarDecoder(1024, 8, F, "float"); d.setErrorDetection(8, "crc")
+        d = pypolar_amd.PolarDecoder(1024, 8, F, DT); d.setErrorDetection(8, "crc")
         lanes = d.launch_info(True)["path_groups"] == 64
         d.decode_batch(x); torch.cuda.synchronize(); t = time.time()
         for _ in range(3): d.decode_batch(x)
