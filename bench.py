@@ -536,7 +536,7 @@ def main():
     dec = pypolar_amd.PolarDecoder(N, L, frozen, "char" if chr_dec else "float", device=dev_index)
     dec.setErrorDetection(cfg["crc"], cfg["crc_type"])
     # the kernel this decoder launches (the PMC passes filter by it): one lane per path = the lane-per-path list kernel
-    kernel_name = ("sc_pair_kernel" if dec.launch_info(False)["codewords_per_workgroup"] == 32 else "sc_decode_kernel") if L <= 1 else ("scl_lane_kernel" if dec.launch_info(True)["path_groups"] == 64 else "scl_decode_kernel")
+    kernel_name = ("sc_pair_kernel" if dec.launch_info(False)["codewords_per_workgroup"] == 32 else "sc_decode_kernel") if L <= 1 else (("scl_lane_char_kernel" if chr_dec else "scl_lane_kernel") if dec.launch_info(True)["path_groups"] == 64 else "scl_decode_kernel")
 
     llr, info = make_batch(cfg, frozen, B, dev, seed=1234 + rank)
     if chr_dec:  # int8 rows resident in HBM: round(8 y), clipped to +-127

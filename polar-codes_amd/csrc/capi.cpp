@@ -1178,9 +1178,8 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         // 59.5 against 63.7 M cw/s, 50 leaves (K = 100) 55.4 against 48.9, cfg 4 (75 leaves) 45.0 against 40.2, cfg 3 (95) 34.0
         // against 27.8.  (Until the leaves rode on the walks the line was 48 FORKING leaves and cfg 4 stayed on the path groups.)
         // (The int8 decoder SclFipChar runs on the same kernel -- saturating f / g, repetition leaves at every size, int8 rows
-        //  widened to fp32 on the way in -- and is exact there, but SLOWER than on the path-group kernels: 20.3 against 23.4 M cw/s
-        //  on cfg3_i8.  Integer metrics tie all the time and every tie sends the selection through the literal emulation of the
-        //  reference's sort.  Diagnostic build only, behind PCD_FORCE_LANE.)
+        //  widened to fp32 on the way in: scl_lane_char.hip --, cfg3_i8 27.4 against 23.4 M cw/s on the path groups; the same
+        //  rule fits it, tools/lane_threshold.py char: 38 leaves 43.8 against 44.1, 53 leaves 38.1 against 32.8 M cw/s.)
         if ((!chr || !PAMD_ENV("PCD_NO_CHAR_LANE")) && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) {
             // (... or from 30 FORKING leaves on: the high-rate trees have few leaves, but large RateOne / SPC ones -- K = 900: 46 leaves, 35 of
             //  them forking, 35.1 against 24.9 M cw/s)
