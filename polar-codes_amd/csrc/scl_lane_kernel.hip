@@ -762,7 +762,9 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
                 }
                 all = all || nz > 1u;
             }
-            if (ballot64(all) != 0) mykey = select_literal<C>(p, cm, np);
+            // (diagnostics, results wrong: PCD_ABLATE=262144 neither emulation, 524288 the cheap one in place of the full one)
+            if (sm.ab & 262144u) {
+            } else if (ballot64(all) != 0 && !(sm.ab & 524288u)) mykey = select_literal<C>(p, cm, np);
             else mykey = select_chosen<C>(p, mykey, at, seated, np, zkey);
         }
     }
