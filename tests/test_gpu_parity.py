@@ -323,6 +323,38 @@ def test_lane_per_path_kernel_codes(built_library, N, K, L, kind):
         assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), "path metrics differ from the oracle's"
 
 
+@pytest.mark.parametrize("dectype,K,kind", [("float", 512, "BB"), ("float", 176, "5G"), ("char", 512, "BB"), ("char", 256, "BB")],
+                         ids=["float_K512", "float_5G_K176", "char_K512", "char_K256"])
+def test_lane_kernel_quantised_rows(built_library, dectype, K, kind):
+    """Quantised LLRs make equal path metrics the normal case at every fork of every codeword of a wave: the lane kernel's
+    three tiers of tie handling (merge order kept / emulation over the candidates that can win / over all of them) must
+    reproduce simplePartialSortDescending's swap order (arrayfuncs.h:161-183) -- AWGN rows at 2 dB rounded to 1/8, 1/2 and
+    to integers, float decoder (also fed int8 rows: widened onto the lane kernel) and int8 decoder; bytes, verdicts and
+    path metrics against the oracle."""
+    import pypolar_amd
+    N, L = 1024, 8
+    rng = np.random.default_rng(K + len(dectype))
+    frozen = np.asarray(pypolar_amd.frozen_bits(N, K, 0.0, kind), dtype=np.uint32)
+    sigma = 0.9
+    y = (1.0 + sigma * rng.standard_normal((96, N))).astype(np.float32) * (2.0 / sigma ** 2)
+    sets = [np.round(y * 8) / 8, np.round(y * 2) / 2, np.round(y)]
+    if dectype == "char":
+        sets = [np.clip(np.rint(y * 8), -128, 127), np.clip(np.rint(y * 2), -128, 127)]
+    for llr in sets:
+        llr = np.ascontiguousarray(llr, dtype=np.float32)
+        e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, 8, llr, True, dectype)
+        d = pypolar_amd.PolarDecoder(N, L, frozen, dectype)
+        d.setErrorDetection(8, "crc")
+        assert d.launch_info(True)["path_groups"] == 64, "expected the lane-per-path kernel for this code"
+        out, ok, met = d.decode_batch(llr, return_metrics=True)
+        assert np.array_equal(out, e_out)
+        assert np.array_equal(ok.astype(np.uint8), e_ok)
+        assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), "path metrics differ from the oracle's"
+        if np.abs(llr).max() <= 127 and np.array_equal(llr, np.rint(llr)):  # the same rows as int8 input
+            out8, ok8 = d.decode_batch(llr.astype(np.int8))
+            assert np.array_equal(out8, e_out) and np.array_equal(ok8.astype(np.uint8), e_ok)
+
+
 PAIR_CODES = [(512, 0.0, "BB"), (400, 0.0, "BB"), (640, 1.0, "BB"), (176, 0.0, "5G"), (512, 2.0, "BB"), (300, -1.0, "BB"), (768, 0.0, "BB"),
               (256, 1.0, "BB"), (100, 0.0, "BB"), (900, 2.0, "BB"), (512, 0.0, "BE"), (448, 0.5, "BB"), (576, 3.0, "BB")]
 
