@@ -807,7 +807,8 @@ int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
     if (rc) return rc;
     P.arena = d->d_arena;
     const bool diag_k = P.trace != nullptr || P.cycles != nullptr || P.ablate != 0;
-    if (P.chr) HIP_TRY(pamd::launch_scl_lane_char(P, diag_k, grid, st));
+    if (P.chr && d->lane_big) HIP_TRY(pamd::launch_scl_lane_char_big(P, diag_k, grid, st));
+    else if (P.chr) HIP_TRY(pamd::launch_scl_lane_char(P, diag_k, grid, st));
     else if (d->lane_big) HIP_TRY(pamd::launch_scl_lane_big(P, diag_k, grid, st));
     else HIP_TRY(pamd::launch_scl_lane(P, diag_k, grid, st));
     return PCD_OK;
@@ -1188,7 +1189,6 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
             // (the second clause only from rate 1/2 on: K = 64 has 44 leaves, 43 of them forking, and runs 63.1 against 64.5 M cw/s)
             if (d->scl_prog.leaves >= 48u || (forks >= 30u && 2u * d->K >= d->N) || PAMD_ENV("PCD_FORCE_LANE"))
                 d->has_lane = pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr, &d->lane_big);
-            if (chr && d->lane_big) d->has_lane = d->lane_big = false;  // (no int8 instantiation with the leaves of 256 LLRs)
         }
     }
     compute_geometry(d);

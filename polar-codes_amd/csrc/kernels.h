@@ -55,6 +55,7 @@ hipError_t launch_scl_lane(const DecodeParams& P, bool diag, unsigned grid, hipS
 hipError_t launch_scl_lane_big(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);
 // the int8 decoder's instantiation (scl_lane_char.hip); no leaves of 256 LLRs
 hipError_t launch_scl_lane_char(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);
+hipError_t launch_scl_lane_char_big(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);  // (scl_lane_char_big.hip)
 unsigned scl_lane_arena_words();
 // two-lanes-per-codeword SC kernel (sc_pair_kernel.hip): N = 1024, fp32 or int8 rows (P.chr: the int8 decoder, int8 rows only); P.prog = the PR_* program, P.ext / P.syn_bytes as for
 // the lane kernel; single-wave workgroups with 40 KB of dynamic LDS

@@ -35,7 +35,9 @@
 #ifndef LN_CHAR
 #define LN_CHAR 0
 #endif
-#if LN_BIG
+#if LN_BIG && LN_CHAR
+#define scl_lane_kernel scl_lane_char_big_kernel
+#elif LN_BIG
 #define scl_lane_kernel scl_lane_big_kernel
 #elif LN_CHAR
 #define scl_lane_kernel scl_lane_char_kernel
@@ -1876,7 +1878,11 @@ void scl_lane_kernel(const DecodeParams P)
 // SclFipChar on the lane kernel: saturating f / g, repetition leaves at every size; the rows arrive widened to fp32
 template __global__ void scl_lane_kernel<false, true>(const DecodeParams);
 
+#if LN_BIG
+hipError_t launch_scl_lane_char_big(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
+#else
 hipError_t launch_scl_lane_char(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
+#endif
 {
 #ifdef PAMD_DIAG
     if (diag) {

@@ -323,8 +323,9 @@ def test_lane_per_path_kernel_codes(built_library, N, K, L, kind):
         assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), "path metrics differ from the oracle's"
 
 
-@pytest.mark.parametrize("dectype,K,kind", [("float", 512, "BB"), ("float", 176, "5G"), ("char", 512, "BB"), ("char", 256, "BB")],
-                         ids=["float_K512", "float_5G_K176", "char_K512", "char_K256"])
+@pytest.mark.parametrize("dectype,K,kind", [("float", 512, "BB"), ("float", 176, "5G"), ("float", 900, "BB"), ("char", 512, "BB"), ("char", 256, "BB"),
+                                            ("char", 768, "BB"), ("char", 900, "BB")],
+                         ids=["float_K512", "float_5G_K176", "float_K900_big", "char_K512", "char_K256", "char_K768_big", "char_K900_big"])
 def test_lane_kernel_quantised_rows(built_library, dectype, K, kind):
     """Quantised LLRs make equal path metrics the normal case at every fork of every codeword of a wave: the lane kernel's
     three tiers of tie handling (merge order kept / emulation over the candidates that can win / over all of them) must
@@ -351,8 +352,10 @@ def test_lane_kernel_quantised_rows(built_library, dectype, K, kind):
         assert np.array_equal(ok.astype(np.uint8), e_ok)
         assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), "path metrics differ from the oracle's"
         if np.abs(llr).max() <= 127 and np.array_equal(llr, np.rint(llr)):  # the same rows as int8 input
-            out8, ok8 = d.decode_batch(llr.astype(np.int8))
-            assert np.array_equal(out8, e_out) and np.array_equal(ok8.astype(np.uint8), e_ok)
+            rows8 = llr.astype(np.int8)  # (a rounded -0.0 becomes +0: the oracle gets what the widening delivers)
+            e_out8, e_ok8, _ = ob.decode_batch(N, L, frozen, 8, rows8.astype(np.float32), True, dectype)
+            out8, ok8 = d.decode_batch(rows8)
+            assert np.array_equal(out8, e_out8) and np.array_equal(ok8.astype(np.uint8), e_ok8)
 
 
 PAIR_CODES = [(512, 0.0, "BB"), (400, 0.0, "BB"), (640, 1.0, "BB"), (176, 0.0, "5G"), (512, 2.0, "BB"), (300, -1.0, "BB"), (768, 0.0, "BB"),
