@@ -341,6 +341,18 @@ def test_launch_geometry_choices(built_library, N, L, cw, groups):
         assert d8.launch_info(False)["codewords_per_workgroup"] == 4
 
 
+@pytest.mark.parametrize("dectype,K,kind,lane", [
+    ("float", 512, "BB", True), ("float", 176, "5G", True), ("float", 900, "BB", True), ("float", 64, "BB", False), ("float", 32, "BB", False),
+    ("char", 512, "BB", True), ("char", 256, "BB", True), ("char", 768, "BB", True), ("char", 64, "BB", False)])
+def test_lane_kernel_rule(built_library, dectype, K, kind, lane):
+    """which list decoders (N = 1024, L = 8) the host puts on the lane-per-path kernel (capi.cpp, pcd_create): from 48 leaves on,
+    or from 30 forking leaves at rate 1/2 and above -- float and int8 decoders alike (profiles/r03_lane_vs_groups*.txt)"""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    d = pypolar_amd.PolarDecoder(1024, 8, frozen_bits(1024, K, 0.0, kind), dectype)
+    assert (d.launch_info(True)["path_groups"] == 64) == lane, d.launch_info(True)
+
+
 @pytest.mark.parametrize("dectype", ["float", "char"])
 def test_pair_kernel_takes_the_trees_it_can_express(built_library, dectype):
     """host side of the two-lanes-per-codeword SC kernel (pair_program.cpp, lower_pair): N = 1024 only, ROne nodes at every
