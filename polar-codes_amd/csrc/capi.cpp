@@ -816,12 +816,14 @@ int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
 
 int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
-    // (int8 rows addressed through a row list -- the list pass of "mixed" -- stay on the path-group kernel, which widens in place)
-    if (d->has_lane && !(i8 && P.rowidx)) {
+    if (d->has_lane && !(i8 && P.rowidx && !P.rows_dev)) {
         if (i8) {  // the lane kernel reads fp32 rows: int8 rows are widened first (exact: bitcontainer.cpp:202-207; 4 bytes per LLR of scratch)
             int rc = grow(d->d_f32, d->d_f32_cap, (size_t)P.rows * d->N * sizeof(float));
             if (rc) return rc;
-            HIP_TRY(pamd::launch_i8_to_f32(reinterpret_cast<const int8_t*>(P.llr), d->d_f32, (size_t)P.rows * d->N, st));
+            if (P.rowidx)  // (the list pass of "mixed": only the listed rows, each at its place in the full batch)
+                HIP_TRY(pamd::launch_i8_rows_to_f32(reinterpret_cast<const int8_t*>(P.llr), d->d_f32, P.rowidx, P.rows_dev, P.rows, d->N, st));
+            else
+                HIP_TRY(pamd::launch_i8_to_f32(reinterpret_cast<const int8_t*>(P.llr), d->d_f32, (size_t)P.rows * d->N, st));
             P.llr = d->d_f32;
         }
         return run_scl_lane(d, P, st);

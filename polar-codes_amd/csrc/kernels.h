@@ -65,6 +65,9 @@ hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned
 hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st);
 // exact widening of int8 rows (n a multiple of 4): the int8 list decoder's lane-per-path kernel reads fp32 rows
 hipError_t launch_i8_to_f32(const int8_t* in, float* out, size_t n, hipStream_t st);
+// the rows rowidx[0 .. *count) only (count in device memory, at most rows_max), each at its own place in the full batch
+hipError_t launch_i8_rows_to_f32(const int8_t* in, float* out, const uint32_t* rowidx, const uint32_t* count, uint32_t rows_max, uint32_t N,
+                                 hipStream_t st);
 hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,
                                  hipStream_t st);
 

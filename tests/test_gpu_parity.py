@@ -146,6 +146,13 @@ def test_mixed_decoder_vs_oracle(built_library):
     out, ok = d.decode_batch(llr)
     e_out, e_ok, _ = ob.decode_batch(fx.N, fx.L, fx.frozen, 24, llr, True, "mixed")
     assert np.array_equal(out, e_out) and np.array_equal(ok.astype(np.uint8), e_ok)
+    # int8 rows (decode_vector(const char*)): the SC pass reads them as they are, the list pass widens the rows it was handed
+    rows8 = np.clip(np.rint(llr * 4.0), -128, 127).astype(np.int8)
+    for B in (rows8.shape[0], 37, 1):
+        out8, ok8 = d.decode_batch(rows8[:B])
+        e_out8, e_ok8, _ = ob.decode_batch(fx.N, fx.L, fx.frozen, 24, rows8[:B].astype(np.float32), True, "mixed")
+        assert np.array_equal(out8, e_out8) and np.array_equal(ok8.astype(np.uint8), e_ok8)
+        assert 0 < int(e_ok8.sum()) or B == 1
 
 
 def test_device_pointer_path_and_ragged_batches(built_library):
