@@ -41,6 +41,18 @@ for dectype in ("float", "char"):
         ts.append(time.perf_counter() - t0)
     dt = min(ts)
     print(f"int8 rows, pageable numpy, \"{dectype}\" decoder: {B8 / dt / 1e6:.2f} M cw/s  ({B8 * N / dt / 1e9:.1f} GB/s of LLRs)")
+    try:  # the same rows resident in HBM: what the kernel alone makes of them (the ceiling of the line above)
+        import torch
+        t8 = torch.from_numpy(rows).cuda()
+        d8.decode_batch(t8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            d8.decode_batch(t8)
+        torch.cuda.synchronize()
+        print(f"    (the same rows from HBM: {3 * B8 / (time.perf_counter() - t0) / 1e6:.2f} M cw/s)")
+    except Exception as e:  # noqa: BLE001
+        print("    (device-resident run skipped:", e, ")")
 try:
     import torch
     pin = torch.from_numpy(llr).pin_memory()
