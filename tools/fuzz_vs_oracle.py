@@ -46,6 +46,9 @@ while time.time() < t_end:
     sysm = bool(rng.integers(0, 2))
     i8 = bool(rng.integers(0, 4) == 0)
     dectype = "mixed" if (L > 1 and rng.integers(0, 5) == 0) else "float"
+    if os.environ.get("FUZZ_CHAR"):  # the int8 decoders (FastSscFipChar / SclFipChar) on int8 rows (the oracle's entry takes int8-valued floats)
+        dectype = "char"
+        i8 = True
     B = int(rng.integers(1, 60 if N <= 2048 else (12 if N <= 8192 else 4)))
     mode = rng.integers(0, 3, B)
     llr = np.where(mode[:, None] == 0, rng.normal(0.5, 1.0, (B, N)) * 6.0,
