@@ -372,3 +372,35 @@ def test_pair_kernel_takes_the_trees_it_can_express(built_library, dectype):
         assert pypolar_amd.PolarDecoder(1024, 1, frozen_bits(1024, K, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] == 32
     for N in (512, 2048):                                               # other block lengths: sc_decode_kernel
         assert pypolar_amd.PolarDecoder(N, 1, frozen_bits(N, N // 2, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] == 4
+
+
+def test_code_objects_keep_the_build_contracts(built_library):
+    """Every gfx950 code object of the shipped library, unbundled and disassembled on the CPU (tools/codeobj.py):
+    (1) no long branch (s_getpc_b64 ... s_setpc_b64) through a scalar register pair that any other instruction of the kernel
+    uses -- LLVM's branch relaxation scavenges such pairs after register allocation when inline asm hides the code size, and a
+    scavenged pair may be live (sc_pair_kernel faulted that way from 2^15 rows on; `-mllvm -amdgpu-long-branch-factor`
+    reserves the pair up front); (2) the hand-allocated kernels (lane / pair: their tree lives in v[104 .. 255] behind inline
+    asm) were given all 256 VGPRs, the pair kernel all 256 AGPRs, and none of them more than a few bytes of scratch."""
+    import importlib.util
+    import pypolar_amd
+    spec = importlib.util.spec_from_file_location("codeobj", os.path.join(ROOT, "tools", "codeobj.py"))
+    codeobj = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(codeobj)
+    rows, problems = codeobj.analyse(pypolar_amd.library_path())
+    assert not problems, "\n".join(problems)
+    names = " ".join(r["kernel"] for r in rows)
+    for k in ("scl_lane_kernel", "scl_lane_char_kernel", "scl_lane_char_big_kernel", "scl_lane_big_kernel", "sc_pair_kernel", "sc_decode_kernel",
+              "scl_decode_kernel", "encode_kernel"):
+        assert k in names, k   # (the check saw the kernels it is about)
+    assert sum(r["long_branches"] for r in rows) > 0   # (... and long branches exist: the pattern match is alive)
+
+
+def test_library_exports_only_the_c_abi(built_library):
+    """`nm -D` of the shipped library: the entry points of include/polar_amd.h and nothing else (exports.map) -- no C++
+    host symbol (pamd::launch_*, pamd::compile_sc, pamd::Detector::*) can be bound to, or clash, from outside"""
+    import subprocess
+    import pypolar_amd
+    out = subprocess.run(["nm", "-D", "--defined-only", pypolar_amd.library_path()], capture_output=True, text=True, check=True).stdout
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert names and all(re.match(r"^(pcd|pce|ppu)_[a-z0-9_]+$", n) for n in names), [n for n in names if not re.match(r"^(pcd|pce|ppu)_", n)]
+    assert set(pypolar_amd.C_SYMBOLS) <= set(names)
