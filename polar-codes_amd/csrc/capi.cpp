@@ -23,6 +23,7 @@
 #include "internal.h"
 #include "kernels.h"
 #include "program.h"
+#include "scl_lane_geo.h"
 
 // Experiment switches (geometry overrides, fusion stages, ablation, verbose launch geometry) exist only in the
 // diagnostic build (`make diag`, -DPAMD_DIAG): the release library reads no environment variable at all.
@@ -76,6 +77,8 @@ struct pcd_decoder {
     // lane-per-path list kernel (scl_lane_kernel.hip): N = 1024, 4 < L <= 8, float arithmetic, fp32 rows
     pamd::Program lane_prog;
     bool has_lane = false, lane_big = false;  // lane_big: a forking leaf of 256 LLRs (the BIG instantiation of the lane kernel)
+    const pamd::LaneKernel* lane_k = nullptr;  // the lane kernel of another geometry (scl_lane_geo.h); nullptr: N = 1024, 8 lanes per codeword
+    unsigned lane_cpw = 8;                     // codewords per wave of the lane kernel
     pamd::Ins* d_lane_prog = nullptr;
     pamd::Program pair_prog;          // two-lanes-per-codeword SC kernel (sc_pair_kernel.hip)
     bool has_pair = false, pair_big = false;  // pair_big: the tree has a leaf above 128 positions (the BIG instantiations)
@@ -802,15 +805,17 @@ int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
     P.ext = d->d_ext;
     P.syn_bytes = d->d_syn_bytes;
     P.prog_len = (uint32_t)d->lane_prog.ins.size() - 1u;
-    const unsigned need = (unsigned)((P.rows + 7u) / 8u);
+    const unsigned need = (unsigned)((P.rows + d->lane_cpw - 1u) / d->lane_cpw);
     unsigned per_cu = 4;
     if (const char* e = PAMD_ENV("PCD_LANE_BLOCKS_PER_CU")) per_cu = (unsigned)std::max(1, std::min(4, std::atoi(e)));  // experiments
     const unsigned grid = std::max(1u, std::min(need, (unsigned)d->num_cu * per_cu));
-    int rc = grow(d->d_arena, d->d_arena_cap, (size_t)grid * pamd::scl_lane_arena_words() * sizeof(uint32_t));
+    const unsigned arena_words = d->lane_k ? d->lane_k->arena_words() : pamd::scl_lane_arena_words();
+    int rc = grow(d->d_arena, d->d_arena_cap, (size_t)grid * arena_words * sizeof(uint32_t));
     if (rc) return rc;
     P.arena = d->d_arena;
     const bool diag_k = P.trace != nullptr || P.cycles != nullptr || P.ablate != 0;
-    if (P.chr && d->lane_big) HIP_TRY(pamd::launch_scl_lane_char_big(P, diag_k, grid, st));
+    if (d->lane_k) HIP_TRY(d->lane_k->launch(P, diag_k, grid, st));
+    else if (P.chr && d->lane_big) HIP_TRY(pamd::launch_scl_lane_char_big(P, diag_k, grid, st));
     else if (P.chr) HIP_TRY(pamd::launch_scl_lane_char(P, diag_k, grid, st));
     else if (d->lane_big) HIP_TRY(pamd::launch_scl_lane_big(P, diag_k, grid, st));
     else HIP_TRY(pamd::launch_scl_lane(P, diag_k, grid, st));
@@ -1243,7 +1248,19 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         // (The int8 decoder SclFipChar runs on the same kernel -- saturating f / g, repetition leaves at every size, int8 rows
         //  widened to fp32 on the way in: scl_lane_char.hip --, cfg3_i8 27.4 against 23.4 M cw/s on the path groups; the same
         //  rule fits it, tools/lane_threshold.py char: 38 leaves 43.8 against 44.1, 53 leaves 38.1 against 32.8 M cw/s.)
-        if ((!chr || !PAMD_ENV("PCD_NO_CHAR_LANE")) && d->L > 4 && d->L <= 8 && !PAMD_ENV("PCD_NO_LANE")) {
+        // Round 4: the same kernel under other geometries (scl_lane_geo.h) -- N = 512 / 2048 / 4096 and 16 / 32 lanes per codeword;
+        // the default geometry keeps its rule, the others take every tree the lowering can express from 48 leaves on.
+        const bool geo_default = d->logN == 10 && d->L > 4 && d->L <= 8;
+        const pamd::LaneKernel* lk = geo_default ? nullptr : pamd::find_lane_kernel(d->logN, d->L, chr);
+        if (lk && !PAMD_ENV("PCD_NO_LANE") && (d->scl_prog.leaves >= 48u || PAMD_ENV("PCD_FORCE_LANE"))) {
+            bool big = false;
+            if (pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr, &big)) {
+                d->has_lane = true;
+                d->lane_k = lk;
+                d->lane_cpw = 64u >> lk->lcl;
+            }
+        }
+        if (geo_default && (!chr || !PAMD_ENV("PCD_NO_CHAR_LANE")) && !PAMD_ENV("PCD_NO_LANE")) {
             // (... or from 30 FORKING leaves on: the high-rate trees have few leaves, but large RateOne / SPC ones -- K = 900: 46 leaves, 35 of
             //  them forking, 35.1 against 24.9 M cw/s)
             unsigned forks = 0;
@@ -1383,9 +1400,9 @@ int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4])
     if (!d || !info) return fail(PCD_ERR_INVALID_ARG, "null argument");
     if (list) {
         if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SCL program");
-        if (d->has_lane) {  // lane-per-path kernel: 40 KB of LDS per wave of 8 codewords, 1 lane per path, 4 waves per CU
-            info[0] = 40960 / 8;
-            info[1] = 8;
+        if (d->has_lane) {  // lane-per-path kernel: 40 KB of LDS per wave of 8 (4, 2) codewords, 1 lane per path, 4 waves per CU
+            info[0] = 40960 / d->lane_cpw;
+            info[1] = d->lane_cpw;
             info[2] = 64;  // path groups per wave: every lane is one
             info[3] = 4;
             return PCD_OK;
@@ -1408,6 +1425,26 @@ int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4])
         info[2] = 1;
         info[3] = (unsigned)(kMaxLds / ((size_t)info[1] * d->sc_wave_words * 4));
     }
+    return PCD_OK;
+}
+
+int pcd_kernel_name(const pcd_decoder* d, int list, char* buf, size_t cap)
+{
+    if (!d || !buf || !cap) return fail(PCD_ERR_INVALID_ARG, "null argument");
+    const char* name;
+    if (list) {
+        if (!d->has_scl) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SCL program");
+        if (d->has_lane)
+            name = d->lane_k ? d->lane_k->name
+                             : (d->dectype == 0 ? (d->lane_big ? "scl_lane_char_big_kernel" : "scl_lane_char_kernel")
+                                                : (d->lane_big ? "scl_lane_big_kernel" : "scl_lane_kernel"));
+        else
+            name = "scl_decode_kernel";
+    } else {
+        if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
+        name = d->has_pair ? "sc_pair_kernel" : "sc_decode_kernel";
+    }
+    std::snprintf(buf, cap, "%s", name);
     return PCD_OK;
 }
 

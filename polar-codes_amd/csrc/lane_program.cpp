@@ -11,7 +11,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
     out.leaves = scl.leaves;
     out.inner = scl.inner;
     if (needs_big) *needs_big = false;
-    if (logN != 10) return false;
+    if (logN < 9 || logN > 12) return false;
     const std::vector<Ins>& v = scl.ins;
     auto put = [&](Op op, unsigned stage, unsigned side, unsigned off) {
         Ins i;
@@ -23,6 +23,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
         out.ins.push_back(i);
     };
     bool right_half = false;  // the root's G has been seen
+    bool isg_at[16] = { false };  // other block lengths: what the last op seen at stage t >= 9 was (true: a G)
     for (size_t k = 0; k < v.size(); ++k) {
         const Ins& x = v[k];
         switch (x.op) {
@@ -30,12 +31,28 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
         case SCL_F:
         case SCL_G: {
             const bool isg = x.op == SCL_G;
-            if (x.stage == logN) {  // root: must be followed by the F of its child (stage 9 is virtual)
+            if (logN != 10 && x.stage >= 9) {
+                // N = 512 / 2048 / 4096: every stage above 8 is virtual -- the op of stage 9 becomes ONE pass over the channel row
+                // that recomputes the stages in between (op_vtg); off bit l = the op at stage logN - l is a G
+                if (x.stage > logN) return false;
+                isg_at[x.stage] = isg;
+                if (x.stage > 9) {  // must be followed by the F of the stage below (no leaf above stage 8)
+                    if (k + 1 >= v.size() || v[k + 1].op != SCL_F || v[k + 1].stage + 1u != x.stage) return false;
+                    continue;
+                }
+                unsigned gm = 0;
+                for (unsigned t = 9; t <= logN; ++t)
+                    if (isg_at[t]) gm |= 1u << (logN - t);
+                if (k + 1 < v.size() && v[k + 1].op == SCL_F && v[k + 1].stage == 8) ++k;  // (the F of stage 8 is part of the pass)
+                put(LN_VT, x.stage, x.side, gm);
+                continue;
+            }
+            if (logN == 10 && x.stage == logN) {  // root: must be followed by the F of its child (stage 9 is virtual)
                 if (isg) right_half = true;
                 if (k + 1 >= v.size() || v[k + 1].op != SCL_F || v[k + 1].stage != logN - 1) return false;
                 continue;  // folded into the LN_VT emitted for that F
             }
-            if (x.stage == logN - 1) {
+            if (logN == 10 && x.stage == logN - 1) {
                 unsigned off = (right_half ? 1u : 0u) | (isg ? 2u : 0u);
                 if (k + 1 < v.size() && v[k + 1].op == SCL_F && v[k + 1].stage == logN - 2) {
                     off |= 4u;

@@ -80,6 +80,7 @@ enum Op : uint8_t {
     LN_VT = 64,    // root + its child in one pass over the channel row: stage-8 block of this path (stage 9 is never stored).
                    // off bit 0: the root's RIGHT child (g with the root's left bits), bit 1: G at stage 9 (else F),
                    // bit 2: the F of stage 8 runs on the values in registers as well (stage 7 goes to LDS)
+                   // N != 1024: ALL stages between the channel row and stage 8 in one pass; off bit l: the op at stage logN - l is a G
     LN_F,          // llr[s-1] = f(llr[s])
     LN_G,          // llr[s-1] = g(llr[s] of the path's slot owner, own left bits)
     LN_G0,         // llr[s-1] = a + b: the left child was all-frozen (no fork since the F, left bits zero)
@@ -138,7 +139,7 @@ struct Program {
 // throws; SclFip::createDecoder scl_fip_char.cpp:745-775: repetition leaves at every block length)
 std::string compile_sc(unsigned N, const std::vector<uint32_t>& frozen, Program& out, bool chr = false);
 std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program& out, bool chr = false);
-// Lowers a plain SCL program (compile_scl output: SCL_F / SCL_G / SCL_COMBINE + leaves) of a code with N = 1024 to the
+// Lowers a plain SCL program (compile_scl output: SCL_F / SCL_G / SCL_COMBINE + leaves) of a code with N = 512 .. 4096 to the
 // program of the lane-per-path kernel.  Returns false when the tree needs an op that kernel does not have (a leaf above
 // stage 8, ...): the caller then keeps the path-group kernels.
 bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr = false, bool* needs_big = nullptr);

@@ -1,0 +1,48 @@
+// The lane-per-path list kernel under its other geometries (scl_lane_kernel.hip compiled once per translation unit
+// scl_lane_n<logN>_l<lcl>[_char].hip): block length N = 2^logN, LC = 2^lcl lanes -- list positions -- per codeword, 64 / LC
+// codewords per wave.  The default geometry (N = 1024, 8 lanes: launch_scl_lane and its three siblings in kernels.h) is not
+// part of this list.  X(logN, lcl): the float decoder's kernels; Y(logN, lcl): the int8 decoder's.
+#pragma once
+#include "kernels.h"
+
+#define PAMD_LANE_GEOS(X) X(12, 5) X(10, 4) X(10, 5) X(11, 3) X(9, 3)
+#define PAMD_LANE_GEOS_CHAR(Y)
+
+namespace pamd {
+
+#define PAMD_LANE_DECL(LOGN, LCL)                                                                                    \
+    hipError_t launch_scl_lane_n##LOGN##_l##LCL(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);     \
+    unsigned scl_lane_n##LOGN##_l##LCL##_arena_words();
+#define PAMD_LANE_DECL_CHAR(LOGN, LCL)                                                                                    \
+    hipError_t launch_scl_lane_n##LOGN##_l##LCL##_char(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);   \
+    unsigned scl_lane_n##LOGN##_l##LCL##_char_arena_words();
+PAMD_LANE_GEOS(PAMD_LANE_DECL)
+PAMD_LANE_GEOS_CHAR(PAMD_LANE_DECL_CHAR)
+#undef PAMD_LANE_DECL
+#undef PAMD_LANE_DECL_CHAR
+
+struct LaneKernel {
+    unsigned logN, lcl;
+    bool chr;
+    hipError_t (*launch)(const DecodeParams&, bool, unsigned, hipStream_t);
+    unsigned (*arena_words)();
+    const char* name;
+};
+// the kernel of (logN, list size, decoder type), or nullptr: the smallest geometry whose lanes hold the list
+inline const LaneKernel* find_lane_kernel(unsigned logN, unsigned L, bool chr)
+{
+    static const LaneKernel table[] = {
+#define PAMD_LANE_ROW(LOGN, LCL) { LOGN, LCL, false, launch_scl_lane_n##LOGN##_l##LCL, scl_lane_n##LOGN##_l##LCL##_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_kernel" },
+#define PAMD_LANE_ROW_CHAR(LOGN, LCL) { LOGN, LCL, true, launch_scl_lane_n##LOGN##_l##LCL##_char, scl_lane_n##LOGN##_l##LCL##_char_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_char_kernel" },
+        PAMD_LANE_GEOS(PAMD_LANE_ROW) PAMD_LANE_GEOS_CHAR(PAMD_LANE_ROW_CHAR)
+#undef PAMD_LANE_ROW
+#undef PAMD_LANE_ROW_CHAR
+        { 0, 0, false, nullptr, nullptr, nullptr }
+    };
+    const LaneKernel* best = nullptr;
+    for (const LaneKernel* k = table; k->launch; ++k)
+        if (k->logN == logN && k->chr == chr && L <= (1u << k->lcl) && L > (1u << k->lcl) / 2 && (!best || k->lcl < best->lcl)) best = k;
+    return best;
+}
+
+}  // namespace pamd

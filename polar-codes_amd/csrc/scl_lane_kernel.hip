@@ -29,13 +29,28 @@
 // with those leaves in the one kernel cfg 3 lost 3.8 %, as a template flag of the one source still 2 % (the lean kernel came out
 // with another register allocation); guarded by the preprocessor the lean kernel's token stream is what it was.
 // LN_CHAR (scl_lane_char.hip): the int8 decoder's instantiation (CH = true), a third translation unit for the same reason.
+// LN_LOGN / LN_LCL (scl_lane_geo.hip.inc and the scl_lane_n*_l*.hip stubs, round 4): the same source for other block lengths
+// (N = 2^LN_LOGN = 512 .. 4096) and list sizes (LC = 2^LN_LCL = 8 / 16 / 32 lanes per codeword, i.e. 8 / 4 / 2 codewords per
+// wave).  Whatever the block length, the tree from stage 8 down is the one described above; the stages between the channel
+// row and stage 8 are recomputed from the row by the top-of-tree pass (N = 1024: two levels, LN_VT; otherwise LOGN - 8
+// levels, op_vtg), their partial sums live in the arena.  With the defaults (10, 3) the token stream is what it was.
 #ifndef LN_BIG
 #define LN_BIG 0
 #endif
 #ifndef LN_CHAR
 #define LN_CHAR 0
 #endif
-#if LN_BIG && LN_CHAR
+#ifndef LN_LOGN
+#define LN_LOGN 10
+#endif
+#ifndef LN_LCL
+#define LN_LCL 3
+#endif
+#define LN_GEO_DEFAULT (LN_LOGN == 10 && LN_LCL == 3)
+#if !LN_GEO_DEFAULT
+// (the stubs of the other geometries name their kernel and launcher themselves: LN_KERNEL_NAME, LN_LAUNCH_NAME)
+#define scl_lane_kernel LN_KERNEL_NAME
+#elif LN_BIG && LN_CHAR
 #define scl_lane_kernel scl_lane_char_big_kernel
 #elif LN_BIG
 #define scl_lane_kernel scl_lane_big_kernel
@@ -59,12 +74,31 @@ constexpr int RBL6 = 116, RBR6 = 118;  // stage 6: 2 words each
 constexpr int RBL7 = 120, RBR7 = 124;  // stage 7: 4 words each
 __host__ __device__ constexpr int RS(int t) { return t == 1 ? 128 : t == 2 ? 130 : t == 3 ? 134 : t == 4 ? 142 : t == 5 ? 158 : 190; }
 __host__ __device__ constexpr int RB(int side, int t) { return t <= 5 ? (side ? RBR0 : RBL0) + t : t == 6 ? (side ? RBR6 : RBL6) : (side ? RBR7 : RBL7); }
+// geometry (see the head of the file): block length, lanes per codeword, codewords per wave, bits of a slot field
+constexpr int LOGN = LN_LOGN, LCL = LN_LCL, LC = 1 << LCL, CPW = 64 / LC;
+constexpr int TOPD = LOGN - 8;                     // levels between the channel row and stage 8
+constexpr int PB = LCL + 3;                        // payload bits of a selection key: (lane of the codeword, candidate)
+constexpr uint32_t PBM = (1u << PB) - 1u;
+constexpr uint32_t PL_DEAD = LC == 8 ? 15u : 99u;  // list position of a lane that hosts no path
 // arena of one wave (32-bit words): stage-8 LLRs [64 chunks][64 lanes][4], then bit words [w][lane], then a dump area
 constexpr uint32_t AR_S8 = 0;
+#if LN_LOGN == 10
 constexpr uint32_t AR_BL9 = 64 * 64 * 4;           // 16 words: output of the root's left child
 constexpr uint32_t AR_BR9 = AR_BL9 + 16 * 64;      // 16 words: output of the root's right child
 constexpr uint32_t AR_BL8 = AR_BR9 + 16 * 64;      // 8 words
 constexpr uint32_t AR_BR8 = AR_BL8 + 8 * 64;       // 8 words
+#else
+// bits of the blocks of stage t = 8 .. LOGN - 1 (2^(t-5) words per lane and side), the highest stage first
+__host__ __device__ constexpr uint32_t ar_bitwords(int t) { return 1u << (t - 5); }
+__host__ __device__ constexpr uint32_t AR_BL(int t)
+{
+    uint32_t o = 64 * 64 * 4;
+    for (int u = LOGN - 1; u > t; --u) o += 2 * ar_bitwords(u) * 64;
+    return o;
+}
+__host__ __device__ constexpr uint32_t AR_BR(int t) { return AR_BL(t) + ar_bitwords(t) * 64; }
+constexpr uint32_t AR_BL8 = AR_BL(8), AR_BR8 = AR_BR(8);
+#endif
 constexpr uint32_t AR_DUMP = AR_BR8 + 8 * 64;      // 16 chunks x 64 lanes x 4: stage 5 / 6 leaf input, read back chunk-wise
 constexpr uint32_t AR_WORDS = AR_DUMP + 16 * 64 * 4;
 // LDS of one wave (32-bit words)
@@ -352,6 +386,7 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 // all-reduce over the 8 lanes of a codeword (DPP: lane ^ 1, lane ^ 2, then the mirrored lane of the other quad)
+#if LN_LCL == 3
 __device__ __forceinline__ uint32_t cw_min(uint32_t v)
 {
     v = umin(v, dpp_u32<0xB1>(v));
@@ -364,6 +399,34 @@ __device__ __forceinline__ uint32_t cw_add(uint32_t v)
     v += dpp_u32<0x4E>(v);
     return v + dpp_u32<0x141>(v);
 }
+#else
+// (16 lanes: + the mirrored lane of the row; 32 lanes: + the other row of the pair -- v_permlane16_swap with both operands the
+//  value hands every lane "the even row's" and "the odd row's", whose minimum / sum needs no lane predicate)
+__device__ __forceinline__ uint32_t cw_min(uint32_t v)
+{
+    v = umin(v, dpp_u32<0xB1>(v));
+    v = umin(v, dpp_u32<0x4E>(v));
+    v = umin(v, dpp_u32<0x141>(v));
+    v = umin(v, dpp_u32<0x140>(v));
+    if constexpr (LC > 16) {
+        const auto s = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        v = umin(s[0], s[1]);
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t cw_add(uint32_t v)
+{
+    v += dpp_u32<0xB1>(v);
+    v += dpp_u32<0x4E>(v);
+    v += dpp_u32<0x141>(v);
+    v += dpp_u32<0x140>(v);
+    if constexpr (LC > 16) {
+        const auto s = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        v = s[0] + s[1];
+    }
+    return v;
+}
+#endif
 
 // diagnostics: cycle stamp k (0 .. 3) of the instruction being profiled (sub: nullptr in the production kernel)
 struct Stamps {
@@ -380,6 +443,7 @@ struct Stamps {
 };
 
 // per-lane state the compiler keeps (everything else lives in the hand-allocated registers)
+#if LN_GEO_DEFAULT
 struct Path {
     float metric;
     uint32_t slot;   // 3-bit fields, stage t at bit 3 * (t - 2), t = 2 .. 10
@@ -398,7 +462,56 @@ struct Path {
         const uint32_t sh = 3u * (t - 2u);
         slot = (slot & ~(7u << sh)) | ((uint32_t)q << sh);
     }
+    __device__ __forceinline__ void reset_slots() { slot = (uint32_t)q * 0x01249249u; }  // every field = own lane
+    __device__ __forceinline__ void take_slots(uint32_t src) { slot = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)slot); }
 };
+#else
+// Other geometries: fields of LCL bits; the stages 2 .. 7 in `slot`, the stages 8 .. LOGN in `slot2` (up to 5 x 5 bits each way)
+struct Path {
+    float metric;
+    uint32_t slot, slot2;
+    uint32_t pl;     // position in the reference's path list; >= P: not a live path
+    uint32_t P;      // live paths per codeword (wave uniform)
+    uint32_t L;
+    int lane, q, g0;
+    uint32_t self4;  // lane * 4 (ds_bpermute address of the own lane)
+    uint32_t* lds;   // this wave's LDS
+    float c127, m128;  // int8 decoder: 127.0 (used as a scalar operand) and -128.0 (kept in a VGPR)
+    uint32_t* arena; // this wave's arena slice
+    static constexpr uint32_t FM = (uint32_t)LC - 1u;
+    __device__ __forceinline__ uint32_t owner(uint32_t t) const
+    {
+        return (uint32_t)g0 | (((t >= 8u ? slot2 : slot) >> ((uint32_t)LCL * (t >= 8u ? t - 8u : t - 2u))) & FM);
+    }
+    __device__ __forceinline__ void set_field(uint32_t t)
+    {
+        if (t < 2u) return;  // (stage 1 is never an inner node: nothing is ever looked up for it)
+        if (t >= 8u) {
+            const uint32_t sh = (uint32_t)LCL * (t - 8u);
+            slot2 = (slot2 & ~(FM << sh)) | ((uint32_t)q << sh);
+        } else {
+            const uint32_t sh = (uint32_t)LCL * (t - 2u);
+            slot = (slot & ~(FM << sh)) | ((uint32_t)q << sh);
+        }
+    }
+    static constexpr uint32_t ones(int n)
+    {
+        uint32_t o = 0;
+        for (int i = 0; i < n; ++i) o |= 1u << (LCL * i);
+        return o;
+    }
+    __device__ __forceinline__ void reset_slots()
+    {
+        slot = (uint32_t)q * ones(6);
+        slot2 = (uint32_t)q * ones(LOGN - 7);
+    }
+    __device__ __forceinline__ void take_slots(uint32_t src)
+    {
+        slot = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)slot);
+        slot2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)slot2);
+    }
+};
+#endif
 
 // ---- findWeakLlrs (arrayfuncs.h:209-231) for one path --------------------------------------------------------------
 // The reference runs a swap-mutating selection: iteration i takes the first minimum among positions >= i and swaps it
@@ -588,7 +701,7 @@ __device__ __forceinline__ uint32_t select_literal(const Path& p, const float (&
 {
     constexpr uint32_t INF = 0xFFFFFFFFu;
     const bool live = p.pl < p.P;
-    const uint32_t cwbase = SCR_SEL + (uint32_t)(p.lane >> 3) * 8u;  // ranks [codeword][8]
+    const uint32_t cwbase = SCR_SEL + (uint32_t)(p.lane >> LCL) * (uint32_t)LC;  // ranks [codeword][LC]
     const uint32_t dummy = SCR_SEL + 64u + (uint32_t)p.lane;          // where the losers post
     uint32_t pos[C], key[C], rec[C];
 #pragma unroll
@@ -630,9 +743,9 @@ __device__ __forceinline__ uint32_t select_literal(const Path& p, const float (&
 template <int C>
 __device__ __forceinline__ uint32_t array_pos(uint32_t key)
 {
-    if constexpr (C == 8) return key & 63u;
-    else if constexpr (C == 4) return ((key >> 1) & 0x1Cu) | (key & 3u);
-    else return ((key >> 2) & 0xEu) | (key & 1u);
+    if constexpr (C == 8) return key & PBM;
+    else if constexpr (C == 4) return ((key >> 1) & (PBM >> 1 & ~3u)) | (key & 3u);
+    else return ((key >> 2) & (PBM >> 2 & ~1u)) | (key & 1u);
 }
 
 // The same emulation over the candidates that can win a round, at most two per lane: the one the merge ranked q (lane q
@@ -643,26 +756,26 @@ template <int C>
 __device__ __forceinline__ uint32_t select_chosen(const Path& p, uint32_t key, uint32_t at, bool seated, uint32_t np, uint32_t zkey)
 {
     constexpr uint32_t INF = 0xFFFFFFFFu;
-    const uint32_t cwbase = SCR_SEL + (uint32_t)(p.lane >> 3) * 8u;
+    const uint32_t cwbase = SCR_SEL + (uint32_t)(p.lane >> LCL) * (uint32_t)LC;
     uint32_t rec = SCR_SEL + 64u + (uint32_t)p.lane, zrec = rec;
-    uint32_t comb = seated ? ((key & ~63u) | at) : INF;
-    uint32_t zcomb = zkey != INF ? ((zkey & ~63u) | array_pos<C>(zkey)) : INF;
+    uint32_t comb = seated ? ((key & ~PBM) | at) : INF;
+    uint32_t zcomb = zkey != INF ? ((zkey & ~PBM) | array_pos<C>(zkey)) : INF;
     const uint32_t rounds = (uint32_t)__builtin_amdgcn_readfirstlane((int)np);  // (np is the same in every lane)
 #pragma unroll 1
     for (uint32_t i = 0; i < rounds; ++i) {
         {
             const uint32_t g = cw_min(umin(comb, zcomb));
-            const uint32_t gp = g & 63u;
+            const uint32_t gp = g & PBM;
             const bool win = comb == g, zwin = zcomb == g;
-            const bool at_i = (comb & 63u) == (uint32_t)i, zat_i = (zcomb & 63u) == (uint32_t)i;
+            const bool at_i = (comb & PBM) == (uint32_t)i, zat_i = (zcomb & PBM) == (uint32_t)i;
             rec = win ? cwbase + (uint32_t)i : rec;
             zrec = zwin ? cwbase + (uint32_t)i : zrec;
-            comb = win ? INF : (at_i ? ((comb & ~63u) | gp) : comb);
-            zcomb = zwin ? INF : (zat_i ? ((zcomb & ~63u) | gp) : zcomb);
+            comb = win ? INF : (at_i ? ((comb & ~PBM) | gp) : comb);
+            zcomb = zwin ? INF : (zat_i ? ((zcomb & ~PBM) | gp) : zcomb);
         }
     }
-    p.lds[zrec] = zkey & 63u;  // (a loser posts at the lane's spare word -- first, so that a winner of the same lane overwrites nothing)
-    p.lds[rec] = key & 63u;
+    p.lds[zrec] = zkey & PBM;  // (a loser posts at the lane's spare word -- first, so that a winner of the same lane overwrites nothing)
+    p.lds[rec] = key & PBM;
     return p.lds[cwbase + (uint32_t)p.q];
 }
 
@@ -675,6 +788,7 @@ __device__ __forceinline__ uint32_t pick8(const uint32_t (&k)[8], uint32_t q)
     return b2 ? c1 : c0;
 }
 
+#if LN_LCL == 3
 // Chooses the np = min(L, P * C) best candidates of every codeword and re-seats the paths BY RANK: lane q of the codeword
 // hosts the path at position q of the reference's list afterwards (p.pl == q for the np live lanes; what a path owns is
 // found through its slot word, so a path changes lanes at the price of one ds_bpermute), taken from lane `src`
@@ -775,12 +889,172 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     cand = mykey & 7u;
     // the path's state: metric from the scratch, slot word from the source lane
     const float nm = reinterpret_cast<const float*>(p.lds + SCR_CM)[src * 8 + cand];
+#if LN_GEO_DEFAULT
     const uint32_t nslot = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)p.slot);
     p.metric = seated ? nm : p.metric;
     p.slot = nslot;
+#else
+    p.take_slots(src);  // (both slot words)
+    p.metric = seated ? nm : p.metric;
+#endif
     p.pl = seated ? (uint32_t)p.q : 15u;
     p.P = np;
 }
+#else
+// ---- the same for 16 / 32 lanes per codeword (list sizes up to 16 / 32) ---------------------------------------------------
+// The np <= LC best candidates no longer fit one lane's eight registers: W = LC / 8 neighbouring lanes hold the sorted list
+// together, lane j of such a group the ranks 8 j .. 8 j + 7.  (A) the lanes of a group sort their 8 W candidates among
+// themselves (bitonic merges: partner's list reversed, the lower lane keeps the minima, the upper one the maxima); (B) groups
+// merge pairwise, both keeping the LC smallest -- min(X[m], Y[LC - 1 - m]) is a bitonic sequence that holds exactly those --,
+// then clean it up among their lanes; after log2(LC / W) such levels every group of the codeword holds the same sorted list.
+// Partners: a group's mirror image inside 4 / 8 / 16 lanes (quad_perm [3,2,1,0], row_half_mirror, row_mirror) is "the other
+// group, lanes reversed", which is what the reversed list needs; across the two rows of a 32-lane codeword ds_swizzle
+// (lane ^ 0x13).  The sorted list then goes to the LDS (ranks [codeword][LC]), lane q reads entry q: seats by rank as above.
+template <int CTRL>
+__device__ __forceinline__ void cross_rev_minmax(uint32_t (&k)[8], bool low)
+{
+    uint32_t b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = dpp_u32<CTRL>(k[7 - i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = low ? umin(k[i], b[i]) : umax(k[i], b[i]);
+}
+template <int CTRL>
+__device__ __forceinline__ void cross_minmax(uint32_t (&k)[8], bool low)
+{
+    uint32_t b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = dpp_u32<CTRL>(k[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = low ? umin(k[i], b[i]) : umax(k[i], b[i]);
+}
+// both groups keep the LC smallest of their two sorted lists (as a bitonic sequence)
+template <int CTRL>
+__device__ __forceinline__ void cross_rev_min(uint32_t (&k)[8])
+{
+    uint32_t b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if constexpr (CTRL == 0) b[i] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)k[7 - i], 0x4C1F);  // lane ^ 0x13 (bit mode: and 0x1F, xor 0x13)
+        else b[i] = dpp_u32<CTRL>(k[7 - i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = umin(k[i], b[i]);
+}
+// a bitonic sequence of 8 W keys over the W lanes of a group -> ascending
+__device__ __forceinline__ void group_clean(uint32_t (&k)[8], int lane)
+{
+    if constexpr (LC == 32) cross_minmax<0x4E>(k, (lane & 2) == 0);
+    cross_minmax<0xB1>(k, (lane & 1) == 0);
+    bitonic_clean<8>(k);
+}
+template <int C>
+__device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint32_t& src, uint32_t& cand, const Stamps& sm)
+{
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+    const bool live = p.pl < p.P;
+    const uint32_t np = (p.P * (uint32_t)C < p.L) ? p.P * (uint32_t)C : p.L;
+    // the candidates' exact metrics go to the scratch: the new host of a path reads the one it was given
+    {
+        float* scm = reinterpret_cast<float*>(p.lds + SCR_CM + p.lane * 8);
+        if constexpr (C == 8) {
+            reinterpret_cast<float4*>(scm)[0] = make_float4(cm[0], cm[1], cm[2], cm[3]);
+            reinterpret_cast<float4*>(scm)[1] = make_float4(cm[4], cm[5], cm[6], cm[7]);
+        } else if constexpr (C == 4) {
+            reinterpret_cast<float4*>(scm)[0] = make_float4(cm[0], cm[1], cm[2], cm[3]);
+        } else {
+            reinterpret_cast<float2*>(scm)[0] = make_float2(cm[0], cm[1]);
+        }
+    }
+    const uint32_t qc = live ? ((uint32_t)p.q << 3) : INF;  // (dead lanes: every key becomes INF)
+    uint32_t k[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) k[c] = c < C ? ((fbits(cm[c < C ? c : 0]) & ~PBM) | qc | (uint32_t)c) : INF;
+    if constexpr (C == 2) cex(k[0], k[1]);
+    if constexpr (C == 8) cex(k[3], k[4]);
+    uint32_t own[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) own[c] = k[c];
+    // (A) the W lanes of a group sort their candidates
+    cross_rev_minmax<0xB1>(k, (p.lane & 1) == 0);
+    bitonic_clean<8>(k);
+    if constexpr (LC == 32) {
+        cross_rev_minmax<0x1B>(k, (p.lane & 2) == 0);
+        cross_minmax<0xB1>(k, (p.lane & 1) == 0);
+        bitonic_clean<8>(k);
+    }
+    // (B) groups merge pairwise
+    if constexpr (LC == 16) {
+        cross_rev_min<0x1B>(k);
+        group_clean(k, p.lane);
+        cross_rev_min<0x141>(k);
+        group_clean(k, p.lane);
+        cross_rev_min<0x140>(k);
+        group_clean(k, p.lane);
+    } else {
+        cross_rev_min<0x141>(k);
+        group_clean(k, p.lane);
+        cross_rev_min<0x140>(k);
+        group_clean(k, p.lane);
+        cross_rev_min<0>(k);
+        group_clean(k, p.lane);
+    }
+    // the sorted list of the codeword: ranks [codeword][LC] in the scratch, written by the first group
+    const uint32_t cwbase = SCR_SEL + (uint32_t)(p.lane >> LCL) * (uint32_t)LC;
+    if ((uint32_t)p.q < (uint32_t)(LC / 8)) {
+        uint4* t = reinterpret_cast<uint4*>(p.lds + cwbase + (uint32_t)p.q * 8u);
+        t[0] = make_uint4(k[0], k[1], k[2], k[3]);
+        t[1] = make_uint4(k[4], k[5], k[6], k[7]);
+    }
+    const uint32_t q = (uint32_t)p.q;
+    uint32_t mykey = p.lds[cwbase + q];
+    const uint32_t kcut = p.lds[cwbase + np - 1u];
+    const uint32_t next = p.lds[cwbase + (q + 1u < (uint32_t)LC ? q + 1u : q)], prev = p.lds[cwbase + (q > 0u ? q - 1u : 0u)];
+    // exactness: neighbours among the np chosen differ above the payload bits, and nobody outside them is at or below
+    // the last one (nme = number of this lane's candidates at or below it).
+    const bool near = (q + 1u < np) && ((mykey ^ next) <= PBM);
+    const uint32_t kcm = kcut | PBM;  // (own <= kcm <=> own >> PB <= kcut >> PB; INF stays above every valid key)
+    uint32_t nme = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) nme += (own[c] <= kcm) ? 1u : 0u;
+    const bool cut_tie = cw_add(nme) != np;
+    const bool seated = q < np;
+    if (ballot64(near || cut_tie) != 0) {  // (wave uniform; rare on real-valued input)
+        // Equal metrics: see the 8-lane form above.
+        uint32_t low = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) low |= fbits(cm[c]);
+        const bool equal = (q > 0u && (mykey ^ prev) <= PBM) || (q + 1u < np && (mykey ^ next) <= PBM) || (cut_tie && (mykey | PBM) == kcm);
+        const uint32_t at = array_pos<C>(mykey);
+        const bool moved = seated && equal && at < q;
+        bool all = live && (low & PBM) != 0u;  // (keys that are not the whole metric: the emulation over all candidates)
+        if (ballot64(moved || all) != 0) {
+            uint32_t zkey = INF;
+            if (ballot64(cut_tie) != 0) {  // candidates left out at the cut
+                uint32_t nz = 0;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const bool z = (own[c] | PBM) == kcm && own[c] > kcut;
+                    zkey = umin(zkey, z ? own[c] : INF);
+                    nz += z ? 1u : 0u;
+                }
+                all = all || nz > 1u;
+            }
+            if (ballot64(all) != 0) mykey = select_literal<C>(p, cm, np);
+            else mykey = select_chosen<C>(p, mykey, at, seated, np, zkey);
+        }
+    }
+    sm.mark(2);
+    src = seated ? ((uint32_t)p.g0 | ((mykey >> 3) & (uint32_t)(LC - 1))) : (uint32_t)p.lane;
+    cand = mykey & 7u;
+    // the path's state: metric from the scratch, slot words from the source lane
+    const float nm = reinterpret_cast<const float*>(p.lds + SCR_CM)[src * 8 + cand];
+    p.take_slots(src);
+    p.metric = seated ? nm : p.metric;
+    p.pl = seated ? (uint32_t)p.q : PL_DEAD;
+    p.P = np;
+}
+#endif
 
 // ---- leaves ---------------------------------------------------------------------------------------------------------------
 // sum of v over the block in the reference's order: 8 strided accumulators (acc[j] += x[8k + j], k ascending), then
@@ -1176,7 +1450,9 @@ __device__ __forceinline__ void op_combine(Path& p, uint32_t side)
         const uint32_t r0 = rdu<RBR7>(), r1 = rdu<RBR7 + 1>(), r2 = rdu<RBR7 + 2>(), r3 = rdu<RBR7 + 3>();
         const uint32_t w[8] = { l0 ^ r0, l1 ^ r1, l2 ^ r2, l3 ^ r3, r0, r1, r2, r3 };
         put_bits<8>(p, side, w);
-    } else {  // T == 9: 8 + 8 words from the arena -> 16 words to the arena
+    } else {
+#if LN_LOGN == 10
+        // T == 9: 8 + 8 words from the arena -> 16 words to the arena
         const uint32_t* lp = p.arena + AR_BL8 + p.owner(9);
         const uint32_t* rp = p.arena + AR_BR8 + p.lane;
         uint32_t* o = p.arena + (side ? AR_BR9 : AR_BL9) + p.lane;
@@ -1191,9 +1467,35 @@ __device__ __forceinline__ void op_combine(Path& p, uint32_t side)
             o[i * 64] = l[i] ^ r[i];
             o[(8 + i) * 64] = r[i];
         }
+#else
+        // T = 9 .. LOGN - 1: 2^(T-6) + 2^(T-6) words from the arena -> 2^(T-5) words to the arena, eight at a time
+        constexpr uint32_t NW = ar_bitwords(T - 1);
+        // (opaque: otherwise the compiler precomputes one 64-bit address per word and block at the head of the kernel and
+        //  keeps -- spills -- them all)
+        uint32_t ln = (uint32_t)p.lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t* lp = p.arena + AR_BL(T - 1) + p.owner(T);
+        const uint32_t* rp = p.arena + AR_BR(T - 1) + ln;
+        uint32_t* o = p.arena + (side ? AR_BR(T) : AR_BL(T)) + ln;
+#pragma unroll 1
+        for (uint32_t i0 = 0; i0 < NW; i0 += 8) {
+            uint32_t l[8], r[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                l[i] = lp[(i0 + i) * 64];
+                r[i] = rp[(i0 + i) * 64];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                o[(i0 + i) * 64] = l[i] ^ r[i];
+                o[(NW + i0 + i) * 64] = r[i];
+            }
+        }
+#endif
     }
 }
 
+#if LN_LOGN == 10
 // ---- the top of the tree -------------------------------------------------------------------------------------------------
 // LN_VT: the stage-8 block of this path from the channel row (stage 9 = f / g of the row is never stored), optionally
 // with the F of stage 8 on the values in registers.  Element e of stage 8 needs the row at e, e + 256, e + 512, e + 768.
@@ -1386,6 +1688,7 @@ __device__ __forceinline__ void op_vt_t(Path& p, const float* chan, uint32_t abs
     if (F8) p.set_field(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#if LN_LCL == 3
 // The first pass of a codeword (F of the root, F of its left child): one live path, whose lane would do 32 steps while
 // the other seven of the codeword idle.  The steps do not depend on the path, so lane q does the steps j = q, q + 8,
 // q + 16, q + 24 and stores into the column of the codeword's first lane, where the path lives.
@@ -1412,6 +1715,27 @@ __device__ __forceinline__ void op_vt_first(Path& p, const float* chan, uint32_t
     p.set_field(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#else
+// (16 / 32 lanes per codeword: lane q does the steps j = q, q + LC, ... < 32)
+template <bool CH>
+__device__ __forceinline__ void op_vt_first(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
+{
+    const uint32_t* s8base = p.arena + AR_S8;
+    const uint32_t s8off = (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
+    const uint32_t s7addr = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
+    const float* rowp = chan + 4 * p.q;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vt_load<VT_SET0>(rowp);
+    if constexpr (LC == 16) vt_load<VT_SET1>(rowp + 64);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vt_step<VT_SET0, false, false, true, CH>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off, s8base, s7addr, p.c127, p.m128);
+    if constexpr (LC == 16)
+        vt_step<VT_SET1, false, false, true, CH>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 16384u, s8base, s7addr + 16384u, p.c127, p.m128);
+    p.set_field(8);
+    p.set_field(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#endif
 template <bool CH>
 __device__ __forceinline__ void op_vt(Path& p, uint32_t off, const float* chan, uint32_t absmask, uint32_t signmask)
 {
@@ -1427,6 +1751,233 @@ __device__ __forceinline__ void op_vt(Path& p, uint32_t off, const float* chan, 
     default: op_vt_t<true, true, true, CH>(p, chan, absmask, signmask); break;
     }
 }
+
+#endif  // LN_LOGN == 10
+#if LN_LOGN != 10
+// ---- the top of the tree at other block lengths: LV = LOGN - 8 levels between the channel row and stage 8 --------------------
+// One step = ONE 16-byte chunk c of the path's stage-8 block (elements 4 c .. 4 c + 3): the 2^LV row chunks it depends on
+// (row[4 c + 256 k ..], k < 2^LV) are loaded into one register set and folded in place, level by level -- level l (0 = the
+// channel row's own f / g) pairs chunk k with chunk k + 2^(LV-1-l) --, f or g per level as the instruction's mask says (wave
+// uniform), the g's steered by the left-child bits of that level's node (arena, column of the slot owner; one word per block
+// and eight steps, bit 4 (c & 7) + i of it for element i: the shift amounts travel as scalar operands).  The result goes to
+// the arena; the F of stage 8 pairs chunk c with chunk c + 32: the chunks c < 32 are parked in the LDS slot of stage-7 chunk
+// c (the same 16 bytes per lane), the step of chunk c + 32 reads the slot back (into v[104 .. 107]: the bit registers of the
+// stages <= 7 are dead during this op), and leaves f there.  NS register sets of 4 * 2^LV registers from v128 on: the loads of
+// step c + NS - 1 are issued in front of step c.
+#define LN_VGS(D_, B_, W_)                                        \
+    "v_lshlrev_b32 %[t0], %[s0], " W_ "\n\t"                     \
+    "v_lshlrev_b32 %[t1], %[s1], " W_ "\n\t"                     \
+    "v_lshlrev_b32 %[t2], %[s2], " W_ "\n\t"                     \
+    "v_lshlrev_b32 %[t3], %[s3], " W_ "\n\t"                     \
+    "v_and_or_b32 %[t0], %[t0], %[sm], 1.0\n\t"                  \
+    "v_and_or_b32 %[t1], %[t1], %[sm], 1.0\n\t"                  \
+    "v_and_or_b32 %[t2], %[t2], %[sm], 1.0\n\t"                  \
+    "v_and_or_b32 %[t3], %[t3], %[sm], 1.0\n\t"                  \
+    "v_fma_f32 v[" D_ "], v[" D_ "], %[t0], v[" B_ "]\n\t"       \
+    "v_fma_f32 v[" D_ "+1], v[" D_ "+1], %[t1], v[" B_ "+1]\n\t" \
+    "v_fma_f32 v[" D_ "+2], v[" D_ "+2], %[t2], v[" B_ "+2]\n\t" \
+    "v_fma_f32 v[" D_ "+3], v[" D_ "+3], %[t3], v[" B_ "+3]"
+constexpr int VTG_H = 104;  // v[104 .. 107]: the parked stage-8 chunk of the second half's steps
+constexpr int VTG_W = 108;  // v[108 .. 122]: the bit words of the current group of eight steps (word i of the op: v[108 + i])
+constexpr int VTG_A = 240;  // a[240 .. 254]: the words of the NEXT group land here (the compiler's spills stay below a104)
+template <int LV>
+struct VtgGeo {
+    static constexpr int NR = 1 << LV;                         // row chunks per step
+    static constexpr int NS = LV >= 4 ? 2 : (LV == 3 ? 4 : 8);  // register sets
+    static constexpr int SW = 4 * NR;                          // registers per set
+    static constexpr int NWD = NR - 1;                         // bit words per group of eight steps (all levels)
+    __host__ __device__ static constexpr int wbase(int l) { return NR - (NR >> l); }  // first word of level l
+};
+// the 2^LV row chunks of one step: base = the row at element 4 c
+template <int S, int LV>
+__device__ __forceinline__ void vtg_load(const float* base)
+{
+    static_for<(1 << LV)>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        const float* pm = base + 1024 * (k >> 2);
+        asm volatile("global_load_dwordx4 v[%0:%0+3], %1, off offset:%2" ::"n"(S + 4 * k), "v"(pm), "n"((k & 3) * 1024) : "memory");
+    });
+}
+// the levels of one step on set S, in place: the stage-8 chunk ends up in v[S .. S + 3].  gm bit l: level l is a g (its
+// words: v[VTG_W + wbase(l) + k]), sh = 31 - 4 (c & 7)
+template <int S, int LV, bool CH>
+__device__ __forceinline__ void vtg_levels(uint32_t gm, uint32_t sh, uint32_t absmask, uint32_t signmask, float c127, float m128)
+{
+    using G = VtgGeo<LV>;
+    uint32_t s0 = sh, s1 = sh - 1u, s2 = sh - 2u, s3 = sh - 3u;  // (not const: a const local is not captured by the lambdas' asm operands)
+    uint32_t am = absmask, sm = signmask;
+    float cc = c127, mm = m128;
+    static_for<LV>([&](auto Lc) {
+        constexpr int l = decltype(Lc)::value;
+        constexpr int NB = 1 << (LV - 1 - l);
+        if (gm & (1u << l)) {
+            static_for<NB>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                uint32_t t0, t1, t2, t3;
+                const uint32_t q0 = s0, q1 = s1, q2 = s2, q3 = s3, qm = sm;  // (copies: the asm operands of a nested lambda do not capture)
+                asm volatile(LN_VGS("%[d]", "%[b]", "v[%[w]]")
+                             : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                             : [d] "n"(S + 4 * k), [b] "n"(S + 4 * (k + NB)), [w] "n"(VTG_W + G::wbase(l) + k), [s0] "s"(q0), [s1] "s"(q1), [s2] "s"(q2),
+                               [s3] "s"(q3), [sm] "s"(qm));
+            });
+            if constexpr (CH) clamp_g<S, 4 * NB>(cc, mm);
+        } else {
+            static_for<NB>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                uint32_t t0, t1, t2, t3;
+                const uint32_t qa = am;
+                asm volatile(LN_F4T("%[d]", "%[d]", "%[b]")
+                             : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                             : [d] "n"(S + 4 * k), [b] "n"(S + 4 * (k + NB)), [am] "s"(qa));
+            });
+            if constexpr (CH) clamp_f<S, 4 * NB>(cc, am);
+        }
+    });
+}
+// what a step does with its chunk.  First half (chunks c < 32): to the arena and into the LDS slot of stage-7 chunk c.
+template <int S>
+__device__ __forceinline__ void vtg_tail_first(uint32_t s8off, const uint32_t* s8base, uint32_t s7addr)
+{
+    asm volatile("s_nop 0\n\t"
+                 "global_store_dwordx4 %[o], v[%[r]:%[r]+3], %[sb]\n\t"
+                 "ds_write_b128 %[la], v[%[r]:%[r]+3]"
+                 :
+                 : [r] "n"(S), [o] "v"(s8off), [sb] "s"(s8base), [la] "v"(s7addr)
+                 : "memory");
+}
+// Second half (chunk c + 32, its partner c parked in v[104 .. 107] by vtg_fetch_parked): to the arena, f of the two to the LDS slot
+template <int S, bool CH>
+__device__ __forceinline__ void vtg_tail_second(uint32_t s8off, const uint32_t* s8base, uint32_t s7addr, uint32_t absmask, float c127)
+{
+    uint32_t t0, t1, t2, t3;
+    asm volatile("s_nop 0\n\t"
+                 "global_store_dwordx4 %[o], v[%[r]:%[r]+3], %[sb]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t" LN_F4T("%[h]", "%[h]", "%[r]")
+                 : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [r] "n"(S), [h] "n"(VTG_H), [o] "v"(s8off), [sb] "s"(s8base), [am] "s"(absmask)
+                 : "memory");
+    if constexpr (CH) clamp_f<VTG_H, 4>(c127, absmask);
+    asm volatile("s_nop 0\n\tds_write_b128 %[la], v[%[h]:%[h]+3]" ::[h] "n"(VTG_H), [la] "v"(s7addr) : "memory");
+}
+__device__ __forceinline__ void vtg_fetch_parked(uint32_t s7addr)
+{
+    asm volatile("ds_read_b128 v[%[h]:%[h]+3], %[la]" ::[h] "n"(VTG_H), [la] "v"(s7addr) : "memory");
+}
+// The bit words of one group of eight steps (g = 0 .. 7) are requested into a[VTG_A ..]: for every g level l the words g + 8 k
+// of its node's left-child block (bo[l]: byte offset of that block in the column of the slot owner, relative to the wave's
+// arena).  They are older than every row chunk of the group's later steps, so the steps' counted waits cover them.
+template <int LV>
+__device__ __forceinline__ void vtg_words_issue(uint32_t gm, const uint32_t (&bo)[LV], uint32_t g, const uint32_t* abase)
+{
+    using G = VtgGeo<LV>;
+    static_for<LV>([&](auto Lc) {
+        constexpr int l = decltype(Lc)::value;
+        constexpr int NB = 1 << (LV - 1 - l);
+        if (gm & (1u << l)) {
+            const uint32_t o = bo[l] + g * 256u;
+            const uint32_t* ab = abase;
+            static_for<NB>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                // word g + 8 k of the block: 8 k words = 2048 k bytes further on in the lane's column
+                const uint32_t ok = o + 4096u * (uint32_t)(k >> 1);
+                const uint32_t* qb = ab;
+                asm volatile("global_load_dword a[%0], %1, %2 offset:%3" ::"n"(VTG_A + G::wbase(l) + k), "v"(ok), "s"(qb), "n"((k & 1) * 2048) : "memory");
+            });
+        }
+    });
+}
+// ... and moved to v[VTG_W ..] when their group starts (all of them: a word of an f level is never looked at)
+template <int LV>
+__device__ __forceinline__ void vtg_words_take()
+{
+    static_for<(1 << LV) - 1>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        asm volatile("v_accvgpr_read_b32 v[%0], a[%1]" ::"n"(VTG_W + i), "n"(VTG_A + i));
+    });
+}
+template <int LV, bool CH>
+__device__ __forceinline__ void op_vtg_t(Path& p, uint32_t gm, const float* chan, uint32_t absmask, uint32_t signmask)
+{
+    using G = VtgGeo<LV>;
+    constexpr int NS = G::NS, SW = G::SW;
+    // the g that has just been executed is the one at the lowest stage: its left child's bits are this lane's own
+    if (gm) p.set_field((uint32_t)LOGN - (31u - (uint32_t)__builtin_clz(gm)));
+    uint32_t bo[LV];
+    static_for<LV>([&](auto Lc) {
+        constexpr int l = decltype(Lc)::value;
+        bo[l] = 4u * (AR_BL(LOGN - l - 1) + p.owner((uint32_t)(LOGN - l)));
+    });
+    const uint32_t* abase = p.arena;
+    const uint32_t* s8base = p.arena + AR_S8;
+    const uint32_t s8col = (uint32_t)p.lane * 16u;  // byte offset of chunk 0 of this lane's column (chunk c: + 1024 c)
+    const uint32_t s7col = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.lane * 16u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing older in flight: the counted waits below see only this op's accesses)
+    vtg_words_issue<LV>(gm, bo, 0, abase);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float* const rowlast = chan + 4 * 63;
+    static_for<NS - 1>([&](auto J) { vtg_load<128 + SW * decltype(J)::value, LV>(chan + 4 * decltype(J)::value); });
+    const float* rowp = chan + 4 * (NS - 1);  // the row at the chunk of the next step to be loaded
+#pragma unroll 1
+    for (uint32_t g = 0; g < 8; ++g) {
+        vtg_words_take<LV>();
+        // the words of the next group are requested now and are long there when it starts
+        vtg_words_issue<LV>(gm, bo, g < 7u ? g + 1u : 7u, abase);
+        const bool second = g >= 4u;
+#pragma unroll 1
+        for (uint32_t i = 0; i < 8; i += NS) {
+            static_for<NS>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const uint32_t c = 8u * g + i + (uint32_t)j;
+                if (second) vtg_fetch_parked(s7col + 1024u * (c - 32u));
+                vtg_load<128 + SW * ((j + NS - 1) % NS), LV>(rowp < rowlast ? rowp : rowlast);
+                rowp += 4;
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * G::NR) : "memory");
+                vtg_levels<128 + SW * j, LV, CH>(gm, 31u - 4u * ((i + (uint32_t)j) & 7u), absmask, signmask, p.c127, p.m128);
+                if (second) vtg_tail_second<128 + SW * j, CH>(s8col + 1024u * c, s8base, s7col + 1024u * (c - 32u), absmask, p.c127);
+                else vtg_tail_first<128 + SW * j>(s8col + 1024u * c, s8base, s7col + 1024u * c);
+            });
+        }
+    }
+    p.set_field(8);
+    p.set_field(7);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// The first pass of a codeword (every level an f): one live path, whose lane would do 64 steps while the others of the
+// codeword idle.  The steps do not depend on the path: lane q does the chunks c = q, q + LC, ... < 32 and their partners
+// c + 32, and stores into the column of the codeword's first lane, where the path lives.  (Not pipelined: a handful of
+// steps per lane, once per codeword.)
+template <int LV, bool CH>
+__device__ __forceinline__ void op_vtg_first(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
+{
+    const uint32_t* s8base = p.arena + AR_S8;
+    const uint32_t s8col = (uint32_t)p.g0 * 16u, s7col = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (uint32_t c = (uint32_t)p.q; c < 32u; c += (uint32_t)LC) {
+        vtg_load<128, LV>(chan + 4 * c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vtg_levels<128, LV, CH>(0u, 31u, absmask, signmask, p.c127, p.m128);
+        vtg_tail_first<128>(s8col + 1024u * c, s8base, s7col + 1024u * c);
+        vtg_fetch_parked(s7col + 1024u * c);
+        vtg_load<128, LV>(chan + 4 * (c + 32u));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vtg_levels<128, LV, CH>(0u, 31u, absmask, signmask, p.c127, p.m128);
+        vtg_tail_second<128, CH>(s8col + 1024u * (c + 32u), s8base, s7col + 1024u * c, absmask, p.c127);
+    }
+    p.set_field(8);
+    p.set_field(7);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// off: bit l = level l (0 = the channel row's own f / g, i.e. the op of the root) is a g
+template <bool CH>
+__device__ __forceinline__ void op_vtg(Path& p, uint32_t off, const float* chan, uint32_t absmask, uint32_t signmask)
+{
+    const uint32_t gm = off & ((1u << TOPD) - 1u);
+    if (gm == 0u && p.P == 1u) op_vtg_first<TOPD, CH>(p, chan, absmask, signmask);
+    else op_vtg_t<TOPD, CH>(p, gm, chan, absmask, signmask);
+}
+#undef LN_VGS
+#endif  // LN_LOGN != 10
 
 // stage 8 (arena column) -> stage 7 (LDS column): kind 0 = F, 1 = G (column of the slot owner), 2 = a + b (= G with zero
 // bits).  Eight steps per batch: their sixteen 16-byte loads go out together into v[128 .. 191] (dead stages), the steps
@@ -1581,18 +2132,22 @@ void scl_lane_kernel(const DecodeParams P)
     using namespace lane;
     // (dynamic: with a static 40 KB the compiler derives one wave per SIMD from the LDS size and then ignores the VGPR cap)
     extern __shared__ uint32_t lds[];
+#if LN_LOGN == 10
     asm volatile("" ::: "v255", "a0");  // (sizes the register file: the hand-allocated registers reach up to v253; a0: see KV)
+#else
+    asm volatile("" ::: "v255", "a0", "a255");  // (... and the top-of-tree pass of the other block lengths lands its bit words in a[240 .. 254])
+#endif
     const int lane = (int)threadIdx.x;
     const uint32_t nrows = P.rows_dev ? *P.rows_dev : P.rows;
-    const uint32_t ngroups = (nrows + 7u) >> 3;
+    const uint32_t ngroups = (nrows + (uint32_t)CPW - 1u) / (uint32_t)CPW;
     const uint32_t absmask = 0x7FFFFFFFu, signmask = 0x80000000u;
     const_u64_ptr prog = (const_u64_ptr)(const void*)P.prog;
     const uint32_t N = P.N;
 
     Path p;
     p.lane = lane;
-    p.q = lane & 7;
-    p.g0 = lane & ~7;
+    p.q = lane & (LC - 1);
+    p.g0 = lane & ~(LC - 1);
     p.self4 = (uint32_t)lane << 2;
     p.lds = lds;
     p.arena = reinterpret_cast<uint32_t*>(P.arena) + (size_t)blockIdx.x * AR_WORDS;
@@ -1602,21 +2157,26 @@ void scl_lane_kernel(const DecodeParams P)
     asm volatile("" : "+v"(p.m128));  // (kept in a VGPR: the clamp's scalar operand is the 127)
 
     for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const uint32_t ci = grp * 8u + ((uint32_t)lane >> 3);
+        const uint32_t ci = grp * (uint32_t)CPW + ((uint32_t)lane >> LCL);
         const bool live = ci < nrows;
-        const uint32_t cj = live ? ci : grp * 8u;
+        const uint32_t cj = live ? ci : grp * (uint32_t)CPW;
         const uint32_t row = P.rowidx ? P.rowidx[cj] : cj;
         const float* chan = reinterpret_cast<const float*>(P.llr) + (size_t)row * N;
         p.metric = 0.0f;
-        p.pl = p.q == 0 ? 0u : 15u;
+        p.pl = p.q == 0 ? 0u : PL_DEAD;
         p.P = 1;
-        p.slot = (uint32_t)p.q * 0x01249249u;  // every field = own lane
+        p.reset_slots();  // every field = own lane
         uint32_t trace_n = 0;
 
         uint64_t nraw = prog[0];
         for (uint32_t pc = 0;; ++pc) {
             const uint64_t raw = nraw;
             nraw = prog[pc + 1];  // (fetched one instruction ahead; the host appends a spare word behind OP_END)
+#if !LN_GEO_DEFAULT
+            // (nothing derived from the lane number is carried around the interpreter loop: with the larger arenas of the other
+            //  geometries the compiler otherwise keeps -- and spills to scratch -- dozens of precomputed 64-bit column addresses)
+            asm volatile("" : "+v"(p.lane), "+v"(p.q), "+v"(p.g0), "+v"(p.self4));
+#endif
             const uint32_t op = (uint32_t)raw & 0xFFu, st = ((uint32_t)raw >> 8) & 0xFFu, side = ((uint32_t)raw >> 16) & 0xFFu;
             const uint32_t off = (uint32_t)(raw >> 32);
             if (op == OP_END) break;
@@ -1633,8 +2193,12 @@ void scl_lane_kernel(const DecodeParams P)
           for (uint32_t again = 0; again < ((DIAG && (P.ablate & 32768u)) ? 2u : 1u); ++again, opx = 0xFFu)  // (PCD_ABLATE=32768: every dispatch twice, the second one of nothing)
             switch (opx) {
             case LN_VT:
+#if LN_LOGN == 10
                 if (!(DIAG && (P.ablate & 1u))) op_vt<CH>(p, off, chan, absmask, signmask);
                 if (DIAG && (P.ablate & 1024u)) op_vt<CH>(p, off, chan, absmask, signmask);  // (idempotent: costed by doing it twice)
+#else
+                if (!(DIAG && (P.ablate & 1u))) op_vtg<CH>(p, off, chan, absmask, signmask);
+#endif
                 break;
             case LN_WALK: {
                 if (DIAG && (P.ablate & 2u)) break;
@@ -1658,7 +2222,17 @@ void scl_lane_kernel(const DecodeParams P)
                         case 6: op_combine<6>(p, sd); break;
                         case 7: op_combine<7>(p, sd); break;
                         case 8: op_combine<8>(p, sd); break;
+#if LN_LOGN == 10
                         default: op_combine<9>(p, sd); break;
+#else
+#if LN_LOGN >= 11
+                        case 9: op_combine<9>(p, sd); break;
+#endif
+#if LN_LOGN >= 12
+                        case 10: op_combine<10>(p, sd); break;
+#endif
+                        default: if constexpr (LOGN >= 10) op_combine<(LOGN >= 10 ? LOGN - 1 : 9)>(p, sd); break;
+#endif
                         }
                     }
                     if (c1 >= 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1768,7 +2342,7 @@ void scl_lane_kernel(const DecodeParams P)
                 if (lane == 0) P.cycles[pc] = (uint32_t)(t_end - t_start);
             }
             if (DIAG && P.trace && grp == 0 && is_leaf) {
-                if (trace_n < P.trace_cap && lane < 8) {
+                if (trace_n < P.trace_cap && lane < LC) {
                     float* t = P.trace + (size_t)trace_n * (1 + P.L);
                     if (lane == 0) t[0] = (float)p.P;
                     if ((uint32_t)lane >= p.P && (uint32_t)lane < P.L) t[1 + lane] = 0.0f;
@@ -1780,6 +2354,7 @@ void scl_lane_kernel(const DecodeParams P)
 
         if (DIAG && (P.ablate & 64u)) continue;
         // ---- SclAvxFloat::extractBestPath :711-750 -----------------------------------------------------------------
+#if LN_LOGN == 10
         // code word of this path: [left ^ right | right] of the root's children (16 + 16 words from the arena)
         uint32_t xw[32];
         {
@@ -1836,6 +2411,80 @@ void scl_lane_kernel(const DecodeParams P)
             }
             if (P.K & 31u) il[(P.K >> 5) * 64 + lane] = __builtin_bswap32(__brev((uint32_t)acc));
         }
+#else
+        // code word of this path: [left ^ right | right] of the root's children (arena), XW words at a time; the information
+        // bits are extracted word by word as above, the shift register runs through the rounds
+        uint32_t* il = lds + LDS_S7;
+        {
+            constexpr uint32_t NWT = (1u << LOGN) / 32u;   // words of the code word
+            constexpr uint32_t XW = NWT < 32u ? NWT : 32u;  // words per round
+            constexpr uint32_t NCK = NWT / XW, NWH = NWT / 2u;
+            uint32_t ln = (uint32_t)lane;
+            asm volatile("" : "+v"(ln));  // (opaque: see op_combine)
+            const uint32_t* lp0 = p.arena + AR_BL(LOGN - 1) + p.owner(LOGN);
+            const uint32_t* rp0 = p.arena + AR_BR(LOGN - 1) + ln;
+            const uint32_t* ext = P.ext;
+            uint64_t acc = 0;
+#pragma unroll 1
+            for (uint32_t ck = 0; ck < NCK; ++ck) {
+                const uint32_t *lp = lp0, *rp = rp0;
+                asm volatile("" : "+v"(lp), "+v"(rp));
+                uint32_t xw[XW];
+                auto load_round = [&](uint32_t cc, bool first) {  // words [XW cc, XW cc + XW) of x, XORed into xw unless first
+                    const bool lefthalf = XW * cc < NWH;         // (a round never straddles the halves unless it is the only one)
+#pragma unroll
+                    for (uint32_t i = 0; i < XW; ++i) {
+                        const uint32_t wi = XW * cc + i;
+                        uint32_t x;
+                        if constexpr (NCK == 1) x = i < NWH ? (lp[i * 64] ^ rp[i * 64]) : rp[(i - NWH) * 64];
+                        else x = lefthalf ? (lp[wi * 64] ^ rp[wi * 64]) : rp[(wi - NWH) * 64];
+                        xw[i] = first ? x : (xw[i] ^ x);
+                        if ((i & 7u) == 7u) asm volatile("" ::: "memory");  // (eight words at a time: not 64 loads in flight and their registers)
+                    }
+                };
+                load_round(ck, true);
+                if (!P.systematic) {  // re-encode (:731-746): u = x G -- between the rounds, inside the words, between the words
+#pragma unroll 1
+                    for (uint32_t cc = ck + 1; cc < NCK; ++cc)
+                        if ((cc & ck) == ck) load_round(cc, false);
+#pragma unroll
+                    for (uint32_t i = 0; i < XW; ++i) {
+                        uint32_t v = xw[i];
+                        v ^= (v >> 1) & 0x55555555u;
+                        v ^= (v >> 2) & 0x33333333u;
+                        v ^= (v >> 4) & 0x0F0F0F0Fu;
+                        v ^= (v >> 8) & 0x00FF00FFu;
+                        v ^= (v >> 16) & 0x0000FFFFu;
+                        xw[i] = v;
+                    }
+#pragma unroll
+                    for (uint32_t hw = 1; hw < XW; hw <<= 1) {
+#pragma unroll
+                        for (uint32_t i = 0; i < XW; ++i)
+                            if (!(i & hw)) xw[i] ^= xw[i + hw];
+                    }
+                }
+                const uint32_t* ex = ext + 8u * XW * ck;
+#pragma unroll
+                for (uint32_t w = 0; w < XW; ++w) {
+                    const uint32_t mask = ex[8 * w], base = ex[8 * w + 1];
+                    uint32_t x = xw[w] & mask;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        const uint32_t t = x & ex[8 * w + 2 + i];
+                        x = (x ^ t) | (t >> (1u << i));
+                    }
+                    acc |= (uint64_t)x << (base & 31u);
+                    const uint32_t end = base + (uint32_t)__builtin_popcount(mask);
+                    if ((end >> 5) != (base >> 5)) {  // (wave uniform) a word is complete
+                        il[(base >> 5) * 64 + lane] = __builtin_bswap32(__brev((uint32_t)acc));
+                        acc >>= 32;
+                    }
+                }
+            }
+            if (P.K & 31u) il[(P.K >> 5) * 64 + lane] = __builtin_bswap32(__brev((uint32_t)acc));
+        }
+#endif
         // detector verdict of every path: XOR of the syndrome words of its output bytes
         const bool alive = p.pl < p.P;
         uint32_t syn = 0;
@@ -1874,7 +2523,26 @@ void scl_lane_kernel(const DecodeParams P)
     }
 }
 
-#if LN_CHAR
+#if !LN_GEO_DEFAULT
+// other geometries (scl_lane_n*_l*.hip): one instantiation per translation unit, named by the stub
+template __global__ void scl_lane_kernel<false, LN_CHAR != 0>(const DecodeParams);
+
+unsigned LN_ARENA_NAME() { return lane::AR_WORDS; }
+hipError_t LN_LAUNCH_NAME(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
+{
+    if ((P.chr != 0) != (LN_CHAR != 0) || P.logN != (uint32_t)lane::LOGN || P.L > (uint32_t)lane::LC) return hipErrorInvalidValue;
+#ifdef PAMD_DIAG
+    if (diag) {
+        hipLaunchKernelGGL((scl_lane_kernel<true, LN_CHAR != 0>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+        return hipGetLastError();
+    }
+#else
+    if (diag) return hipErrorInvalidValue;
+#endif
+    hipLaunchKernelGGL((scl_lane_kernel<false, LN_CHAR != 0>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
+    return hipGetLastError();
+}
+#elif LN_CHAR
 // SclFipChar on the lane kernel: saturating f / g, repetition leaves at every size; the rows arrive widened to fp32
 template __global__ void scl_lane_kernel<false, true>(const DecodeParams);
 

@@ -31,7 +31,7 @@ PCD_MEM_HOST, PCD_MEM_DEVICE = 0, 1
 C_SYMBOLS = [
     "pcd_create", "pcd_destroy", "pcd_set_error_detection", "pcd_set_systematic", "pcd_is_systematic",
     "pcd_block_length", "pcd_info_length", "pcd_list_size", "pcd_frozen_bits", "pcd_error_detection_mode",
-    "pcd_out_bytes", "pcd_decode_f32", "pcd_decode_i8", "pcd_program_stats", "pcd_launch_info",
+    "pcd_out_bytes", "pcd_decode_f32", "pcd_decode_i8", "pcd_program_stats", "pcd_launch_info", "pcd_kernel_name",
     "pcd_set_timing", "pcd_kernel_times", "pcd_last_error", "pcd_version",
     "pce_create", "pce_destroy", "pce_set_error_detection", "pce_set_systematic", "pce_is_systematic",
     "pce_block_length", "pce_info_length", "pce_info_bytes", "pce_code_bytes", "pce_frozen_bits",
@@ -88,6 +88,8 @@ def load_library():
     lib.pcd_program_stats.argtypes = [vp, C.c_int, u32p]
     lib.pcd_launch_info.restype = C.c_int
     lib.pcd_launch_info.argtypes = [vp, C.c_int, u32p]
+    lib.pcd_kernel_name.restype = C.c_int
+    lib.pcd_kernel_name.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     lib.pcd_set_timing.restype = C.c_int
     lib.pcd_set_timing.argtypes = [vp, C.c_int]
     lib.pcd_kernel_times.restype = C.c_int
@@ -368,6 +370,14 @@ class PolarDecoder:
             _raise(rc)
         return {"lds_bytes_per_codeword": int(info[0]), "codewords_per_workgroup": int(info[1]),
                 "path_groups": int(info[2]), "workgroups_per_cu_by_lds": int(info[3])}
+
+    def kernel_name(self, list_program):
+        """name of the kernel decode calls launch for the SC (False) or the list (True) program, as rocprofv3 shows it"""
+        buf = C.create_string_buffer(96)
+        rc = self._lib.pcd_kernel_name(self._h, int(bool(list_program)), buf, C.c_size_t(len(buf)))
+        if rc:
+            _raise(rc)
+        return buf.value.decode()
 
     def _need_diag(self):
         if not hasattr(self._lib, "pcd_scl_trace"):
