@@ -100,7 +100,17 @@ __host__ __device__ constexpr uint32_t AR_BR(int t) { return AR_BL(t) + ar_bitwo
 constexpr uint32_t AR_BL8 = AR_BL(8), AR_BR8 = AR_BR(8);
 #endif
 constexpr uint32_t AR_DUMP = AR_BR8 + 8 * 64;      // 16 chunks x 64 lanes x 4: stage 5 / 6 leaf input, read back chunk-wise
+#if LN_LOGN == 10
 constexpr uint32_t AR_WORDS = AR_DUMP + 16 * 64 * 4;
+#else
+// "virtual rows": the leftmost block of every stage 9 .. LOGN - 1 (f of the channel row, f of that, ...) does not depend on
+// the path -- computed once per codeword by the first pass, every later top-of-tree pass whose upper levels are f's starts
+// from the highest one it can use instead of the channel row.  Per codeword: stage LOGN - 1 first, then LOGN - 2, ...
+constexpr uint32_t AR_VROW = AR_DUMP + 16 * 64 * 4;
+constexpr uint32_t VROW_FLOATS = (1u << LOGN) - 512u;
+__host__ __device__ constexpr uint32_t vrow_off(int t) { return (1u << LOGN) - (2u << t); }  // (floats in front of stage t's row)
+constexpr uint32_t AR_WORDS = AR_VROW + (uint32_t)CPW * VROW_FLOATS;
+#endif
 // LDS of one wave (32-bit words)
 constexpr uint32_t LDS_S7 = 0;                     // [32 chunks][64 lanes][4 words]
 constexpr uint32_t LDS_SCR = 8192;                 // scratch: 2048 words
@@ -1019,7 +1029,38 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     for (int c = 0; c < C; ++c) nme += (own[c] <= kcm) ? 1u : 0u;
     const bool cut_tie = cw_add(nme) != np;
     const bool seated = q < np;
-    if (ballot64(near || cut_tie) != 0) {  // (wave uniform; rare on real-valued input)
+    bool resolved = false;
+    if (ballot64(near) != 0 && ballot64(cut_tie) == 0) {
+        // Keys that agree above the payload bits while the cut is clean.  With 16 / 32 paths this happens in a good part of the
+        // forks on real-valued input (a key keeps 24 - LCL bits of the metric), so it gets a cheap exact answer first: the
+        // chosen SET is right, and a run of equal keys only has to be put in the order of the exact metrics -- odd-even
+        // transposition between neighbouring ranks on (exact metric bits, key), until two rounds in a row change nothing.
+        // If two neighbours then still carry the same exact metric, the order depends on the reference's swaps: the tiers below.
+        const uint32_t* scm = p.lds + SCR_CM;
+        uint32_t fk = mykey;
+        uint32_t tm = seated ? scm[((uint32_t)p.g0 | ((fk >> 3) & (uint32_t)(LC - 1))) * 8u + (fk & 7u)] : INF;
+        uint32_t quiet = 0;
+#pragma unroll 1
+        for (uint32_t round = 0; round < 2u * (uint32_t)LC && quiet < 2u; ++round) {
+            const uint32_t pr = (round & 1u) ? (((q + 1u) ^ 1u) - 1u) : (q ^ 1u);  // partner rank (odd rounds: (1,2) (3,4) ...; rank 0 and the last one rest)
+            const bool valid = pr < (uint32_t)LC;
+            const uint32_t pa = ((uint32_t)p.g0 | (valid ? pr : q)) << 2;
+            const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pa, (int)fk);
+            const uint32_t pt = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pa, (int)tm);
+            const bool run = valid && ((fk ^ pk) <= PBM);  // (both seated: an unseated rank holds a key above every run of chosen ones or INF)
+            const bool take = run && (q < pr ? (pt < tm) : (tm < pt));
+            fk = take ? pk : fk;
+            tm = take ? pt : tm;
+            quiet = ballot64(take) != 0 ? 0u : quiet + 1u;
+        }
+        const uint32_t nt = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)p.g0 | (q + 1u < (uint32_t)LC ? q + 1u : q)) << 2), (int)tm);
+        const bool exact_tie = (q + 1u < np) && nt == tm;
+        if (ballot64(exact_tie) == 0) {
+            mykey = fk;
+            resolved = true;
+        }
+    }
+    if (!resolved && ballot64(near || cut_tie) != 0) {  // (wave uniform)
         // Equal metrics: see the 8-lane form above.
         uint32_t low = 0;
 #pragma unroll
@@ -1895,17 +1936,20 @@ __device__ __forceinline__ void vtg_words_take()
         asm volatile("v_accvgpr_read_b32 v[%0], a[%1]" ::"n"(VTG_W + i), "n"(VTG_A + i));
     });
 }
-template <int LV, bool CH>
+// TOP: the stage of the source row (LOGN: the channel row; lower: a virtual row), LV = TOP - 8 levels; gm bit l: the op at
+// stage TOP - l is a g
+template <int TOP, bool CH>
 __device__ __forceinline__ void op_vtg_t(Path& p, uint32_t gm, const float* chan, uint32_t absmask, uint32_t signmask)
 {
+    constexpr int LV = TOP - 8;
     using G = VtgGeo<LV>;
     constexpr int NS = G::NS, SW = G::SW;
     // the g that has just been executed is the one at the lowest stage: its left child's bits are this lane's own
-    if (gm) p.set_field((uint32_t)LOGN - (31u - (uint32_t)__builtin_clz(gm)));
+    if (gm) p.set_field((uint32_t)TOP - (31u - (uint32_t)__builtin_clz(gm)));
     uint32_t bo[LV];
     static_for<LV>([&](auto Lc) {
         constexpr int l = decltype(Lc)::value;
-        bo[l] = 4u * (AR_BL(LOGN - l - 1) + p.owner((uint32_t)(LOGN - l)));
+        bo[l] = 4u * (AR_BL(TOP - l - 1) + p.owner((uint32_t)(TOP - l)));
     });
     const uint32_t* abase = p.arena;
     const uint32_t* s8base = p.arena + AR_S8;
@@ -1946,22 +1990,52 @@ __device__ __forceinline__ void op_vtg_t(Path& p, uint32_t gm, const float* chan
 // codeword idle.  The steps do not depend on the path: lane q does the chunks c = q, q + LC, ... < 32 and their partners
 // c + 32, and stores into the column of the codeword's first lane, where the path lives.  (Not pipelined: a handful of
 // steps per lane, once per codeword.)
+// every level an f, and what the levels above the last one produce goes to the codeword's virtual rows: after level l the set
+// holds the chunks c + 64 k, k < 2^(LV-1-l), of the leftmost block of stage LOGN - 1 - l
+template <int S, int LV, bool CH>
+__device__ __forceinline__ void vtg_levels_first(float* vrow, uint32_t c, uint32_t absmask, float c127)
+{
+    uint32_t am = absmask;
+    float cc = c127;
+    static_for<LV>([&](auto Lc) {
+        constexpr int l = decltype(Lc)::value;
+        constexpr int NB = 1 << (LV - 1 - l);
+        static_for<NB>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            uint32_t t0, t1, t2, t3;
+            const uint32_t qa = am;
+            asm volatile(LN_F4T("%[d]", "%[d]", "%[b]")
+                         : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                         : [d] "n"(S + 4 * k), [b] "n"(S + 4 * (k + NB)), [am] "s"(qa));
+        });
+        if constexpr (CH) clamp_f<S, 4 * NB>(cc, am);
+        if constexpr (l + 1 < LV) {
+            float* const dst = vrow + vrow_off(LOGN - 1 - l) + 4u * c;
+            static_for<NB>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                float* const dk = dst + 256 * (k & ~3);  // (chunk c + 64 k: 1024 k bytes on; the immediate offset takes k & 3)
+                asm volatile("s_nop 0\n\tglobal_store_dwordx4 %0, v[%1:%1+3], off offset:%2" ::"v"(dk), "n"(S + 4 * k), "n"((k & 3) * 1024) : "memory");
+            });
+        }
+    });
+}
 template <int LV, bool CH>
 __device__ __forceinline__ void op_vtg_first(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
 {
     const uint32_t* s8base = p.arena + AR_S8;
     const uint32_t s8col = (uint32_t)p.g0 * 16u, s7col = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u;
+    float* const vrow = reinterpret_cast<float*>(p.arena + AR_VROW) + ((uint32_t)p.lane >> LCL) * VROW_FLOATS;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
     for (uint32_t c = (uint32_t)p.q; c < 32u; c += (uint32_t)LC) {
         vtg_load<128, LV>(chan + 4 * c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        vtg_levels<128, LV, CH>(0u, 31u, absmask, signmask, p.c127, p.m128);
+        vtg_levels_first<128, LV, CH>(vrow, c, absmask, p.c127);
         vtg_tail_first<128>(s8col + 1024u * c, s8base, s7col + 1024u * c);
         vtg_fetch_parked(s7col + 1024u * c);
         vtg_load<128, LV>(chan + 4 * (c + 32u));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        vtg_levels<128, LV, CH>(0u, 31u, absmask, signmask, p.c127, p.m128);
+        vtg_levels_first<128, LV, CH>(vrow, c + 32u, absmask, p.c127);
         vtg_tail_second<128, CH>(s8col + 1024u * (c + 32u), s8base, s7col + 1024u * c, absmask, p.c127);
     }
     p.set_field(8);
@@ -1973,8 +2047,23 @@ template <bool CH>
 __device__ __forceinline__ void op_vtg(Path& p, uint32_t off, const float* chan, uint32_t absmask, uint32_t signmask)
 {
     const uint32_t gm = off & ((1u << TOPD) - 1u);
-    if (gm == 0u && p.P == 1u) op_vtg_first<TOPD, CH>(p, chan, absmask, signmask);
-    else op_vtg_t<TOPD, CH>(p, gm, chan, absmask, signmask);
+    if (gm == 0u && p.P == 1u) {
+        op_vtg_first<TOPD, CH>(p, chan, absmask, signmask);
+        return;
+    }
+    // the levels above the first g are path-independent f's: start from the virtual row of that stage
+    const float* const vrow = reinterpret_cast<const float*>(p.arena + AR_VROW) + ((uint32_t)p.lane >> LCL) * VROW_FLOATS;
+    const uint32_t l0 = gm ? (uint32_t)__builtin_ctz(gm) : 0u;
+    switch (l0) {
+#if LN_LOGN >= 12
+    case 3: op_vtg_t<LOGN - 3, CH>(p, gm >> 3, vrow + vrow_off(LOGN - 3), absmask, signmask); break;
+#endif
+#if LN_LOGN >= 11
+    case 2: op_vtg_t<LOGN - 2, CH>(p, gm >> 2, vrow + vrow_off(LOGN - 2), absmask, signmask); break;
+    case 1: op_vtg_t<LOGN - 1, CH>(p, gm >> 1, vrow + vrow_off(LOGN - 1), absmask, signmask); break;
+#endif
+    default: op_vtg_t<LOGN, CH>(p, gm, chan, absmask, signmask); break;
+    }
 }
 #undef LN_VGS
 #endif  // LN_LOGN != 10
@@ -2417,7 +2506,7 @@ void scl_lane_kernel(const DecodeParams P)
         uint32_t* il = lds + LDS_S7;
         {
             constexpr uint32_t NWT = (1u << LOGN) / 32u;   // words of the code word
-            constexpr uint32_t XW = NWT < 32u ? NWT : 32u;  // words per round
+            constexpr uint32_t XW = NWT < 32u ? NWT : (LOGN >= 12 ? 16u : 32u);  // words per round (N = 4096: 16, for the registers' sake)
             constexpr uint32_t NCK = NWT / XW, NWH = NWT / 2u;
             uint32_t ln = (uint32_t)lane;
             asm volatile("" : "+v"(ln));  // (opaque: see op_combine)
