@@ -38,6 +38,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc-traffic", dest="pmc_traffic", action="store_false")
     ap.add_argument("--launch-timeout", type=float, default=900.0,
                     help="N > 1 started without a launcher: seconds after which the rank processes are terminated")
+    ap.add_argument("--kernel-name", action="store_true",
+                    help="print the name of the kernel the decoder of --config launches (host only, no GPU) and exit")
     ap.add_argument("--launch-check", action="store_true",
                     help="every rank reports its RANK / WORLD_SIZE / LOCAL_RANK and exits before touching the GPU "
                          "(test of the N > 1 launcher)")
@@ -476,6 +478,17 @@ def main():
         if info["rank"] == 0:
             emit(info)
         return
+    if args.kernel_name:  # (host side only: which kernel the library picks for this config -- tools/collect_profiles.sh)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "polar-codes_amd"))
+        import pypolar_amd as _pp
+        _cfg = CONFIGS[args.config]
+        if _cfg["L"] == 0:
+            os.write(real_stdout, b"\n")
+            return
+        from pypolar_amd.construction import frozen_bits as _fb
+        _d = _pp.PolarDecoder(_cfg["N"], _cfg["L"], _fb(_cfg["N"], _cfg["K"], _cfg["dsnr"], _cfg.get("ctor", "BB")), "char" if _cfg.get("dectype") == "char" else "float")
+        os.write(real_stdout, (_d.kernel_name(_cfg["L"] > 1) + "\n").encode())
+        return
     heavy_imports()
     if args.pmc_traffic is None:  # default: on for the single-GPU run when the profiler is there (and not inside its own child pass)
         import shutil
@@ -535,8 +548,8 @@ def main():
     chr_dec = cfg.get("dectype") == "char"
     dec = pypolar_amd.PolarDecoder(N, L, frozen, "char" if chr_dec else "float", device=dev_index)
     dec.setErrorDetection(cfg["crc"], cfg["crc_type"])
-    # the kernel this decoder launches (the PMC passes filter by it): one lane per path = the lane-per-path list kernel
-    kernel_name = ("sc_pair_kernel" if dec.launch_info(False)["codewords_per_workgroup"] == 32 else "sc_decode_kernel") if L <= 1 else (("scl_lane_char_kernel" if chr_dec else "scl_lane_kernel") if dec.launch_info(True)["path_groups"] == 64 else "scl_decode_kernel")
+    # the kernel this decoder launches, as the library reports it (pcd_kernel_name): the PMC passes filter their rows by it
+    kernel_name = dec.kernel_name(L > 1)
 
     llr, info = make_batch(cfg, frozen, B, dev, seed=1234 + rank)
     if chr_dec:  # int8 rows resident in HBM: round(8 y), clipped to +-127

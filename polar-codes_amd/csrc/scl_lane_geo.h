@@ -5,7 +5,7 @@
 #pragma once
 #include "kernels.h"
 
-#define PAMD_LANE_GEOS(X) X(12, 5) X(10, 4) X(10, 5) X(11, 3) X(9, 3)
+#define PAMD_LANE_GEOS(X) X(12, 5) X(10, 4) X(10, 5) X(11, 3) X(9, 3) X(9, 4) X(9, 5) X(11, 4) X(11, 5) X(12, 3) X(12, 4)
 #define PAMD_LANE_GEOS_CHAR(Y)
 
 namespace pamd {

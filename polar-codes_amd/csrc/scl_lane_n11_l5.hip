@@ -1,0 +1,8 @@
+// lane-per-path list kernel, N = 2048, up to 32 paths (2 codewords per wave): scl_lane_kernel.hip under another geometry
+#define LN_LOGN 11
+#define LN_LCL 5
+#define LN_BIG 1
+#define LN_KERNEL_NAME scl_lane_n11_l5_kernel
+#define LN_LAUNCH_NAME launch_scl_lane_n11_l5
+#define LN_ARENA_NAME scl_lane_n11_l5_arena_words
+#include "scl_lane_kernel.hip"

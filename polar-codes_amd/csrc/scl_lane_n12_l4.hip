@@ -1,0 +1,8 @@
+// lane-per-path list kernel, N = 4096, up to 16 paths (4 codewords per wave): scl_lane_kernel.hip under another geometry
+#define LN_LOGN 12
+#define LN_LCL 4
+#define LN_BIG 1
+#define LN_KERNEL_NAME scl_lane_n12_l4_kernel
+#define LN_LAUNCH_NAME launch_scl_lane_n12_l4
+#define LN_ARENA_NAME scl_lane_n12_l4_arena_words
+#include "scl_lane_kernel.hip"

@@ -330,6 +330,44 @@ def test_lane_per_path_kernel_codes(built_library, N, K, L, kind):
         assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), "path metrics differ from the oracle's"
 
 
+LANE_GEO_CODES = [(512, 256, 8, "BB"), (512, 128, 6, "BB"), (512, 256, 16, "BB"), (512, 200, 32, "BE"), (512, 256, 5, "rand"),
+                  (1024, 512, 16, "BB"), (1024, 300, 12, "BE"), (1024, 512, 32, "BB"), (1024, 800, 24, "BB"), (1024, 512, 9, "rand"),
+                  (2048, 1024, 8, "BB"), (2048, 512, 7, "BE"), (2048, 1500, 8, "BB"), (2048, 1024, 16, "BB"), (2048, 700, 24, "BB"), (2048, 1024, 8, "rand"),
+                  (4096, 2048, 8, "BB"), (4096, 2048, 16, "BB"), (4096, 2048, 32, "BB"), (4096, 2048, 20, "BE"), (4096, 1400, 32, "BB"), (2048, 256, 8, "BB")]
+
+
+@pytest.mark.parametrize("N,K,L,kind", LANE_GEO_CODES, ids=[f"N{n}_K{k}_L{l}_{c}" for n, k, l, c in LANE_GEO_CODES])
+def test_lane_kernel_geometries(built_library, N, K, L, kind):
+    """The lane-per-path list kernel under its other geometries (round 4, csrc/scl_lane_geo.h): N = 512 / 2048 / 4096 -- every stage
+    between the channel row and stage 8 recomputed by the generic top-of-tree pass, the path-independent ones shared through the
+    virtual rows -- and 16 / 32 lanes per codeword (distributed merge selection, near ties resolved on the exact metrics), on AWGN,
+    pure-noise and tie-heavy rows, systematic and not, ragged batch sizes; bytes, verdicts and all L path metrics bit for bit.
+    Reference: SclAvxFloat scl_avx_float.cpp:229-263, 316-651, 711-750."""
+    import pypolar_amd
+    rng = np.random.default_rng(7 * N + K + L)
+    if kind == "rand":
+        frozen = np.sort(rng.choice(N, N - K, replace=False)).astype(np.uint32)
+    else:
+        frozen = np.asarray(pypolar_amd.frozen_bits(N, K, 0.0, kind), dtype=np.uint32)
+    rows = 21 if N <= 1024 else (13 if N == 2048 else 7)     # (not a multiple of the codewords per wave)
+    awgn = (1.0 + 0.8 * rng.standard_normal((rows, N))).astype(np.float32) * np.where(rng.random((rows, N)) < 0.5, 1, -1).astype(np.float32)
+    noise = rng.standard_normal((rows // 3, N)).astype(np.float32)
+    ties = rng.integers(-3, 4, (rows // 2, N)).astype(np.float32)
+    eighths = (np.round(awgn[: rows // 2] * 8) / 8).astype(np.float32)    # quantised: equal metrics at most forks
+    llr = np.concatenate([awgn, noise, ties, eighths])
+    d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
+    if kind == "BB" and 2 * K == N:
+        assert d.kernel_name(True).startswith("scl_lane_"), d.kernel_name(True)   # (expressible: the new kernels run; a leaf above stage 8 -- low and high rates at N >= 2048 -- keeps the path-group kernels)
+    for systematic in (True, False):
+        e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, 8, llr, systematic, "float")
+        d.setErrorDetection(8, "crc")
+        d.setSystematic(systematic)
+        out, ok, met = d.decode_batch(llr, return_metrics=True)
+        assert np.array_equal(out, e_out), (N, K, L, kind, systematic)
+        assert np.array_equal(ok.astype(np.uint8), e_ok)
+        assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), "path metrics differ from the oracle's"
+
+
 @pytest.mark.parametrize("dectype,K,kind", [("float", 512, "BB"), ("float", 176, "5G"), ("float", 900, "BB"), ("char", 512, "BB"), ("char", 256, "BB"),
                                             ("char", 768, "BB"), ("char", 900, "BB")],
                          ids=["float_K512", "float_5G_K176", "float_K900_big", "char_K512", "char_K256", "char_K768_big", "char_K900_big"])

@@ -323,9 +323,11 @@ def test_sc_builder_refuses_the_sets_the_reference_refuses(built_library):
 
 @pytest.mark.parametrize("N,L,cw,groups", [
     (128, 1, 8, 1), (256, 1, 8, 1), (512, 1, 4, 1), (1024, 1, 32, 1), (4096, 1, 4, 1),       # SC: 8 lanes per codeword up to 256, 2 lanes at N = 1024 (sc_pair_kernel)
-    (1024, 2, 8, 16), (1024, 4, 4, 16), (512, 8, 2, 16), (2048, 3, 4, 16),                     # 4 lanes per path up to N = 2048
+    (1024, 2, 8, 16), (1024, 4, 4, 16), (2048, 3, 4, 16),                                      # 4 lanes per path up to N = 2048 for L <= 4
     (1024, 8, 8, 64), (1024, 5, 8, 64),                                                       # lane-per-path kernel: N = 1024, 4 < L <= 8
-    (4096, 2, 4, 8), (4096, 4, 2, 8), (4096, 8, 1, 8), (1024, 16, 1, 16), (4096, 32, 1, 32)])  # 8 lanes / one codeword above
+    (512, 8, 8, 64), (2048, 8, 8, 64), (4096, 8, 8, 64),                                      # ... and, since round 4, N = 512 / 2048 / 4096
+    (1024, 16, 4, 64), (1024, 32, 2, 64), (4096, 32, 2, 64), (2048, 12, 4, 64), (512, 24, 2, 64),  # ... with 16 / 32 lanes per codeword for L > 8
+    (4096, 2, 4, 8), (4096, 4, 2, 8), (8192, 8, 1, 8), (8192, 16, 1, 16), (16384, 8, 1, 8), (256, 16, 1, 16)])  # 8 lanes / one codeword elsewhere
 def test_launch_geometry_choices(built_library, N, L, cw, groups):
     """codewords per wave and path groups per wave the host picks (capi.cpp, compute_geometry): the measured choices of
     DESIGN.md section 3 -- a change here is a performance change and should come with a sweep (tools/perf_sweep.py)"""
@@ -351,6 +353,27 @@ def test_lane_kernel_rule(built_library, dectype, K, kind, lane):
     from pypolar_amd.construction import frozen_bits
     d = pypolar_amd.PolarDecoder(1024, 8, frozen_bits(1024, K, 0.0, kind), dectype)
     assert (d.launch_info(True)["path_groups"] == 64) == lane, d.launch_info(True)
+
+
+@pytest.mark.parametrize("N,L,K,name", [
+    (512, 8, 256, "scl_lane_n9_l3_kernel"), (512, 16, 256, "scl_lane_n9_l4_kernel"), (512, 32, 256, "scl_lane_n9_l5_kernel"),
+    (1024, 8, 512, "scl_lane_kernel"), (1024, 12, 512, "scl_lane_n10_l4_kernel"), (1024, 32, 512, "scl_lane_n10_l5_kernel"),
+    (2048, 8, 1024, "scl_lane_n11_l3_kernel"), (2048, 16, 1024, "scl_lane_n11_l4_kernel"), (2048, 20, 1024, "scl_lane_n11_l5_kernel"),
+    (4096, 6, 2048, "scl_lane_n12_l3_kernel"), (4096, 16, 2048, "scl_lane_n12_l4_kernel"), (4096, 32, 2048, "scl_lane_n12_l5_kernel"),
+    (4096, 32, 3000, "scl_decode_kernel"),   # a leaf above stage 8: the lowering cannot express the tree
+    (1024, 4, 512, "scl_decode_kernel"), (8192, 8, 4096, "scl_decode_kernel"), (256, 8, 128, "scl_decode_kernel"),
+    (512, 8, 32, "scl_decode_kernel")])      # fewer than 48 leaves
+def test_kernel_name_reports_the_side_of_the_geometry_rules(built_library, N, L, K, name):
+    """pcd_kernel_name: which kernel a decoder's calls launch (csrc/scl_lane_geo.h lists the lane-per-path geometries) -- the
+    name rocprofv3 shows, so a caller can tell which side of a rule a code fell on without reading geometry numbers"""
+    import pypolar_amd
+    from pypolar_amd.construction import frozen_bits
+    d = pypolar_amd.PolarDecoder(N, L, frozen_bits(N, K, 0.0, "BB"), "float")
+    assert d.kernel_name(True) == name
+    sc = pypolar_amd.PolarDecoder(1024, 1, frozen_bits(1024, 512, 0.0, "BB"), "float")
+    assert sc.kernel_name(False) == "sc_pair_kernel"
+    with pytest.raises(Exception):   # (PCD_ERR_INVALID_ARG: this decoder has no list program)
+        sc.kernel_name(True)
 
 
 @pytest.mark.parametrize("dectype", ["float", "char"])
@@ -404,3 +427,49 @@ def test_library_exports_only_the_c_abi(built_library):
     names = [l.split()[-1] for l in out.splitlines() if l.strip()]
     assert names and all(re.match(r"^(pcd|pce|ppu)_[a-z0-9_]+$", n) for n in names), [n for n in names if not re.match(r"^(pcd|pce|ppu)_", n)]
     assert set(pypolar_amd.C_SYMBOLS) <= set(names)
+
+
+def test_host_compilers_under_sanitizers(built_library, tmp_path):
+    """`make -C polar-codes_amd hostcheck`: program.cpp / lane_program.cpp / pair_program.cpp built with g++
+    -fsanitize=address,undefined and driven (hostcheck/hostcheck.cpp) over the reference's accept / refuse list
+    (tests/golden/sc_accept.txt), the frozen sets of every golden fixture and 10 000 generated sets -- scattered, polar-like,
+    aligned runs, frozen prefixes; N = 8 .. 8192; float and int8 node selection; every program checked for shape, the lowered ones
+    against the plain ones.  A sanitizer report or a malformed program fails the run."""
+    import subprocess
+    pkg = os.path.join(ROOT, "polar-codes_amd")
+    subprocess.check_call(["make", "-C", pkg, "hostcheck"], stdout=subprocess.DEVNULL)
+    exe = os.path.join(pkg, "build", "hostcheck")
+    lines = []
+    n_accept = 0
+    with open(os.path.join(gio.GOLDEN_DIR, "sc_accept.txt")) as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            n_accept += int(t[0]) == 1                      # (column 0: 1 = the reference's SC constructor accepted the set)
+            lines.append(" ".join([t[1], str(len(t) - 2)] + t[2:]))
+    n_list = len(lines)
+    seen = set()
+    for path in gio.all_files():
+        for fx in gio.load(path):                         # (a file may hold several records: the sweeps, the random sets)
+            key = (fx.N, tuple(int(x) for x in fx.frozen))
+            if key in seen:
+                continue
+            seen.add(key)
+            lines.append(" ".join([str(fx.N), str(len(fx.frozen))] + [str(int(x)) for x in fx.frozen]))
+    sets = tmp_path / "sets.txt"
+    sets.write_text("\n".join(lines) + "\n")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, "sets", str(sets)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"hostcheck ok: {len(lines)} sets" in r.stdout, r.stdout
+    r2 = subprocess.run([exe, "sets", str(sets.parent / "sets.txt")], capture_output=True, text=True, env=env, timeout=600)
+    assert r2.stdout == r.stdout
+    # the reference's verdicts: the float builder refuses exactly the listed sets (the int8 builder never refuses)
+    only = tmp_path / "accept_only.txt"
+    only.write_text("\n".join(lines[:n_list]) + "\n")
+    r3 = subprocess.run([exe, "sets", str(only)], capture_output=True, text=True, env=env, timeout=600)
+    m = re.search(r"SC accepted (\d+) \(pair kernel \d+\), refused (\d+)", r3.stdout)
+    assert m and int(m.group(2)) == n_list - n_accept and int(m.group(1)) == n_list + n_accept, (r3.stdout, n_list, n_accept)
+    r4 = subprocess.run([exe, "fuzz", "10000", "20261005"], capture_output=True, text=True, env=env, timeout=900)
+    assert r4.returncode == 0 and "hostcheck ok: 10000 sets" in r4.stdout, r4.stdout + r4.stderr

@@ -7,8 +7,10 @@
 TAG=${1:-r03}; shift; CFGS=${@:-cfg3 cfg2 cfg4 cfg5 cfg3_i8 cfg2_i8}
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/profiles_$TAG; mkdir -p $O
 for CFG in $CFGS; do
-  KER=scl_decode_kernel; LB=18
-  case $CFG in cfg2*) KER=sc_pair_kernel;; cfg5) LB=13;; cfg4) LB=17; KER=scl_lane_kernel;; cfg3) KER=scl_lane_kernel;; cfg3_i8) KER=scl_lane_char_kernel;; esac  # (cfg 3: the lane-per-path kernel)
+  LB=18
+  case $CFG in cfg5) LB=13;; cfg4) LB=17;; esac
+  # the kernel the decoder of this config launches, as the library reports it (pcd_kernel_name)
+  KER=$(python3 $R/bench.py --config $CFG --kernel-name)
   python3 $R/bench.py --config $CFG --cpu-seconds 5 > $O/${TAG}_${CFG}_bench.json 2> $O/${CFG}_bench.err
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$CFG -o $CFG -- python3 $R/bench.py --config $CFG --steps 4 --warmup 2 --no-cpu-baseline --no-pmc-traffic > /dev/null 2> $O/${CFG}_kt.err)
   cp $(ls $O/kt_$CFG/*/*kernel_stats.csv $O/kt_$CFG/*kernel_stats.csv 2>/dev/null | head -1) $O/${TAG}_${CFG}_rocprofv3_kernel_stats.csv

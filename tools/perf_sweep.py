@@ -13,9 +13,11 @@ import pypolar_amd  # noqa: E402
 from pypolar_amd.construction import frozen_bits  # noqa: E402
 
 dev = torch.device("cuda", 0)
-print(f"{'N':>6} {'L':>3} {'rows':>8} {'kernel ms':>10} {'cw/s':>12} {'info Gbit/s':>12} {'LDS B/cw':>9}")
-for N in (128, 512, 1024, 2048, 4096, 16384):
-    for L in (1, 2, 4, 8, 16, 32):
+print(f"{'N':>6} {'L':>3} {'rows':>8} {'kernel ms':>10} {'cw/s':>12} {'info Gbit/s':>12} {'LDS B/cw':>9}  kernel")
+NS = [int(x) for x in os.environ.get("SWEEP_N", "128,512,1024,2048,4096,16384").split(",")]
+LS = [int(x) for x in os.environ.get("SWEEP_L", "1,2,4,8,16,32").split(",")]
+for N in NS:
+    for L in LS:
         K = N // 2
         cfg = dict(N=N, K=K, L=L, dsnr=0.0, crc=8 if L > 1 else 0, crc_type="crc", ebn0=2.0)
         frozen = frozen_bits(N, K, 0.0, "BB")
@@ -36,5 +38,5 @@ for N in (128, 512, 1024, 2048, 4096, 16384):
         ms = float(np.mean(d.kernel_times_ms()))
         li = d.launch_info(L > 1)
         print(f"{N:6d} {L:3d} {B:8d} {ms:10.3f} {B / ms * 1e3:12.4g} {B / ms * 1e3 * K / 1e9:12.3f} "
-              f"{li['lds_bytes_per_codeword']:9d}", flush=True)
+              f"{li['lds_bytes_per_codeword']:9d}  {d.kernel_name(L > 1)}", flush=True)
         del llr, info, out, ok, d
