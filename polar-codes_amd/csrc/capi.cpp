@@ -119,8 +119,6 @@ struct pcd_decoder {
     uint8_t* h_res = nullptr;  // pinned staging of the results of a pipelined host call: bytes | verdicts | metrics
     size_t h_res_cap = 0;
     hipEvent_t ev_h2d[kRing] = { nullptr, nullptr, nullptr }, ev_run[kRing] = { nullptr, nullptr, nullptr };
-    float* d_f32 = nullptr;  // int8 list decoder on the lane kernel: its int8 rows widened to fp32
-    size_t d_f32_cap = 0;
     int8_t* d_i8 = nullptr;  // int8 decoders called with float rows: CharContainer::insertLlr(const float*) on the device
     size_t d_i8_cap = 0;
     uint8_t* d_out = nullptr;
@@ -815,6 +813,7 @@ int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
     P.arena = d->d_arena;
     const bool diag_k = P.trace != nullptr || P.cycles != nullptr || P.ablate != 0;
     if (d->lane_k) HIP_TRY(d->lane_k->launch(P, diag_k, grid, st));
+    else if (!P.chr && P.i8rows) HIP_TRY((d->lane_big ? pamd::launch_scl_lane_i8_big : pamd::launch_scl_lane_i8)(P, diag_k, grid, st));
     else if (P.chr && d->lane_big) HIP_TRY(pamd::launch_scl_lane_char_big(P, diag_k, grid, st));
     else if (P.chr) HIP_TRY(pamd::launch_scl_lane_char(P, diag_k, grid, st));
     else if (d->lane_big) HIP_TRY(pamd::launch_scl_lane_big(P, diag_k, grid, st));
@@ -824,16 +823,11 @@ int run_scl_lane(pcd_decoder* d, pamd::DecodeParams P, hipStream_t st)
 
 int run_scl(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
-    if (d->has_lane && !(i8 && P.rowidx && !P.rows_dev)) {
-        if (i8) {  // the lane kernel reads fp32 rows: int8 rows are widened first (exact: bitcontainer.cpp:202-207; 4 bytes per LLR of scratch)
-            int rc = grow(d->d_f32, d->d_f32_cap, (size_t)P.rows * d->N * sizeof(float));
-            if (rc) return rc;
-            if (P.rowidx)  // (the list pass of "mixed": only the listed rows, each at its place in the full batch)
-                HIP_TRY(pamd::launch_i8_rows_to_f32(reinterpret_cast<const int8_t*>(P.llr), d->d_f32, P.rowidx, P.rows_dev, P.rows, d->N, st));
-            else
-                HIP_TRY(pamd::launch_i8_to_f32(reinterpret_cast<const int8_t*>(P.llr), d->d_f32, (size_t)P.rows * d->N, st));
-            P.llr = d->d_f32;
-        }
+    // The lane-per-path kernels read the rows as they are: fp32, or int8 widened in the top-of-tree pass (round 4: no widened copy
+    // of the batch any more).  The int8 decoder's kernels read int8 rows only (float rows were converted by the caller), the float
+    // decoder's have an int8-row twin in the default geometry; elsewhere int8 rows into the float decoder keep the path groups.
+    if (d->has_lane && (!i8 || d->dectype == 0 || !d->lane_k)) {
+        P.i8rows = i8 ? 1u : 0u;
         return run_scl_lane(d, P, st);
     }
     P.prog = d->d_scl_prog;
@@ -1315,7 +1309,6 @@ void pcd_destroy(pcd_decoder* d)
     }
     if (d->d_in) (void)hipFree(d->d_in);
     if (d->d_i8) (void)hipFree(d->d_i8);
-    if (d->d_f32) (void)hipFree(d->d_f32);
     for (int b = 0; b < pcd_decoder::kRing; ++b) {
         if (d->h_ring[b]) (void)hipHostFree(d->h_ring[b]);
         if (d->d_ring[b]) (void)hipFree(d->d_ring[b]);

@@ -41,6 +41,8 @@ struct DecodeParams {
     uint32_t prog_len;
     uint32_t ablate;         // perf experiments only (PCD_ABLATE): skips parts of the work, results are wrong
     uint32_t* cycles;        // diagnostics (nullable): row 0 only, s_memtime cycles spent per program instruction
+    uint32_t i8rows;         // lane kernels (checked by their launchers): llr points at int8 rows, 1 byte per LLR (at the end: the
+                             // kernels of the BASELINE configurations keep their argument offsets, and with them their code)
 };
 
 // occupancy != nullptr: do not launch, return the resident workgroups per CU (occupancy API) in *occupancy
@@ -56,6 +58,9 @@ hipError_t launch_scl_lane_big(const DecodeParams& P, bool diag, unsigned grid, 
 // the int8 decoder's instantiation (scl_lane_char.hip); no leaves of 256 LLRs
 hipError_t launch_scl_lane_char(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);
 hipError_t launch_scl_lane_char_big(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);  // (scl_lane_char_big.hip)
+// the float decoder on int8 rows (decode_vector(const char*)): scl_lane_i8.hip / scl_lane_i8_big.hip
+hipError_t launch_scl_lane_i8(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);
+hipError_t launch_scl_lane_i8_big(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);
 unsigned scl_lane_arena_words();
 // two-lanes-per-codeword SC kernel (sc_pair_kernel.hip): N = 1024, fp32 or int8 rows (P.chr: the int8 decoder, int8 rows only); P.prog = the PR_* program, P.ext / P.syn_bytes as for
 // the lane kernel; single-wave workgroups with 40 KB of dynamic LDS
@@ -63,11 +68,6 @@ unsigned scl_lane_arena_words();
 hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
 // CharContainer::insertLlr(const float*) (bitcontainer.cpp:449-516, N >= 8): round to nearest even, saturate to int8
 hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st);
-// exact widening of int8 rows (n a multiple of 4): the int8 list decoder's lane-per-path kernel reads fp32 rows
-hipError_t launch_i8_to_f32(const int8_t* in, float* out, size_t n, hipStream_t st);
-// the rows rowidx[0 .. *count) only (count in device memory, at most rows_max), each at its own place in the full batch
-hipError_t launch_i8_rows_to_f32(const int8_t* in, float* out, const uint32_t* rowidx, const uint32_t* count, uint32_t rows_max, uint32_t N,
-                                 hipStream_t st);
 hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,
                                  hipStream_t st);
 

@@ -875,31 +875,6 @@ __global__ void f32_to_i8_kernel(const float* in, int8_t* out, size_t n)
     }
 }
 
-// int8 rows for the lane-per-path list kernel of the int8 decoder, which reads fp32 rows like its float twin
-__global__ void i8_to_f32_kernel(const int8_t* in, float* out, size_t n4)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t w = reinterpret_cast<const uint32_t*>(in)[i];
-        reinterpret_cast<float4*>(out)[i] = make_float4((float)(int8_t)(w & 0xFFu), (float)(int8_t)((w >> 8) & 0xFFu), (float)(int8_t)((w >> 16) & 0xFFu),
-                                                        (float)(int8_t)(w >> 24));
-    }
-}
-
-// ... and only the rows of a row list whose length sits in device memory (the list pass of "mixed" on int8 rows): row r of the
-// list is widened in place of row r of the full batch, one workgroup per row at a time
-__global__ void i8_rows_to_f32_kernel(const int8_t* in, float* out, const uint32_t* rowidx, const uint32_t* count, uint32_t n4_per_row)
-{
-    const uint32_t n = *count;
-    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
-        const size_t base = (size_t)rowidx[r] * n4_per_row;
-        for (uint32_t i = threadIdx.x; i < n4_per_row; i += blockDim.x) {
-            const uint32_t w = reinterpret_cast<const uint32_t*>(in)[base + i];
-            reinterpret_cast<float4*>(out)[base + i] = make_float4((float)(int8_t)(w & 0xFFu), (float)(int8_t)((w >> 8) & 0xFFu),
-                                                                   (float)(int8_t)((w >> 16) & 0xFFu), (float)(int8_t)(w >> 24));
-        }
-    }
-}
-
 // =============================================================================================
 //  launchers
 // =============================================================================================
@@ -1007,22 +982,6 @@ hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t 
     if (n == 0) return hipSuccess;
     const size_t blocks = std::min<size_t>((n + 255) / 256, (size_t)1 << 20);  // (grid-stride loop: any n)
     hipLaunchKernelGGL(f32_to_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
-    return hipGetLastError();
-}
-
-hipError_t launch_i8_to_f32(const int8_t* in, float* out, size_t n, hipStream_t st)
-{
-    if (n == 0) return hipSuccess;  // (n: a multiple of 4 -- rows of at least 8 positions)
-    const size_t n4 = n / 4, blocks = std::min<size_t>((n4 + 255) / 256, (size_t)1 << 20);
-    hipLaunchKernelGGL(i8_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n4);
-    return hipGetLastError();
-}
-
-hipError_t launch_i8_rows_to_f32(const int8_t* in, float* out, const uint32_t* rowidx, const uint32_t* count, uint32_t rows_max, uint32_t N,
-                                 hipStream_t st)
-{
-    if (rows_max == 0) return hipSuccess;
-    hipLaunchKernelGGL(i8_rows_to_f32_kernel, dim3(std::min<uint32_t>(rows_max, 8192u)), dim3(256), 0, st, in, out, rowidx, count, N / 4u);
     return hipGetLastError();
 }
 

@@ -40,6 +40,9 @@
 #ifndef LN_CHAR
 #define LN_CHAR 0
 #endif
+#ifndef LN_I8ROWS
+#define LN_I8ROWS LN_CHAR  // the channel rows are int8 (1 byte per LLR): always for the int8 decoder; for the float decoder in scl_lane_i8rows*.hip
+#endif
 #ifndef LN_LOGN
 #define LN_LOGN 10
 #endif
@@ -47,8 +50,9 @@
 #define LN_LCL 3
 #endif
 #define LN_GEO_DEFAULT (LN_LOGN == 10 && LN_LCL == 3)
-#if !LN_GEO_DEFAULT
-// (the stubs of the other geometries name their kernel and launcher themselves: LN_KERNEL_NAME, LN_LAUNCH_NAME)
+#ifdef LN_KERNEL_NAME
+// (the stubs of the other geometries -- and of the float decoder on int8 rows -- name their kernel and launcher themselves:
+//  LN_KERNEL_NAME, LN_LAUNCH_NAME, LN_ARENA_NAME)
 #define scl_lane_kernel LN_KERNEL_NAME
 #elif LN_BIG && LN_CHAR
 #define scl_lane_kernel scl_lane_char_big_kernel
@@ -66,6 +70,11 @@
 namespace pamd {
 namespace lane {
 
+#if LN_I8ROWS
+using RowT = int8_t;  // element type of the channel rows in HBM
+#else
+using RowT = float;
+#endif
 // ---- register map (per lane) ---------------------------------------------------------------------------------------
 constexpr int KV = 104;      // the compiler's VGPR budget: v0 .. v103
 constexpr int RBL0 = 104;    // left-child / root output bits of stage t <= 5: v[104 + t]
@@ -1536,6 +1545,12 @@ __device__ __forceinline__ void op_combine(Path& p, uint32_t side)
     }
 }
 
+// int8 channel rows: a dword of four LLRs in v[R] -> four floats in v[R .. R + 3] (v_cvt_f32_i32 on a sign-extended byte)
+#define LN_WIDEN4(R_)                                                                                                   \
+    "v_cvt_f32_i32_sdwa v[" R_ "+3], sext(v[" R_ "]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3\n\t"           \
+    "v_cvt_f32_i32_sdwa v[" R_ "+2], sext(v[" R_ "]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n\t"           \
+    "v_cvt_f32_i32_sdwa v[" R_ "+1], sext(v[" R_ "]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"           \
+    "v_cvt_f32_i32_sdwa v[" R_ "], sext(v[" R_ "]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0\n\t"
 #if LN_LOGN == 10
 // ---- the top of the tree -------------------------------------------------------------------------------------------------
 // LN_VT: the stage-8 block of this path from the channel row (stage 9 = f / g of the row is never stored), optionally
@@ -1545,6 +1560,31 @@ __device__ __forceinline__ void op_combine(Path& p, uint32_t side)
 // the loads of step j + 1 are issued before step j is computed.
 constexpr int VT_SET0 = 128, VT_SET1 = 160, VT_SET2 = 192, VT_SET3 = 224;  // (v254 / v255 are free as well)
 // set layout: +0 row[e], +4 row[e+256], +8 row[e+512], +12 row[e+768], +16 row[e+128], +20 row[e+384], +24 row[e+640], +28 row[e+896]
+// (int8 rows: a chunk of four LLRs is one dword, fetched into the first register of its group of four and widened in place by
+//  vt_widen -- v_cvt_f32_i32 with a sign-extended byte select, one instruction per LLR)
+template <int SET>
+__device__ __forceinline__ void vt_load(const int8_t* rowp)
+{
+    asm volatile(
+        "global_load_dword v[%[r]], %[a], off\n\t"
+        "global_load_dword v[%[r]+4], %[a], off offset:256\n\t"
+        "global_load_dword v[%[r]+8], %[a], off offset:512\n\t"
+        "global_load_dword v[%[r]+12], %[a], off offset:768\n\t"
+        "global_load_dword v[%[r]+16], %[a], off offset:128\n\t"
+        "global_load_dword v[%[r]+20], %[a], off offset:384\n\t"
+        "global_load_dword v[%[r]+24], %[a], off offset:640\n\t"
+        "global_load_dword v[%[r]+28], %[a], off offset:896"
+        :
+        : [r] "n"(SET), [a] "v"(rowp)
+        : "memory");
+}
+template <int SET>
+__device__ __forceinline__ void vt_widen()
+{
+    asm volatile("s_waitcnt vmcnt(24)\n\t" LN_WIDEN4("%[r]") LN_WIDEN4("%[r]+4") LN_WIDEN4("%[r]+8") LN_WIDEN4("%[r]+12") LN_WIDEN4("%[r]+16")
+                 LN_WIDEN4("%[r]+20") LN_WIDEN4("%[r]+24") LN_WIDEN4("%[r]+28") "s_nop 0" ::[r] "n"(SET)
+                 : "memory");
+}
 template <int SET>
 __device__ __forceinline__ void vt_load(const float* rowp)
 {
@@ -1582,6 +1622,9 @@ __device__ __forceinline__ void vt_step(uint32_t wa, uint32_t wb, uint32_t wc, u
     "v_fma_f32 v[" D_ "+1], v[" D_ "+1], %[t1], v[" B_ "+1]\n\t"  \
     "v_fma_f32 v[" D_ "+2], v[" D_ "+2], %[t2], v[" B_ "+2]\n\t"  \
     "v_fma_f32 v[" D_ "+3], v[" D_ "+3], %[t3], v[" B_ "+3]\n\t"
+#if LN_I8ROWS
+    vt_widen<SET>();
+#endif
     // stage 9 (in place): a -> +0, b -> +4, c -> +16, d -> +20
     if constexpr (R9) {
         asm volatile("s_waitcnt vmcnt(24)\n\t" LN_VG("%[r]", "%[r]+8", "%[wa]") LN_VG("%[r]+4", "%[r]+12", "%[wb]")
@@ -1679,7 +1722,7 @@ __device__ __forceinline__ void vt_words(const uint32_t* bl9, const uint32_t* bl
     }
 }
 template <bool R9, bool ISG, bool F8, bool CH>
-__device__ __forceinline__ void op_vt_t(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
+__device__ __forceinline__ void op_vt_t(Path& p, const RowT* chan, uint32_t absmask, uint32_t signmask)
 {
     if (R9 && !ISG) p.set_field(10);  // the G of the root directly follows its left child: the bits are this lane's own
     const uint32_t* bl9 = p.arena + AR_BL9 + p.owner(10);  // the root's left-child bits: with the slot holder
@@ -1687,8 +1730,8 @@ __device__ __forceinline__ void op_vt_t(Path& p, const float* chan, uint32_t abs
     const uint32_t* s8base = p.arena + AR_S8;
     uint32_t s8off = (uint32_t)p.lane * 16u;               // byte offset of chunk j of this lane's column (+ 32 KB: chunk j + 32)
     uint32_t s7addr = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.lane * 16u;
-    const float* rowp = chan;
-    const float* const rowend = chan + 4 * 31;
+    const RowT* rowp = chan;
+    const RowT* const rowend = chan + 4 * 31;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing older in flight: the counted waits below see only this op's accesses)
     uint32_t wa, wb, wc, wd, ue, uf;
     vt_words<R9, ISG>(bl9, bl8, 0, wa, wb, wc, wd, ue, uf);
@@ -1734,12 +1777,12 @@ __device__ __forceinline__ void op_vt_t(Path& p, const float* chan, uint32_t abs
 // the other seven of the codeword idle.  The steps do not depend on the path, so lane q does the steps j = q, q + 8,
 // q + 16, q + 24 and stores into the column of the codeword's first lane, where the path lives.
 template <bool CH>
-__device__ __forceinline__ void op_vt_first(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
+__device__ __forceinline__ void op_vt_first(Path& p, const RowT* chan, uint32_t absmask, uint32_t signmask)
 {
     const uint32_t* s8base = p.arena + AR_S8;
     const uint32_t s8off = (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
     const uint32_t s7addr = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
-    const float* rowp = chan + 4 * p.q;
+    const RowT* rowp = chan + 4 * p.q;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     vt_load<VT_SET0>(rowp);
     vt_load<VT_SET1>(rowp + 32);
@@ -1759,12 +1802,12 @@ __device__ __forceinline__ void op_vt_first(Path& p, const float* chan, uint32_t
 #else
 // (16 / 32 lanes per codeword: lane q does the steps j = q, q + LC, ... < 32)
 template <bool CH>
-__device__ __forceinline__ void op_vt_first(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
+__device__ __forceinline__ void op_vt_first(Path& p, const RowT* chan, uint32_t absmask, uint32_t signmask)
 {
     const uint32_t* s8base = p.arena + AR_S8;
     const uint32_t s8off = (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
     const uint32_t s7addr = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
-    const float* rowp = chan + 4 * p.q;
+    const RowT* rowp = chan + 4 * p.q;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     vt_load<VT_SET0>(rowp);
     if constexpr (LC == 16) vt_load<VT_SET1>(rowp + 64);
@@ -1778,7 +1821,7 @@ __device__ __forceinline__ void op_vt_first(Path& p, const float* chan, uint32_t
 }
 #endif
 template <bool CH>
-__device__ __forceinline__ void op_vt(Path& p, uint32_t off, const float* chan, uint32_t absmask, uint32_t signmask)
+__device__ __forceinline__ void op_vt(Path& p, uint32_t off, const RowT* chan, uint32_t absmask, uint32_t signmask)
 {
     // (bit 2 of off -- "the F of stage 8 follows" -- needs no variant of its own: stage 7 is dead whenever it is clear, so the
     //  F is computed and stored regardless)
@@ -1830,6 +1873,26 @@ struct VtgGeo {
     __host__ __device__ static constexpr int wbase(int l) { return NR - (NR >> l); }  // first word of level l
 };
 // the 2^LV row chunks of one step: base = the row at element 4 c
+// (int8 rows: one dword per chunk into the first register of its group, 256 bytes apart; widened in place by vtg_widen)
+template <int S, int LV>
+__device__ __forceinline__ void vtg_load(const int8_t* base)
+{
+    static_for<(1 << LV)>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        const int8_t* pm = base;
+        asm volatile("global_load_dword v[%0], %1, off offset:%2" ::"n"(S + 4 * k), "v"(pm), "n"(k * 256) : "memory");
+    });
+}
+template <int S, int LV, typename RT>
+__device__ __forceinline__ void vtg_widen()
+{
+    if constexpr (sizeof(RT) == 1) {
+        static_for<(1 << LV)>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            asm volatile(LN_WIDEN4("%[r]") "s_nop 0" ::[r] "n"(S + 4 * k));
+        });
+    }
+}
 template <int S, int LV>
 __device__ __forceinline__ void vtg_load(const float* base)
 {
@@ -1938,8 +2001,8 @@ __device__ __forceinline__ void vtg_words_take()
 }
 // TOP: the stage of the source row (LOGN: the channel row; lower: a virtual row), LV = TOP - 8 levels; gm bit l: the op at
 // stage TOP - l is a g
-template <int TOP, bool CH>
-__device__ __forceinline__ void op_vtg_t(Path& p, uint32_t gm, const float* chan, uint32_t absmask, uint32_t signmask)
+template <int TOP, bool CH, typename RT>
+__device__ __forceinline__ void op_vtg_t(Path& p, uint32_t gm, const RT* chan, uint32_t absmask, uint32_t signmask)
 {
     constexpr int LV = TOP - 8;
     using G = VtgGeo<LV>;
@@ -1958,9 +2021,9 @@ __device__ __forceinline__ void op_vtg_t(Path& p, uint32_t gm, const float* chan
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing older in flight: the counted waits below see only this op's accesses)
     vtg_words_issue<LV>(gm, bo, 0, abase);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const float* const rowlast = chan + 4 * 63;
+    const RT* const rowlast = chan + 4 * 63;
     static_for<NS - 1>([&](auto J) { vtg_load<128 + SW * decltype(J)::value, LV>(chan + 4 * decltype(J)::value); });
-    const float* rowp = chan + 4 * (NS - 1);  // the row at the chunk of the next step to be loaded
+    const RT* rowp = chan + 4 * (NS - 1);  // the row at the chunk of the next step to be loaded
 #pragma unroll 1
     for (uint32_t g = 0; g < 8; ++g) {
         vtg_words_take<LV>();
@@ -1976,6 +2039,7 @@ __device__ __forceinline__ void op_vtg_t(Path& p, uint32_t gm, const float* chan
                 vtg_load<128 + SW * ((j + NS - 1) % NS), LV>(rowp < rowlast ? rowp : rowlast);
                 rowp += 4;
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * G::NR) : "memory");
+                vtg_widen<128 + SW * j, LV, RT>();
                 vtg_levels<128 + SW * j, LV, CH>(gm, 31u - 4u * ((i + (uint32_t)j) & 7u), absmask, signmask, p.c127, p.m128);
                 if (second) vtg_tail_second<128 + SW * j, CH>(s8col + 1024u * c, s8base, s7col + 1024u * (c - 32u), absmask, p.c127);
                 else vtg_tail_first<128 + SW * j>(s8col + 1024u * c, s8base, s7col + 1024u * c);
@@ -2020,7 +2084,7 @@ __device__ __forceinline__ void vtg_levels_first(float* vrow, uint32_t c, uint32
     });
 }
 template <int LV, bool CH>
-__device__ __forceinline__ void op_vtg_first(Path& p, const float* chan, uint32_t absmask, uint32_t signmask)
+__device__ __forceinline__ void op_vtg_first(Path& p, const RowT* chan, uint32_t absmask, uint32_t signmask)
 {
     const uint32_t* s8base = p.arena + AR_S8;
     const uint32_t s8col = (uint32_t)p.g0 * 16u, s7col = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u;
@@ -2030,11 +2094,13 @@ __device__ __forceinline__ void op_vtg_first(Path& p, const float* chan, uint32_
     for (uint32_t c = (uint32_t)p.q; c < 32u; c += (uint32_t)LC) {
         vtg_load<128, LV>(chan + 4 * c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vtg_widen<128, LV, RowT>();
         vtg_levels_first<128, LV, CH>(vrow, c, absmask, p.c127);
         vtg_tail_first<128>(s8col + 1024u * c, s8base, s7col + 1024u * c);
         vtg_fetch_parked(s7col + 1024u * c);
         vtg_load<128, LV>(chan + 4 * (c + 32u));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vtg_widen<128, LV, RowT>();
         vtg_levels_first<128, LV, CH>(vrow, c + 32u, absmask, p.c127);
         vtg_tail_second<128, CH>(s8col + 1024u * (c + 32u), s8base, s7col + 1024u * c, absmask, p.c127);
     }
@@ -2044,7 +2110,7 @@ __device__ __forceinline__ void op_vtg_first(Path& p, const float* chan, uint32_
 }
 // off: bit l = level l (0 = the channel row's own f / g, i.e. the op of the root) is a g
 template <bool CH>
-__device__ __forceinline__ void op_vtg(Path& p, uint32_t off, const float* chan, uint32_t absmask, uint32_t signmask)
+__device__ __forceinline__ void op_vtg(Path& p, uint32_t off, const RowT* chan, uint32_t absmask, uint32_t signmask)
 {
     const uint32_t gm = off & ((1u << TOPD) - 1u);
     if (gm == 0u && p.P == 1u) {
@@ -2056,17 +2122,18 @@ __device__ __forceinline__ void op_vtg(Path& p, uint32_t off, const float* chan,
     const uint32_t l0 = gm ? (uint32_t)__builtin_ctz(gm) : 0u;
     switch (l0) {
 #if LN_LOGN >= 12
-    case 3: op_vtg_t<LOGN - 3, CH>(p, gm >> 3, vrow + vrow_off(LOGN - 3), absmask, signmask); break;
+    case 3: op_vtg_t<LOGN - 3, CH, float>(p, gm >> 3, vrow + vrow_off(LOGN - 3), absmask, signmask); break;
 #endif
 #if LN_LOGN >= 11
-    case 2: op_vtg_t<LOGN - 2, CH>(p, gm >> 2, vrow + vrow_off(LOGN - 2), absmask, signmask); break;
-    case 1: op_vtg_t<LOGN - 1, CH>(p, gm >> 1, vrow + vrow_off(LOGN - 1), absmask, signmask); break;
+    case 2: op_vtg_t<LOGN - 2, CH, float>(p, gm >> 2, vrow + vrow_off(LOGN - 2), absmask, signmask); break;
+    case 1: op_vtg_t<LOGN - 1, CH, float>(p, gm >> 1, vrow + vrow_off(LOGN - 1), absmask, signmask); break;
 #endif
-    default: op_vtg_t<LOGN, CH>(p, gm, chan, absmask, signmask); break;
+    default: op_vtg_t<LOGN, CH, RowT>(p, gm, chan, absmask, signmask); break;
     }
 }
 #undef LN_VGS
 #endif  // LN_LOGN != 10
+#undef LN_WIDEN4
 
 // stage 8 (arena column) -> stage 7 (LDS column): kind 0 = F, 1 = G (column of the slot owner), 2 = a + b (= G with zero
 // bits).  Eight steps per batch: their sixteen 16-byte loads go out together into v[128 .. 191] (dead stages), the steps
@@ -2213,7 +2280,8 @@ __device__ __forceinline__ void op_fg_reg(Path& p, uint32_t absmask, uint32_t si
 // =====================================================================================================================
 //  kernel
 // =====================================================================================================================
-// CH: the int8 list decoder SclFipChar (rows arrive as fp32 all the same: the host converts int8 rows first)
+// CH: the int8 list decoder SclFipChar.  LN_I8ROWS: the channel rows are int8 and are widened in the top-of-tree pass (always
+// for CH; the float decoder called with int8 rows -- decode_vector(const char*) -- has its own translation units)
 template <bool DIAG, bool CH = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(lane::KV)))
 void scl_lane_kernel(const DecodeParams P)
@@ -2250,7 +2318,7 @@ void scl_lane_kernel(const DecodeParams P)
         const bool live = ci < nrows;
         const uint32_t cj = live ? ci : grp * (uint32_t)CPW;
         const uint32_t row = P.rowidx ? P.rowidx[cj] : cj;
-        const float* chan = reinterpret_cast<const float*>(P.llr) + (size_t)row * N;
+        const RowT* chan = reinterpret_cast<const RowT*>(P.llr) + (size_t)row * N;
         p.metric = 0.0f;
         p.pl = p.q == 0 ? 0u : PL_DEAD;
         p.P = 1;
@@ -2612,14 +2680,16 @@ void scl_lane_kernel(const DecodeParams P)
     }
 }
 
-#if !LN_GEO_DEFAULT
-// other geometries (scl_lane_n*_l*.hip): one instantiation per translation unit, named by the stub
+#ifdef LN_KERNEL_NAME
+// other geometries (scl_lane_n*_l*.hip), the float decoder on int8 rows (scl_lane_i8*.hip): one instantiation per translation unit, named by the stub
 template __global__ void scl_lane_kernel<false, LN_CHAR != 0>(const DecodeParams);
 
 unsigned LN_ARENA_NAME() { return lane::AR_WORDS; }
 hipError_t LN_LAUNCH_NAME(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st)
 {
-    if ((P.chr != 0) != (LN_CHAR != 0) || P.logN != (uint32_t)lane::LOGN || P.L > (uint32_t)lane::LC) return hipErrorInvalidValue;
+    // (P.i8rows: what the caller's rows are; this kernel reads one kind only)
+    if ((P.chr != 0) != (LN_CHAR != 0) || (P.i8rows != 0) != (LN_I8ROWS != 0) || P.logN != (uint32_t)lane::LOGN || P.L > (uint32_t)lane::LC)
+        return hipErrorInvalidValue;
 #ifdef PAMD_DIAG
     if (diag) {
         hipLaunchKernelGGL((scl_lane_kernel<true, LN_CHAR != 0>), dim3(grid), dim3(64), lane::LDS_WORDS * 4, st, P);
