@@ -48,6 +48,22 @@ static int run_cpu()
         if (ref->getErrorDetectionMode() != buf) return fail(std::string("detector of the handle: ") + buf);
     }
     if (gpu->packedOutput() == nullptr) return fail("packedOutput");
+    if (gpu->inputContainer() == nullptr) return fail("inputContainer: setSignal(const char*) is not virtual and writes into it");
+    {   // the int8 flavour: a CharContainer behind the same interface; both setSignal overloads must land in it without a GPU
+        std::unique_ptr<Decoding::Decoder> chr(new Decoding::GpuChar(N, L, frozen));
+        std::unique_ptr<Decoding::Decoder> cref(Decoding::create(N, L, frozen, "char"));
+        if (chr->infoLength() != cref->infoLength() || chr->getListSize() != cref->getListSize()) return fail("GpuChar getters");
+        std::vector<char> r8(N, 5);
+        std::vector<float> rf(N, -3.25f);
+        chr->setSignal(r8.data());
+        if (static_cast<CharContainer*>(chr->inputContainer())->data()[7] != 5) return fail("GpuChar setSignal(const char*)");
+        chr->setSignal(rf.data());
+        cref->setSignal(rf.data());
+        if (static_cast<CharContainer*>(chr->inputContainer())->data()[9] != static_cast<CharContainer*>(cref->inputContainer())->data()[9])
+            return fail("GpuChar setSignal(const float*) quantises differently from the reference's char decoder");
+        gpu->setSignal(r8.data());  // (GpuFloat: the int8 row is widened into its FloatContainer -- used to dereference a null container)
+        if (static_cast<FloatContainer*>(gpu->inputContainer())->data()[3] != 5.0f) return fail("GpuFloat setSignal(const char*)");
+    }
     std::printf("cpu ok: GpuFloat constructs through the reference's Decoder interface; getters agree with Decoding::create()\n");
     return 0;
 }
@@ -60,16 +76,20 @@ static int run_gpu(const char* path)
     f.read(reinterpret_cast<char*>(h), sizeof h);
     if (h[0] != 0x31584650u) return fail("bad fixture magic");
     const uint32_t N = h[1], L = h[3], nF = h[4], count = h[5], nb = h[6], crcsize = h[7], crcnr = h[8], dectype = h[9];
-    if ((dectype & 0xFF) != 0) return fail("float-decoder fixture expected");
+    const bool chr = (dectype & 0xFF) == 3;        // the int8 decoders (type "char"): GpuChar
+    const bool i8rows = chr || (dectype & 0x200);  // the row went through decode_vector(const char*) in the reference
+    if ((dectype & 0xFF) != 0 && !chr) return fail("float- or char-decoder fixture expected");
     std::vector<uint32_t> fz(nF);
     f.read(reinterpret_cast<char*>(fz.data()), 4 * nF);
     std::vector<unsigned> frozen(fz.begin(), fz.end());
-    Decoding::GpuFloat gpu(N, L, frozen);
-    Decoding::Decoder& dec = gpu;  // everything below goes through the reference's base class
+    std::unique_ptr<Decoding::Decoder> owner(chr ? static_cast<Decoding::Decoder*>(new Decoding::GpuChar(N, L, frozen))
+                                                 : static_cast<Decoding::Decoder*>(new Decoding::GpuFloat(N, L, frozen)));
+    Decoding::Decoder& dec = *owner;  // everything below goes through the reference's base class
     dec.setSystematic(!(dectype & 0x100));
     dec.setErrorDetection(ErrorDetection::create(crcsize, crcnr ? "crcnr" : "crc"));
     const size_t rec = 4 * (size_t)N + nb + nb + 1 + 1 + 4 * (size_t)L;
     std::vector<char> row(rec);
+    std::vector<char> row8(N);
     std::vector<unsigned char> out(nb);
     unsigned bad = 0;
     for (uint32_t r = 0; r < count; ++r) {
@@ -77,7 +97,13 @@ static int run_gpu(const char* path)
         const float* llr = reinterpret_cast<const float*>(row.data());
         const unsigned char* want = reinterpret_cast<const unsigned char*>(row.data()) + 4 * (size_t)N + nb;
         const bool want_ok = want[nb] != 0;
-        const bool ok = dec.decode_vector(llr, out.data());  // Decoder::decode_vector decoder.cpp:154-167
+        bool ok;
+        if (i8rows) {  // the NON-virtual overload: Decoder::decode_vector(const char*, void*) decoder.cpp:169-181 -> setSignal(const char*)
+            for (uint32_t i = 0; i < N; ++i) row8[i] = (char)(int)llr[i];  // (the fixture stores the int8 values as floats)
+            ok = dec.decode_vector(row8.data(), out.data());
+        } else {
+            ok = dec.decode_vector(llr, out.data());  // Decoder::decode_vector decoder.cpp:154-167
+        }
         if (ok != want_ok || std::memcmp(out.data(), want, nb) != 0 || std::memcmp(dec.packedOutput(), want, nb) != 0) ++bad;
     }
     if (bad) return fail(std::to_string(bad) + " of " + std::to_string(count) + " rows differ from the reference's CPU decoder");
