@@ -473,3 +473,11 @@ def test_host_compilers_under_sanitizers(built_library, tmp_path):
     assert m and int(m.group(2)) == n_list - n_accept and int(m.group(1)) == n_list + n_accept, (r3.stdout, n_list, n_accept)
     r4 = subprocess.run([exe, "fuzz", "10000", "20261005"], capture_output=True, text=True, env=env, timeout=900)
     assert r4.returncode == 0 and "hostcheck ok: 10000 sets" in r4.stdout, r4.stdout + r4.stderr
+
+
+def test_generated_asm_runs_match_their_generator():
+    """csrc/lane_runs.inc and csrc/pair_runs.inc (1 154 lines of asm-run macros the lane / pair kernels use) are the output of
+    tools/gen_runs.py: the committed files must equal what the generator writes"""
+    import subprocess
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "gen_runs.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
