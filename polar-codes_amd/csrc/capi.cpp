@@ -1245,13 +1245,15 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         // Round 4: the same kernel under other geometries (scl_lane_geo.h) -- N = 512 / 2048 / 4096 and 16 / 32 lanes per codeword;
         // the default geometry keeps its rule, the others take every tree the lowering can express from 48 leaves on.
         const bool geo_default = d->logN == 10 && d->L > 4 && d->L <= 8;
-        const pamd::LaneKernel* lk = geo_default ? nullptr : pamd::find_lane_kernel(d->logN, d->L, chr);
-        if (lk && !PAMD_ENV("PCD_NO_LANE") && (d->scl_prog.leaves >= 48u || PAMD_ENV("PCD_FORCE_LANE"))) {
-            bool big = false;
-            if (pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr, &big)) {
-                d->has_lane = true;
-                d->lane_k = lk;
-                d->lane_cpw = 64u >> lk->lcl;
+        if (!geo_default && pamd::find_lane_kernel(d->logN, d->L, chr, false) && !PAMD_ENV("PCD_NO_LANE") &&
+            (d->scl_prog.leaves >= 48u || PAMD_ENV("PCD_FORCE_LANE"))) {
+            bool big = false, hi = false;
+            if (pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr, &big, &hi)) {
+                if (const pamd::LaneKernel* lk = pamd::find_lane_kernel(d->logN, d->L, chr, hi)) {
+                    d->has_lane = true;
+                    d->lane_k = lk;
+                    d->lane_cpw = 64u >> lk->lcl;
+                }
             }
         }
         if (geo_default && (!chr || !PAMD_ENV("PCD_NO_CHAR_LANE")) && !PAMD_ENV("PCD_NO_LANE")) {

@@ -5,8 +5,9 @@
 
 namespace pamd {
 
-bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool* needs_big)
+bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool* needs_big, bool* needs_hi)
 {
+    if (needs_hi) *needs_hi = false;
     out = Program();
     out.leaves = scl.leaves;
     out.inner = scl.inner;
@@ -36,8 +37,10 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
                 // that recomputes the stages in between (op_vtg); off bit l = the op at stage logN - l is a G
                 if (x.stage > logN) return false;
                 isg_at[x.stage] = isg;
-                if (x.stage > 9) {  // must be followed by the F of the stage below (no leaf above stage 8)
-                    if (k + 1 >= v.size() || v[k + 1].op != SCL_F || v[k + 1].stage + 1u != x.stage) return false;
+                if (x.stage > 9) {  // must be followed by the F of the stage below, or by an all-frozen leaf of 512 / 1024 LLRs
+                    if (k + 1 >= v.size() || v[k + 1].stage + 1u != x.stage) return false;
+                    const bool r0_high = v[k + 1].op == SCL_R0 && logN >= 11 && v[k + 1].stage <= 10 && v[k + 1].stage + 1u <= logN - 0u && v[k + 1].stage < logN;
+                    if (v[k + 1].op != SCL_F && !r0_high) return false;
                     continue;
                 }
                 unsigned gm = 0;
@@ -76,6 +79,16 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
             put(LN_C, x.stage, x.side, 0);
             break;
         case SCL_R0:
+            if (x.stage > 8 && logN >= 11 && x.stage <= 10 && x.stage < logN) {
+                // an all-frozen leaf of 512 / 1024 LLRs: recomputed from the channel row by the kernel; off bit l = the op at
+                // stage logN - l is a G (the stages logN .. stage + 1)
+                unsigned gm = 0;
+                for (unsigned t = x.stage + 1u; t <= logN; ++t)
+                    if (isg_at[t]) gm |= 1u << (logN - t);
+                put(LN_R0, x.stage, x.side, gm);
+                if (needs_hi) *needs_hi = true;
+                break;
+            }
             if (x.stage > 8 || x.stage < 1) return false;
             put(LN_R0, x.stage, x.side, 0);
             break;
@@ -97,8 +110,19 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
         }
     }
     put(OP_END, 0, 0, 0);
-    // the first op must be the left-left pass over the channel row
-    if (out.ins.empty() || out.ins[0].op != LN_VT) return false;
+    // the first op must be the left-left pass over the channel row -- or, at N >= 2048, an all-frozen leaf above stage 8: then
+    // the virtual rows that pass would have produced come from an op of their own
+    if (out.ins.empty()) return false;
+    if (out.ins[0].op != LN_VT) {
+        if (!(logN >= 11 && out.ins[0].op == LN_R0 && out.ins[0].stage > 8)) return false;
+        Ins i;
+        i.op = (uint8_t)LN_VROWS;
+        i.stage = (uint8_t)logN;
+        i.side = 0;
+        i.pad = 0;
+        i.off = 0;
+        out.ins.insert(out.ins.begin(), i);
+    }
     // fuse what lies between two leaves into LN_WALK: [C ... C] [G | G0] [F ... F]
     std::vector<Ins> w;
     const std::vector<Ins>& o = out.ins;

@@ -94,6 +94,9 @@ enum Op : uint8_t {
     // then Fs from stage f1 down to f0, then an all-frozen leaf of stage r0 (side r0side) if the descent ends at one.
     // off: c0 | c1 << 4 | gs << 8 | kind << 12 | f1 << 16 | f0 << 20 | r0 << 24 | r0side << 28 (0 = absent)
     LN_WALK,
+    // N >= 2048: the virtual rows (the path-independent leftmost block of every stage 9 .. logN - 1) only -- emitted in front of a
+    // program that does not start with the all-f pass over the channel row (low rates: an all-frozen leaf above stage 8 comes first)
+    LN_VROWS,
     // ---- two-lanes-per-codeword SC kernel (sc_pair_kernel.hip): 32 codewords per wave ---------------------------------------
     // Lowered from the plain SC program by lower_pair (pair_program.cpp).  `stage` = LOCAL stage T = log2(block) - 1 (the
     // parent block for F / G / G0R / C / C0R / RONE), `side` = 1 when the finished block is a right child.
@@ -142,7 +145,8 @@ std::string compile_scl(unsigned N, const std::vector<uint32_t>& frozen, Program
 // Lowers a plain SCL program (compile_scl output: SCL_F / SCL_G / SCL_COMBINE + leaves) of a code with N = 512 .. 4096 to the
 // program of the lane-per-path kernel.  Returns false when the tree needs an op that kernel does not have (a leaf above
 // stage 8, ...): the caller then keeps the path-group kernels.
-bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr = false, bool* needs_big = nullptr);
+// *needs_hi: the tree has an all-frozen leaf above stage 8 (N >= 2048; the *_hi instantiations of the kernel)
+bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr = false, bool* needs_big = nullptr, bool* needs_hi = nullptr);
 // Lowers a plain SC program (compile_sc output; chr: of the int8 decoder) of a code with N = 1024 to the program of the
 // two-lanes-per-codeword kernel.  Returns false when the tree needs an op that kernel does not have (a double-SPC leaf above 128
 // positions, ...): the caller then keeps sc_decode_kernel.  *needs_big: the tree has a leaf above 128 positions (the BIG

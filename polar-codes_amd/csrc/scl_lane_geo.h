@@ -7,6 +7,9 @@
 
 #define PAMD_LANE_GEOS(X) X(12, 5) X(10, 4) X(10, 5) X(11, 3) X(9, 3) X(9, 4) X(9, 5) X(11, 4) X(11, 5) X(12, 3) X(12, 4)
 #define PAMD_LANE_GEOS_CHAR(Y)
+// N >= 2048 with an all-frozen leaf of 512 / 1024 LLRs in the tree (low rates): the same kernels with that leaf, as translation
+// units of their own (scl_lane_n<logN>_l<lcl>_hi.hip) -- the code it adds moved cfg 5 by 2.5 % when it sat in the one kernel
+#define PAMD_LANE_GEOS_HI(Z) Z(11, 3) Z(11, 4) Z(11, 5) Z(12, 3) Z(12, 4) Z(12, 5)
 
 namespace pamd {
 
@@ -16,32 +19,40 @@ namespace pamd {
 #define PAMD_LANE_DECL_CHAR(LOGN, LCL)                                                                                    \
     hipError_t launch_scl_lane_n##LOGN##_l##LCL##_char(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);   \
     unsigned scl_lane_n##LOGN##_l##LCL##_char_arena_words();
+#define PAMD_LANE_DECL_HI(LOGN, LCL)                                                                                    \
+    hipError_t launch_scl_lane_n##LOGN##_l##LCL##_hi(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);     \
+    unsigned scl_lane_n##LOGN##_l##LCL##_hi_arena_words();
 PAMD_LANE_GEOS(PAMD_LANE_DECL)
 PAMD_LANE_GEOS_CHAR(PAMD_LANE_DECL_CHAR)
+PAMD_LANE_GEOS_HI(PAMD_LANE_DECL_HI)
+#undef PAMD_LANE_DECL_HI
 #undef PAMD_LANE_DECL
 #undef PAMD_LANE_DECL_CHAR
 
 struct LaneKernel {
     unsigned logN, lcl;
     bool chr;
+    bool hi;  // carries the leaves above stage 8
     hipError_t (*launch)(const DecodeParams&, bool, unsigned, hipStream_t);
     unsigned (*arena_words)();
     const char* name;
 };
-// the kernel of (logN, list size, decoder type), or nullptr: the smallest geometry whose lanes hold the list
-inline const LaneKernel* find_lane_kernel(unsigned logN, unsigned L, bool chr)
+// the kernel of (logN, list size, decoder type, leaves above stage 8 in the tree), or nullptr: the smallest geometry whose lanes hold the list
+inline const LaneKernel* find_lane_kernel(unsigned logN, unsigned L, bool chr, bool hi)
 {
     static const LaneKernel table[] = {
-#define PAMD_LANE_ROW(LOGN, LCL) { LOGN, LCL, false, launch_scl_lane_n##LOGN##_l##LCL, scl_lane_n##LOGN##_l##LCL##_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_kernel" },
-#define PAMD_LANE_ROW_CHAR(LOGN, LCL) { LOGN, LCL, true, launch_scl_lane_n##LOGN##_l##LCL##_char, scl_lane_n##LOGN##_l##LCL##_char_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_char_kernel" },
-        PAMD_LANE_GEOS(PAMD_LANE_ROW) PAMD_LANE_GEOS_CHAR(PAMD_LANE_ROW_CHAR)
+#define PAMD_LANE_ROW(LOGN, LCL) { LOGN, LCL, false, false, launch_scl_lane_n##LOGN##_l##LCL, scl_lane_n##LOGN##_l##LCL##_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_kernel" },
+#define PAMD_LANE_ROW_HI(LOGN, LCL) { LOGN, LCL, false, true, launch_scl_lane_n##LOGN##_l##LCL##_hi, scl_lane_n##LOGN##_l##LCL##_hi_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_hi_kernel" },
+#define PAMD_LANE_ROW_CHAR(LOGN, LCL) { LOGN, LCL, true, false, launch_scl_lane_n##LOGN##_l##LCL##_char, scl_lane_n##LOGN##_l##LCL##_char_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_char_kernel" },
+        PAMD_LANE_GEOS(PAMD_LANE_ROW) PAMD_LANE_GEOS_CHAR(PAMD_LANE_ROW_CHAR) PAMD_LANE_GEOS_HI(PAMD_LANE_ROW_HI)
+#undef PAMD_LANE_ROW_HI
 #undef PAMD_LANE_ROW
 #undef PAMD_LANE_ROW_CHAR
-        { 0, 0, false, nullptr, nullptr, nullptr }
+        { 0, 0, false, false, nullptr, nullptr, nullptr }
     };
     const LaneKernel* best = nullptr;
     for (const LaneKernel* k = table; k->launch; ++k)
-        if (k->logN == logN && k->chr == chr && L <= (1u << k->lcl) && L > (1u << k->lcl) / 2 && (!best || k->lcl < best->lcl)) best = k;
+        if (k->logN == logN && k->chr == chr && k->hi == hi && L <= (1u << k->lcl) && L > (1u << k->lcl) / 2 && (!best || k->lcl < best->lcl)) best = k;
     return best;
 }
 

@@ -43,6 +43,9 @@
 #ifndef LN_I8ROWS
 #define LN_I8ROWS LN_CHAR  // the channel rows are int8 (1 byte per LLR): always for the int8 decoder; for the float decoder in scl_lane_i8rows*.hip
 #endif
+#ifndef LN_HILEAF
+#define LN_HILEAF 0  // N >= 2048: the all-frozen leaves of 512 / 1024 LLRs (low rates) -- translation units of their own (*_hi.hip), like LN_BIG
+#endif
 #ifndef LN_LOGN
 #define LN_LOGN 10
 #endif
@@ -1866,21 +1869,21 @@ constexpr int VTG_W = 108;  // v[108 .. 122]: the bit words of the current group
 constexpr int VTG_A = 240;  // a[240 .. 254]: the words of the NEXT group land here (the compiler's spills stay below a104)
 template <int LV>
 struct VtgGeo {
-    static constexpr int NR = 1 << LV;                         // row chunks per step
+    static constexpr int NR = 1 << LV;                         // row chunks per step (LV = 0: the source row is the block itself)
     static constexpr int NS = LV >= 4 ? 2 : (LV == 3 ? 4 : 8);  // register sets
     static constexpr int SW = 4 * NR;                          // registers per set
     static constexpr int NWD = NR - 1;                         // bit words per group of eight steps (all levels)
     __host__ __device__ static constexpr int wbase(int l) { return NR - (NR >> l); }  // first word of level l
 };
 // the 2^LV row chunks of one step: base = the row at element 4 c
-// (int8 rows: one dword per chunk into the first register of its group, 256 bytes apart; widened in place by vtg_widen)
-template <int S, int LV>
+// (int8 rows: one dword per chunk into the first register of its group, 2^TOUT bytes apart; widened in place by vtg_widen)
+template <int S, int LV, int TOUT = 8>
 __device__ __forceinline__ void vtg_load(const int8_t* base)
 {
     static_for<(1 << LV)>([&](auto K) {
         constexpr int k = decltype(K)::value;
         const int8_t* pm = base;
-        asm volatile("global_load_dword v[%0], %1, off offset:%2" ::"n"(S + 4 * k), "v"(pm), "n"(k * 256) : "memory");
+        asm volatile("global_load_dword v[%0], %1, off offset:%2" ::"n"(S + 4 * k), "v"(pm), "n"(k << TOUT) : "memory");
     });
 }
 template <int S, int LV, typename RT>
@@ -1893,13 +1896,15 @@ __device__ __forceinline__ void vtg_widen()
         });
     }
 }
-template <int S, int LV>
+// (TOUT: the stage of the block the step produces -- chunk k of its input is 2^TOUT elements further on; 8 for the top-of-tree pass)
+template <int S, int LV, int TOUT = 8>
 __device__ __forceinline__ void vtg_load(const float* base)
 {
     static_for<(1 << LV)>([&](auto K) {
         constexpr int k = decltype(K)::value;
-        const float* pm = base + 1024 * (k >> 2);
-        asm volatile("global_load_dwordx4 v[%0:%0+3], %1, off offset:%2" ::"n"(S + 4 * k), "v"(pm), "n"((k & 3) * 1024) : "memory");
+        constexpr int bytes = (4 * k) << TOUT;
+        const float* pm = base + (bytes & ~4095) / 4;
+        asm volatile("global_load_dwordx4 v[%0:%0+3], %1, off offset:%2" ::"n"(S + 4 * k), "v"(pm), "n"(bytes & 4095) : "memory");
     });
 }
 // the levels of one step on set S, in place: the stage-8 chunk ends up in v[S .. S + 3].  gm bit l: level l is a g (its
@@ -1970,8 +1975,8 @@ __device__ __forceinline__ void vtg_fetch_parked(uint32_t s7addr)
 // The bit words of one group of eight steps (g = 0 .. 7) are requested into a[VTG_A ..]: for every g level l the words g + 8 k
 // of its node's left-child block (bo[l]: byte offset of that block in the column of the slot owner, relative to the wave's
 // arena).  They are older than every row chunk of the group's later steps, so the steps' counted waits cover them.
-template <int LV>
-__device__ __forceinline__ void vtg_words_issue(uint32_t gm, const uint32_t (&bo)[LV], uint32_t g, const uint32_t* abase)
+template <int LV, int TOUT = 8>
+__device__ __forceinline__ void vtg_words_issue(uint32_t gm, const uint32_t (&bo)[LV > 0 ? LV : 1], uint32_t g, const uint32_t* abase)
 {
     using G = VtgGeo<LV>;
     static_for<LV>([&](auto Lc) {
@@ -1982,10 +1987,11 @@ __device__ __forceinline__ void vtg_words_issue(uint32_t gm, const uint32_t (&bo
             const uint32_t* ab = abase;
             static_for<NB>([&](auto K) {
                 constexpr int k = decltype(K)::value;
-                // word g + 8 k of the block: 8 k words = 2048 k bytes further on in the lane's column
-                const uint32_t ok = o + 4096u * (uint32_t)(k >> 1);
+                // word g + 2^(TOUT-5) k of the block: 2^(TOUT+3) k bytes further on in the lane's column
+                constexpr uint32_t bytes = (uint32_t)k << (TOUT + 3);
+                const uint32_t ok = o + (bytes & ~4095u);
                 const uint32_t* qb = ab;
-                asm volatile("global_load_dword a[%0], %1, %2 offset:%3" ::"n"(VTG_A + G::wbase(l) + k), "v"(ok), "s"(qb), "n"((k & 1) * 2048) : "memory");
+                asm volatile("global_load_dword a[%0], %1, %2 offset:%3" ::"n"(VTG_A + G::wbase(l) + k), "v"(ok), "s"(qb), "n"(bytes & 4095u) : "memory");
             });
         }
     });
@@ -1999,61 +2005,99 @@ __device__ __forceinline__ void vtg_words_take()
         asm volatile("v_accvgpr_read_b32 v[%0], a[%1]" ::"n"(VTG_W + i), "n"(VTG_A + i));
     });
 }
-// TOP: the stage of the source row (LOGN: the channel row; lower: a virtual row), LV = TOP - 8 levels; gm bit l: the op at
-// stage TOP - l is a g
-template <int TOP, bool CH, typename RT>
-__device__ __forceinline__ void op_vtg_t(Path& p, uint32_t gm, const RT* chan, uint32_t absmask, uint32_t signmask)
+// What a step does with its chunk (the sinks of vtg_core).  The top-of-tree pass: arena + the F of stage 8 through the LDS slots.
+template <bool CH>
+struct SinkStage8 {
+    const uint32_t* s8base;
+    uint32_t s8col, s7col, absmask;
+    float c127;
+    __device__ __forceinline__ void pre(uint32_t c) const
+    {
+        if (c >= 32u) vtg_fetch_parked(s7col + 1024u * (c - 32u));
+    }
+    template <int S, int PAR>
+    __device__ __forceinline__ void take(uint32_t c)
+    {
+        if (c >= 32u) vtg_tail_second<S, CH>(s8col + 1024u * c, s8base, s7col + 1024u * (c - 32u), absmask, c127);
+        else vtg_tail_first<S>(s8col + 1024u * c, s8base, s7col + 1024u * c);
+    }
+};
+// An all-frozen leaf above stage 8 (RateZeroDecoder::decode scl_avx_float.cpp:316-337 on a block that is never stored): the sum of
+// min(x, 0) in the reference's order -- eight strided accumulators, acc[j] += x[8 k + j]: chunk c feeds acc[4 (c & 1) ..].
+struct SinkMin0 {
+    float acc[8];
+    __device__ __forceinline__ void pre(uint32_t) const {}
+    template <int S, int PAR>
+    __device__ __forceinline__ void take(uint32_t)
+    {
+        float t0, t1, t2, t3;
+        asm volatile("v_min_f32 %[t0], 0, v[%[r]]\n\t"
+                     "v_min_f32 %[t1], 0, v[%[r]+1]\n\t"
+                     "v_min_f32 %[t2], 0, v[%[r]+2]\n\t"
+                     "v_min_f32 %[t3], 0, v[%[r]+3]\n\t"
+                     "v_add_f32 %[a0], %[a0], %[t0]\n\t"
+                     "v_add_f32 %[a1], %[a1], %[t1]\n\t"
+                     "v_add_f32 %[a2], %[a2], %[t2]\n\t"
+                     "v_add_f32 %[a3], %[a3], %[t3]"
+                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [a0] "+v"(acc[4 * PAR]), [a1] "+v"(acc[4 * PAR + 1]),
+                       [a2] "+v"(acc[4 * PAR + 2]), [a3] "+v"(acc[4 * PAR + 3])
+                     : [r] "n"(S));
+    }
+};
+// The pass itself.  TOP: the stage of the source row (LOGN: the channel row; lower: a virtual row), TOUT: the stage of the block
+// it produces chunk by chunk (8: the top-of-tree pass), LV = TOP - TOUT levels; gm bit l: the op at stage TOP - l is a g.
+// 2^TOUT / 4 steps in groups of eight (one bit word per block and group), NS register sets.
+template <int TOP, int TOUT, bool CH, typename RT, typename SINK>
+__device__ __forceinline__ void vtg_core(Path& p, uint32_t gm, const RT* chan, uint32_t absmask, uint32_t signmask, SINK& sink)
 {
-    constexpr int LV = TOP - 8;
+    constexpr int LV = TOP - TOUT;
     using G = VtgGeo<LV>;
     constexpr int NS = G::NS, SW = G::SW;
+    constexpr uint32_t NG = (1u << TOUT) / 32u;  // groups of eight steps
     // the g that has just been executed is the one at the lowest stage: its left child's bits are this lane's own
     if (gm) p.set_field((uint32_t)TOP - (31u - (uint32_t)__builtin_clz(gm)));
-    uint32_t bo[LV];
+    uint32_t bo[LV > 0 ? LV : 1];
     static_for<LV>([&](auto Lc) {
         constexpr int l = decltype(Lc)::value;
         bo[l] = 4u * (AR_BL(TOP - l - 1) + p.owner((uint32_t)(TOP - l)));
     });
     const uint32_t* abase = p.arena;
-    const uint32_t* s8base = p.arena + AR_S8;
-    const uint32_t s8col = (uint32_t)p.lane * 16u;  // byte offset of chunk 0 of this lane's column (chunk c: + 1024 c)
-    const uint32_t s7col = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.lane * 16u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing older in flight: the counted waits below see only this op's accesses)
-    vtg_words_issue<LV>(gm, bo, 0, abase);
+    vtg_words_issue<LV, TOUT>(gm, bo, 0, abase);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const RT* const rowlast = chan + 4 * 63;
-    static_for<NS - 1>([&](auto J) { vtg_load<128 + SW * decltype(J)::value, LV>(chan + 4 * decltype(J)::value); });
+    const RT* const rowlast = chan + 4 * (8 * NG - 1);
+    static_for<NS - 1>([&](auto J) { vtg_load<128 + SW * decltype(J)::value, LV, TOUT>(chan + 4 * decltype(J)::value); });
     const RT* rowp = chan + 4 * (NS - 1);  // the row at the chunk of the next step to be loaded
 #pragma unroll 1
-    for (uint32_t g = 0; g < 8; ++g) {
+    for (uint32_t g = 0; g < NG; ++g) {
         vtg_words_take<LV>();
         // the words of the next group are requested now and are long there when it starts
-        vtg_words_issue<LV>(gm, bo, g < 7u ? g + 1u : 7u, abase);
-        const bool second = g >= 4u;
+        vtg_words_issue<LV, TOUT>(gm, bo, g + 1u < NG ? g + 1u : NG - 1u, abase);
 #pragma unroll 1
         for (uint32_t i = 0; i < 8; i += NS) {
             static_for<NS>([&](auto J) {
                 constexpr int j = decltype(J)::value;
                 const uint32_t c = 8u * g + i + (uint32_t)j;
-                if (second) vtg_fetch_parked(s7col + 1024u * (c - 32u));
-                vtg_load<128 + SW * ((j + NS - 1) % NS), LV>(rowp < rowlast ? rowp : rowlast);
+                sink.pre(c);
+                vtg_load<128 + SW * ((j + NS - 1) % NS), LV, TOUT>(rowp < rowlast ? rowp : rowlast);
                 rowp += 4;
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * G::NR) : "memory");
                 vtg_widen<128 + SW * j, LV, RT>();
                 vtg_levels<128 + SW * j, LV, CH>(gm, 31u - 4u * ((i + (uint32_t)j) & 7u), absmask, signmask, p.c127, p.m128);
-                if (second) vtg_tail_second<128 + SW * j, CH>(s8col + 1024u * c, s8base, s7col + 1024u * (c - 32u), absmask, p.c127);
-                else vtg_tail_first<128 + SW * j>(s8col + 1024u * c, s8base, s7col + 1024u * c);
+                sink.template take<128 + SW * j, (j & 1)>(c);
             });
         }
     }
-    p.set_field(8);
-    p.set_field(7);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
-// The first pass of a codeword (every level an f): one live path, whose lane would do 64 steps while the others of the
-// codeword idle.  The steps do not depend on the path: lane q does the chunks c = q, q + LC, ... < 32 and their partners
-// c + 32, and stores into the column of the codeword's first lane, where the path lives.  (Not pipelined: a handful of
-// steps per lane, once per codeword.)
+template <int TOP, bool CH, typename RT>
+__device__ __forceinline__ void op_vtg_t(Path& p, uint32_t gm, const RT* chan, uint32_t absmask, uint32_t signmask)
+{
+    SinkStage8<CH> sink{ p.arena + AR_S8, (uint32_t)p.lane * 16u, (uint32_t)(uintptr_t)p.lds + (uint32_t)p.lane * 16u, absmask, p.c127 };
+    vtg_core<TOP, 8, CH, RT>(p, gm, chan, absmask, signmask, sink);
+    p.set_field(8);
+    p.set_field(7);
+}
 // every level an f, and what the levels above the last one produce goes to the codeword's virtual rows: after level l the set
 // holds the chunks c + 64 k, k < 2^(LV-1-l), of the leftmost block of stage LOGN - 1 - l
 template <int S, int LV, bool CH>
@@ -2083,7 +2127,9 @@ __device__ __forceinline__ void vtg_levels_first(float* vrow, uint32_t c, uint32
         }
     });
 }
-template <int LV, bool CH>
+// TAILS = false (LN_VROWS): the virtual rows only -- the program of a low-rate code starts with an all-frozen leaf above stage 8,
+// not with this pass
+template <int LV, bool CH, bool TAILS = true>
 __device__ __forceinline__ void op_vtg_first(Path& p, const RowT* chan, uint32_t absmask, uint32_t signmask)
 {
     const uint32_t* s8base = p.arena + AR_S8;
@@ -2096,16 +2142,20 @@ __device__ __forceinline__ void op_vtg_first(Path& p, const RowT* chan, uint32_t
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         vtg_widen<128, LV, RowT>();
         vtg_levels_first<128, LV, CH>(vrow, c, absmask, p.c127);
-        vtg_tail_first<128>(s8col + 1024u * c, s8base, s7col + 1024u * c);
-        vtg_fetch_parked(s7col + 1024u * c);
+        if constexpr (TAILS) {
+            vtg_tail_first<128>(s8col + 1024u * c, s8base, s7col + 1024u * c);
+            vtg_fetch_parked(s7col + 1024u * c);
+        }
         vtg_load<128, LV>(chan + 4 * (c + 32u));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         vtg_widen<128, LV, RowT>();
         vtg_levels_first<128, LV, CH>(vrow, c + 32u, absmask, p.c127);
-        vtg_tail_second<128, CH>(s8col + 1024u * (c + 32u), s8base, s7col + 1024u * c, absmask, p.c127);
+        if constexpr (TAILS) vtg_tail_second<128, CH>(s8col + 1024u * (c + 32u), s8base, s7col + 1024u * c, absmask, p.c127);
     }
-    p.set_field(8);
-    p.set_field(7);
+    if constexpr (TAILS) {
+        p.set_field(8);
+        p.set_field(7);
+    }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 // off: bit l = level l (0 = the channel row's own f / g, i.e. the op of the root) is a g
@@ -2131,6 +2181,47 @@ __device__ __forceinline__ void op_vtg(Path& p, uint32_t off, const RowT* chan, 
     default: op_vtg_t<LOGN, CH, RowT>(p, gm, chan, absmask, signmask); break;
     }
 }
+#if LN_LOGN >= 11 && LN_HILEAF
+// RateZeroDecoder::decode scl_avx_float.cpp:316-337 on a block of 512 / 1024 LLRs (stage T = 9, 10: the low rates at N >= 2048).
+// The block is never stored: the pass recomputes it from the channel row -- or from the highest virtual row it can use -- and
+// the sink adds up min(x, 0) in the reference's order; the output bits are zeros.  off bit l: the op at stage LOGN - l is a g.
+template <int T, int L0, bool CH>
+__device__ __forceinline__ void r0_high_from(Path& p, uint32_t gm, const RowT* chan, const float* vrow, uint32_t absmask, uint32_t signmask, SinkMin0& sink)
+{
+    if constexpr (L0 == 0) vtg_core<LOGN, T, CH, RowT>(p, gm, chan, absmask, signmask, sink);
+    else vtg_core<LOGN - L0, T, CH, float>(p, gm >> L0, vrow + vrow_off(LOGN - L0), absmask, signmask, sink);
+}
+template <int T, bool CH>
+__device__ __forceinline__ void leaf_r0_high(Path& p, uint32_t side, uint32_t off, const RowT* chan, uint32_t absmask, uint32_t signmask)
+{
+    constexpr int LVR = LOGN - T;
+    const uint32_t gm = off & ((1u << LVR) - 1u);
+    const float* const vrow = reinterpret_cast<const float*>(p.arena + AR_VROW) + ((uint32_t)p.lane >> LCL) * VROW_FLOATS;
+    SinkMin0 sink;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sink.acc[j] = 0.0f;
+    const uint32_t l0 = gm ? (uint32_t)__builtin_ctz(gm) : (uint32_t)LVR;  // leading f levels: path-independent
+    switch (l0) {
+    case 0: r0_high_from<T, 0, CH>(p, gm, chan, vrow, absmask, signmask, sink); break;
+    case 1: r0_high_from<T, 1, CH>(p, gm, chan, vrow, absmask, signmask, sink); break;
+    case 2: if constexpr (LVR >= 2) r0_high_from<T, 2, CH>(p, gm, chan, vrow, absmask, signmask, sink); break;
+    default: if constexpr (LVR >= 3) r0_high_from<T, 3, CH>(p, gm, chan, vrow, absmask, signmask, sink); break;
+    }
+    const float* a = sink.acc;
+    p.metric = p.metric + (((((((a[0] + a[1]) + a[2]) + a[3]) + a[4]) + a[5]) + a[6]) + a[7]);
+    uint32_t ln = (uint32_t)p.lane;
+    asm volatile("" : "+v"(ln));
+    uint32_t* o = p.arena + (side ? AR_BR(T) : AR_BL(T)) + ln;
+#pragma unroll 1
+    for (uint32_t i = 0; i < ar_bitwords(T); i += 4) {
+        o[(i + 0) * 64] = 0u;
+        o[(i + 1) * 64] = 0u;
+        o[(i + 2) * 64] = 0u;
+        o[(i + 3) * 64] = 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#endif
 #undef LN_VGS
 #endif  // LN_LOGN != 10
 #undef LN_WIDEN4
@@ -2329,10 +2420,14 @@ void scl_lane_kernel(const DecodeParams P)
         for (uint32_t pc = 0;; ++pc) {
             const uint64_t raw = nraw;
             nraw = prog[pc + 1];  // (fetched one instruction ahead; the host appends a spare word behind OP_END)
-#if !LN_GEO_DEFAULT
+#if (!LN_GEO_DEFAULT && !(defined(LN_OPAQUE_LANE) && LN_OPAQUE_LANE == 0)) || (defined(LN_OPAQUE_LANE) && LN_OPAQUE_LANE > 0)
             // (nothing derived from the lane number is carried around the interpreter loop: with the larger arenas of the other
             //  geometries the compiler otherwise keeps -- and spills to scratch -- dozens of precomputed 64-bit column addresses)
+#if defined(LN_OPAQUE_LANE) && LN_OPAQUE_LANE == 1
+            asm volatile("" : "+v"(p.lane));
+#else
             asm volatile("" : "+v"(p.lane), "+v"(p.q), "+v"(p.g0), "+v"(p.self4));
+#endif
 #endif
             const uint32_t op = (uint32_t)raw & 0xFFu, st = ((uint32_t)raw >> 8) & 0xFFu, side = ((uint32_t)raw >> 16) & 0xFFu;
             const uint32_t off = (uint32_t)(raw >> 32);
@@ -2436,6 +2531,9 @@ void scl_lane_kernel(const DecodeParams P)
                 lside = r0side;
                 break;
             }
+#if LN_LOGN >= 11 && LN_HILEAF
+            case LN_VROWS: op_vtg_first<TOPD, CH, false>(p, chan, absmask, signmask); break;
+#endif
             case LN_R0: lk = 1; break;
             case LN_R1: lk = 2; break;
             case LN_SPC: lk = 3; break;
@@ -2455,6 +2553,10 @@ void scl_lane_kernel(const DecodeParams P)
 #pragma unroll 1
                 for (uint32_t rep = 0; rep < ((DIAG && (P.ablate & 4096u) && cls == 3u) ? 2u : 1u); ++rep)
                     switch (lcode) {  // (flat: see the G step)
+#if LN_LOGN >= 11 && LN_HILEAF
+                    case 0x19: leaf_r0_high<9, CH>(p, lside, off, chan, absmask, signmask); break;
+                    case 0x1A: if constexpr (LOGN >= 12) leaf_r0_high<(LOGN >= 12 ? 10 : 9), CH>(p, lside, off, chan, absmask, signmask); break;
+#endif
                     case 0x18: leaf_r0<8>(p, lside); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
                     case 0x17: leaf_r0<7>(p, lside); break;
                     case 0x16: leaf_r0<6>(p, lside); break;

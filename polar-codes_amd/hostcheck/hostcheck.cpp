@@ -49,6 +49,7 @@ static const char* opname(unsigned op)
     case LN_REP: return "LN_REP";
     case LN_SPC: return "LN_SPC";
     case LN_WALK: return "LN_WALK";
+    case LN_VROWS: return "LN_VROWS";
     default: return "?";
     }
 }
@@ -98,7 +99,7 @@ static int run_set(unsigned N, const std::vector<uint32_t>& frozen, unsigned lon
         bool big = false;
         if (lower_lane(logN, scl, lane, chr != 0, &big)) {
             ++stats[4];
-            if (check_program(lane, logN, LN_VT, LN_WALK, "lane program malformed", N, frozen.size())) return 1;
+            if (check_program(lane, logN, LN_VT, LN_VROWS, "lane program malformed", N, frozen.size())) return 1;
             if (lane.leaves != scl.leaves || lane.inner != scl.inner) return fail("lane program counts differ", N, frozen.size());
             // every leaf of the plain program must be reachable in the lowered one: count them (riding on walks or on their own)
             unsigned leaves = 0;

@@ -333,7 +333,9 @@ def test_lane_per_path_kernel_codes(built_library, N, K, L, kind):
 LANE_GEO_CODES = [(512, 256, 8, "BB"), (512, 128, 6, "BB"), (512, 256, 16, "BB"), (512, 200, 32, "BE"), (512, 256, 5, "rand"),
                   (1024, 512, 16, "BB"), (1024, 300, 12, "BE"), (1024, 512, 32, "BB"), (1024, 800, 24, "BB"), (1024, 512, 9, "rand"),
                   (2048, 1024, 8, "BB"), (2048, 512, 7, "BE"), (2048, 1500, 8, "BB"), (2048, 1024, 16, "BB"), (2048, 700, 24, "BB"), (2048, 1024, 8, "rand"),
-                  (4096, 2048, 8, "BB"), (4096, 2048, 16, "BB"), (4096, 2048, 32, "BB"), (4096, 2048, 20, "BE"), (4096, 1400, 32, "BB"), (2048, 256, 8, "BB")]
+                  (4096, 2048, 8, "BB"), (4096, 2048, 16, "BB"), (4096, 2048, 32, "BB"), (4096, 2048, 20, "BE"),
+                  # low rates: an all-frozen leaf of 512 / 1024 LLRs, recomputed from the channel row (the *_hi kernels)
+                  (4096, 1400, 32, "BB"), (2048, 256, 8, "BB"), (4096, 512, 16, "BB"), (4096, 256, 8, "BE"), (2048, 128, 32, "BB")]
 
 
 @pytest.mark.parametrize("N,K,L,kind", LANE_GEO_CODES, ids=[f"N{n}_K{k}_L{l}_{c}" for n, k, l, c in LANE_GEO_CODES])
@@ -356,8 +358,8 @@ def test_lane_kernel_geometries(built_library, N, K, L, kind):
     eighths = (np.round(awgn[: rows // 2] * 8) / 8).astype(np.float32)    # quantised: equal metrics at most forks
     llr = np.concatenate([awgn, noise, ties, eighths])
     d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
-    if kind == "BB" and 2 * K == N:
-        assert d.kernel_name(True).startswith("scl_lane_"), d.kernel_name(True)   # (expressible: the new kernels run; a leaf above stage 8 -- low and high rates at N >= 2048 -- keeps the path-group kernels)
+    if kind == "BB" and 2 * K <= N:
+        assert d.kernel_name(True).startswith("scl_lane_"), d.kernel_name(True)   # (expressible: the new kernels run; a RateOne / SPC leaf above stage 8 -- high rates at N >= 2048 -- keeps the path-group kernels)
     for systematic in (True, False):
         e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, 8, llr, systematic, "float")
         d.setErrorDetection(8, "crc")
