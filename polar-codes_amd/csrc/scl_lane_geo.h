@@ -6,10 +6,11 @@
 #include "kernels.h"
 
 #define PAMD_LANE_GEOS(X) X(12, 5) X(10, 4) X(10, 5) X(11, 3) X(9, 3) X(9, 4) X(9, 5) X(11, 4) X(11, 5) X(12, 3) X(12, 4)
-#define PAMD_LANE_GEOS_CHAR(Y)
+#define PAMD_LANE_GEOS_CHAR(Y) Y(9, 3) Y(9, 4) Y(9, 5) Y(10, 4) Y(10, 5) Y(11, 3) Y(11, 4) Y(11, 5) Y(12, 3) Y(12, 4) Y(12, 5)
 // N >= 2048 with an all-frozen leaf of 512 / 1024 LLRs in the tree (low rates): the same kernels with that leaf, as translation
 // units of their own (scl_lane_n<logN>_l<lcl>_hi.hip) -- the code it adds moved cfg 5 by 2.5 % when it sat in the one kernel
 #define PAMD_LANE_GEOS_HI(Z) Z(11, 3) Z(11, 4) Z(11, 5) Z(12, 3) Z(12, 4) Z(12, 5)
+#define PAMD_LANE_GEOS_CHAR_HI(W) W(11, 3) W(11, 4) W(11, 5) W(12, 3) W(12, 4) W(12, 5)
 
 namespace pamd {
 
@@ -24,7 +25,12 @@ namespace pamd {
     unsigned scl_lane_n##LOGN##_l##LCL##_hi_arena_words();
 PAMD_LANE_GEOS(PAMD_LANE_DECL)
 PAMD_LANE_GEOS_CHAR(PAMD_LANE_DECL_CHAR)
+#define PAMD_LANE_DECL_CHAR_HI(LOGN, LCL)                                                                                    \
+    hipError_t launch_scl_lane_n##LOGN##_l##LCL##_char_hi(const DecodeParams& P, bool diag, unsigned grid, hipStream_t st);   \
+    unsigned scl_lane_n##LOGN##_l##LCL##_char_hi_arena_words();
 PAMD_LANE_GEOS_HI(PAMD_LANE_DECL_HI)
+PAMD_LANE_GEOS_CHAR_HI(PAMD_LANE_DECL_CHAR_HI)
+#undef PAMD_LANE_DECL_CHAR_HI
 #undef PAMD_LANE_DECL_HI
 #undef PAMD_LANE_DECL
 #undef PAMD_LANE_DECL_CHAR
@@ -44,7 +50,9 @@ inline const LaneKernel* find_lane_kernel(unsigned logN, unsigned L, bool chr, b
 #define PAMD_LANE_ROW(LOGN, LCL) { LOGN, LCL, false, false, launch_scl_lane_n##LOGN##_l##LCL, scl_lane_n##LOGN##_l##LCL##_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_kernel" },
 #define PAMD_LANE_ROW_HI(LOGN, LCL) { LOGN, LCL, false, true, launch_scl_lane_n##LOGN##_l##LCL##_hi, scl_lane_n##LOGN##_l##LCL##_hi_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_hi_kernel" },
 #define PAMD_LANE_ROW_CHAR(LOGN, LCL) { LOGN, LCL, true, false, launch_scl_lane_n##LOGN##_l##LCL##_char, scl_lane_n##LOGN##_l##LCL##_char_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_char_kernel" },
-        PAMD_LANE_GEOS(PAMD_LANE_ROW) PAMD_LANE_GEOS_CHAR(PAMD_LANE_ROW_CHAR) PAMD_LANE_GEOS_HI(PAMD_LANE_ROW_HI)
+#define PAMD_LANE_ROW_CHAR_HI(LOGN, LCL) { LOGN, LCL, true, true, launch_scl_lane_n##LOGN##_l##LCL##_char_hi, scl_lane_n##LOGN##_l##LCL##_char_hi_arena_words, "scl_lane_n" #LOGN "_l" #LCL "_char_hi_kernel" },
+        PAMD_LANE_GEOS(PAMD_LANE_ROW) PAMD_LANE_GEOS_CHAR(PAMD_LANE_ROW_CHAR) PAMD_LANE_GEOS_HI(PAMD_LANE_ROW_HI) PAMD_LANE_GEOS_CHAR_HI(PAMD_LANE_ROW_CHAR_HI)
+#undef PAMD_LANE_ROW_CHAR_HI
 #undef PAMD_LANE_ROW_HI
 #undef PAMD_LANE_ROW
 #undef PAMD_LANE_ROW_CHAR

@@ -370,6 +370,31 @@ def test_lane_kernel_geometries(built_library, N, K, L, kind):
         assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), "path metrics differ from the oracle's"
 
 
+LANE_GEO_CHAR_CODES = [(512, 200, 32), (1024, 512, 16), (1024, 512, 32), (2048, 1024, 8), (2048, 1024, 16), (2048, 700, 32), (2048, 256, 8), (4096, 1024, 8)]
+
+
+@pytest.mark.parametrize("N,K,L", LANE_GEO_CHAR_CODES, ids=[f"N{n}_K{k}_L{l}" for n, k, l in LANE_GEO_CHAR_CODES])
+def test_lane_kernel_geometries_int8_decoder(built_library, N, K, L):
+    """the same geometries for the int8 decoder SclFipChar (scl_fip_char.cpp:388-775; scl_lane_n*_l*_char[_hi].hip): int8 rows read as
+    bytes and widened in the top-of-tree pass, saturating f / g at every recomputed level, integer metrics (equal at most forks)"""
+    import pypolar_amd
+    rng = np.random.default_rng(11 * N + K + L)
+    frozen = np.asarray(pypolar_amd.frozen_bits(N, K, 0.0, "BB"), dtype=np.uint32)
+    rows = 13 if N <= 2048 else 6
+    awgn = (1.0 + 0.8 * rng.standard_normal((rows, N))) * np.where(rng.random((rows, N)) < 0.5, 1, -1)
+    llr = np.concatenate([np.clip(np.round(awgn * 8), -128, 127), rng.integers(-128, 128, (rows // 2, N)), rng.integers(-3, 4, (rows // 2, N))]).astype(np.int8)
+    d = pypolar_amd.PolarDecoder(N, L, frozen, "char")
+    assert d.kernel_name(True).startswith("scl_lane_") and "_char" in d.kernel_name(True), d.kernel_name(True)
+    for systematic in (True, False):
+        e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, 8, llr.astype(np.float32), systematic, "char")
+        d.setErrorDetection(8, "crc")
+        d.setSystematic(systematic)
+        out, ok, met = d.decode_batch(llr, return_metrics=True)
+        assert np.array_equal(out, e_out), (N, K, L, systematic)
+        assert np.array_equal(ok.astype(np.uint8), e_ok)
+        assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), "path metrics differ from the oracle's"
+
+
 @pytest.mark.parametrize("dectype,K,kind", [("float", 512, "BB"), ("float", 176, "5G"), ("float", 900, "BB"), ("char", 512, "BB"), ("char", 256, "BB"),
                                             ("char", 768, "BB"), ("char", 900, "BB")],
                          ids=["float_K512", "float_5G_K176", "float_K900_big", "char_K512", "char_K256", "char_K768_big", "char_K900_big"])
