@@ -88,6 +88,15 @@ int pcd_decode_f32(pcd_decoder* d, const float* llr, size_t rows, uint8_t* out, 
 int pcd_decode_i8(pcd_decoder* d, const int8_t* llr, size_t rows, uint8_t* out, uint8_t* ok,
                   float* metrics, int mem, void* stream);
 
+/* Small batches.  The reference's interface is ONE codeword per call (Decoder::decode_vector decoder.cpp:154-181,
+ * decoder_python.cc:41-74); the throughput kernels pack 32 (SC) / 8 .. 2 (list) codewords into a wavefront, whose run time does not
+ * depend on how many of its slots are filled.  Calls of up to pcd_small_batch_rows() rows therefore run on a sibling geometry with
+ * one codeword per wavefront (shorter per-call latency, same results bit for bit); 0 = no such sibling for this decoder.
+ * pcd_set_small_batch_rows changes the threshold (0: every call takes the throughput kernels).  While pcd_set_timing is on, every
+ * call takes the throughput kernels as well. */
+int pcd_set_small_batch_rows(pcd_decoder* d, size_t rows);
+size_t pcd_small_batch_rows(const pcd_decoder* d);
+
 /* Introspection of the compiled decode program (host only, no GPU): counts[0] = leaf ops,
  * counts[1] = inner nodes, for the SC (list=0) or SCL (list=1) program of this decoder. */
 int pcd_program_stats(const pcd_decoder* d, int list, unsigned counts[2]);

@@ -77,6 +77,13 @@ struct pcd_decoder {
     // lane-per-path list kernel (scl_lane_kernel.hip): N = 1024, 4 < L <= 8, float arithmetic, fp32 rows
     pamd::Program lane_prog;
     bool has_lane = false, lane_big = false;  // lane_big: a forking leaf of 256 LLRs (the BIG instantiation of the lane kernel)
+    // Small batches (round 4): the kernels above pack 32 (SC) / 8 .. 2 (list) codewords into a wave, and a lone wave takes the
+    // same time whether one of its slots is filled or all -- 83 / 217 us per call for one codeword of cfg 2 / cfg 3.  A sibling
+    // handle with the shortest lone-wave geometry (ONE codeword per wave: 64 lanes per codeword for SC, 8 lanes per path for lists)
+    // takes the calls of up to small_rows rows: 63 / 190 us, flat up to ~1000 rows since every codeword gets a wave of its own.
+    pcd_decoder* small = nullptr;
+    size_t small_rows = 0;
+    bool is_small = false;  // this handle IS such a sibling: no pair / lane kernels, one codeword per wave
     const pamd::LaneKernel* lane_k = nullptr;  // the lane kernel of another geometry (scl_lane_geo.h); nullptr: N = 1024, 8 lanes per codeword
     unsigned lane_cpw = 8;                     // codewords per wave of the lane kernel
     pamd::Ins* d_lane_prog = nullptr;
@@ -183,6 +190,7 @@ void compute_geometry(pcd_decoder* d)
     // 1.80 / 1.17 / 0.77 -> 3.30 / 1.90 / 0.96 G cw/s, but N = 512: 0.43 -> 0.34 (the LDS slices of eight codewords)
     d->sc_lcl = N <= 256 ? 3 : (N <= 2048 ? 4 : 6);
     if (d->dectype == 0 && d->sc_lcl == 3) d->sc_lcl = 4;  // (the int8 reductions need the 32 byte lanes on 16 or 64 lanes)
+    if (d->is_small) d->sc_lcl = 6;
     if (const char* e = PAMD_ENV("PCD_SC_LCL")) {  // experiments
         const int v = std::atoi(e);
         d->sc_lcl = (v == 3 || v == 6) ? v : 4;
@@ -190,7 +198,7 @@ void compute_geometry(pcd_decoder* d)
     }
     d->sc_s0 = d->logN;
     d->sc_arena_cw_words = 0;
-    if ((N >= 2048 || (N >= 512 && PAMD_ENV("PCD_SC_S0"))) && d->sc_virtual_top && !PAMD_ENV("PCD_SC_NO_ARENA") && !PAMD_ENV("PCD_SC_LCL")) {
+    if ((N >= 2048 || (N >= 512 && PAMD_ENV("PCD_SC_S0"))) && d->sc_virtual_top && !PAMD_ENV("PCD_SC_NO_ARENA") && !PAMD_ENV("PCD_SC_LCL") && !d->is_small) {
         // long blocks: keep 16 lanes per codeword (four codewords per wave) and move the LLR stages from s0 up into a
         // per-codeword arena slice, s0 chosen so that a wave stays within 10 KB of LDS (16 waves per CU)
         unsigned s0 = d->logN - 1;
@@ -227,6 +235,7 @@ void compute_geometry(pcd_decoder* d)
         //  level at 1024; L = 4 +41 % / +19 % / +10 % / +5 % at N = 128 / 512 / 1024 / 2048; from N = 4096 on the 8-lane forms
         //  are 5-40 % faster again)
         d->cwl = lprime == 2 ? (d->logN <= 11 ? 3u : 2u) : (lprime == 4 ? (d->logN <= 11 ? 2u : 1u) : (lprime == 8 && d->logN <= 11 ? 1u : 0u));
+        if (d->is_small) d->cwl = 0;
         if (const char* e = PAMD_ENV("PCD_CWL")) {  // experiments: 0 = one codeword per wave; 1 at L <= 8: 4 lanes per path
             const unsigned v = (unsigned)std::atoi(e);
             d->cwl = (lprime == 2 && v <= 3) || (lprime == 4 && v <= 2) || (lprime <= 8 && v <= 1) ? v : 0u;
@@ -1109,6 +1118,9 @@ int decode_any(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t* o
                int mem, void* stream)
 {
     if (!d) return fail(PCD_ERR_INVALID_ARG, "null decoder");
+    // small batches: the sibling with one codeword per wave (not while kernel times are being recorded on this handle: the
+    // measurement is about the main kernels)
+    if (d->small && rows && rows <= d->small_rows && !d->timing) return decode_any(d->small, llr, i8, rows, out, ok, metrics, mem, stream);
     if (rows && (!llr || !out)) return fail(PCD_ERR_INVALID_ARG, "null llr/out pointer");
     if (d->det.size != 0 && d->nb < d->det.check_bytes())
         return fail(PCD_ERR_INVALID_ARG, "information word shorter than the detector's checksum field");
@@ -1171,8 +1183,30 @@ int decode_any(pcd_decoder* d, const void* llr, bool i8, size_t rows, uint8_t* o
 
 extern "C" {
 
+static int create_decoder(size_t block_length, size_t list_size, const uint32_t* frozen, size_t n_frozen, const char* type, int device,
+                          bool small, pcd_decoder** out);
+
 int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, size_t n_frozen, const char* type,
                int device, pcd_decoder** out)
+{
+    const int rc = create_decoder(block_length, list_size, frozen, n_frozen, type, device, false, out);
+    if (rc != PCD_OK) return rc;
+    pcd_decoder* d = *out;
+    // the sibling for small batches (see pcd_decoder::small): only where the main geometry packs codewords into waves
+    if ((d->has_pair || d->has_lane) && !PAMD_ENV("PCD_NO_SMALL")) {
+        pcd_decoder* sm = nullptr;
+        if (create_decoder(block_length, list_size, frozen, n_frozen, type, device, true, &sm) == PCD_OK) {
+            d->small = sm;
+            // (measured on MI355X, device pointers, us per call: SC 63 against 83 up to 2 048 rows, 78 / 84 there; list decoder L = 8
+            //  192 against 217 at one row, 216 / 226 at 1 024, 234 / 231 at 2 048 -- profiles/r04_host_latency.txt)
+            d->small_rows = d->L <= 1 ? 2048 : (d->dectype == 2 ? 512 : 1024);
+        }
+    }
+    return PCD_OK;
+}
+
+static int create_decoder(size_t block_length, size_t list_size, const uint32_t* frozen, size_t n_frozen, const char* type, int device,
+                          bool small, pcd_decoder** out)
 {
     if (!out) return fail(PCD_ERR_INVALID_ARG, "null output handle");
     *out = nullptr;
@@ -1208,6 +1242,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
     }
 
     pcd_decoder* d = new pcd_decoder();
+    d->is_small = small;
     d->N = (unsigned)N;
     d->logN = ilog2(N);
     d->L = (unsigned)list_size;
@@ -1229,7 +1264,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         d->has_sc = true;
         // the two-lanes-per-codeword kernel takes the float codes it has every op for (lowered from the plain program,
         // before fuse_sc rewrites it for sc_decode_kernel)
-        if (!PAMD_ENV("PCD_NO_PAIR")) d->has_pair = pamd::lower_pair(d->logN, d->sc_prog, d->pair_prog, chr, &d->pair_big);
+        if (!PAMD_ENV("PCD_NO_PAIR") && !small) d->has_pair = pamd::lower_pair(d->logN, d->sc_prog, d->pair_prog, chr, &d->pair_big);
     }
     if (d->L > 1) {
         pamd::compile_scl(d->N, d->frozen, d->scl_prog, chr);
@@ -1245,7 +1280,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
         // Round 4: the same kernel under other geometries (scl_lane_geo.h) -- N = 512 / 2048 / 4096 and 16 / 32 lanes per codeword;
         // the default geometry keeps its rule, the others take every tree the lowering can express from 48 leaves on.
         const bool geo_default = d->logN == 10 && d->L > 4 && d->L <= 8;
-        if (!geo_default && pamd::find_lane_kernel(d->logN, d->L, chr, false) && !PAMD_ENV("PCD_NO_LANE") &&
+        if (!small && !geo_default && pamd::find_lane_kernel(d->logN, d->L, chr, false) && !PAMD_ENV("PCD_NO_LANE") &&
             (d->scl_prog.leaves >= 48u || PAMD_ENV("PCD_FORCE_LANE"))) {
             bool big = false, hi = false;
             if (pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr, &big, &hi)) {
@@ -1256,7 +1291,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
                 }
             }
         }
-        if (geo_default && (!chr || !PAMD_ENV("PCD_NO_CHAR_LANE")) && !PAMD_ENV("PCD_NO_LANE")) {
+        if (!small && geo_default && (!chr || !PAMD_ENV("PCD_NO_CHAR_LANE")) && !PAMD_ENV("PCD_NO_LANE")) {
             // (... or from 30 FORKING leaves on: the high-rate trees have few leaves, but large RateOne / SPC ones -- K = 900: 46 leaves, 35 of
             //  them forking, 35.1 against 24.9 M cw/s)
             unsigned forks = 0;
@@ -1293,6 +1328,7 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
 void pcd_destroy(pcd_decoder* d)
 {
     if (!d) return;
+    if (d->small) pcd_destroy(d->small);
     if (d->dev_ready) {
         pamd::DeviceScope scope;
         (void)scope.enter(d->device);
@@ -1338,6 +1374,10 @@ int pcd_set_error_detection(pcd_decoder* d, unsigned size, const char* type)
     if (rc) return fail(rc, err);
     d->det = det;
     d->det_dirty = true;
+    if (d->small) {
+        d->small->det = det;
+        d->small->det_dirty = true;
+    }
     return PCD_OK;
 }
 
@@ -1345,8 +1385,17 @@ int pcd_set_systematic(pcd_decoder* d, int systematic)
 {
     if (!d) return fail(PCD_ERR_INVALID_ARG, "null decoder");
     d->systematic = systematic != 0;
+    if (d->small) d->small->systematic = d->systematic;
     return PCD_OK;
 }
+
+int pcd_set_small_batch_rows(pcd_decoder* d, size_t rows)
+{
+    if (!d) return fail(PCD_ERR_INVALID_ARG, "null decoder");
+    if (d->small) d->small_rows = rows;
+    return PCD_OK;
+}
+size_t pcd_small_batch_rows(const pcd_decoder* d) { return (d && d->small) ? d->small_rows : 0; }
 
 int pcd_is_systematic(const pcd_decoder* d) { return d && d->systematic; }
 size_t pcd_block_length(const pcd_decoder* d) { return d ? d->N : 0; }

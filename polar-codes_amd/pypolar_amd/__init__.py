@@ -26,12 +26,15 @@ _LIB_PATH = os.environ.get("PYPOLAR_AMD_LIB") or os.path.join(os.path.dirname(_H
 _lib = None
 
 PCD_MEM_HOST, PCD_MEM_DEVICE = 0, 1
+# None: keep the library's small-batch routing (pcd_small_batch_rows); a number: every new PolarDecoder gets this threshold
+SMALL_BATCH_ROWS = None
 
 # every symbol include/polar_amd.h declares
 C_SYMBOLS = [
     "pcd_create", "pcd_destroy", "pcd_set_error_detection", "pcd_set_systematic", "pcd_is_systematic",
     "pcd_block_length", "pcd_info_length", "pcd_list_size", "pcd_frozen_bits", "pcd_error_detection_mode",
     "pcd_out_bytes", "pcd_decode_f32", "pcd_decode_i8", "pcd_program_stats", "pcd_launch_info", "pcd_kernel_name",
+    "pcd_set_small_batch_rows", "pcd_small_batch_rows",
     "pcd_set_timing", "pcd_kernel_times", "pcd_last_error", "pcd_version",
     "pce_create", "pce_destroy", "pce_set_error_detection", "pce_set_systematic", "pce_is_systematic",
     "pce_block_length", "pce_info_length", "pce_info_bytes", "pce_code_bytes", "pce_frozen_bits",
@@ -90,6 +93,10 @@ def load_library():
     lib.pcd_launch_info.argtypes = [vp, C.c_int, u32p]
     lib.pcd_kernel_name.restype = C.c_int
     lib.pcd_kernel_name.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
+    lib.pcd_set_small_batch_rows.restype = C.c_int
+    lib.pcd_set_small_batch_rows.argtypes = [vp, C.c_size_t]
+    lib.pcd_small_batch_rows.restype = C.c_size_t
+    lib.pcd_small_batch_rows.argtypes = [vp]
     lib.pcd_set_timing.restype = C.c_int
     lib.pcd_set_timing.argtypes = [vp, C.c_int]
     lib.pcd_kernel_times.restype = C.c_int
@@ -225,6 +232,8 @@ class PolarDecoder:
             _raise(rc)
         self._lib = lib
         self._device = int(device)
+        if SMALL_BATCH_ROWS is not None:  # (module-level override of the library's threshold: the test suite sets 0 so that small
+            lib.pcd_set_small_batch_rows(self._h, C.c_size_t(int(SMALL_BATCH_ROWS)))  # test batches still run the throughput kernels)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -370,6 +379,15 @@ class PolarDecoder:
             _raise(rc)
         return {"lds_bytes_per_codeword": int(info[0]), "codewords_per_workgroup": int(info[1]),
                 "path_groups": int(info[2]), "workgroups_per_cu_by_lds": int(info[3])}
+
+    def set_small_batch_rows(self, rows):
+        """calls of up to `rows` rows run on the low-latency sibling geometry (one codeword per wavefront); 0: never"""
+        rc = self._lib.pcd_set_small_batch_rows(self._h, C.c_size_t(int(rows)))
+        if rc:
+            _raise(rc)
+
+    def small_batch_rows(self):
+        return int(self._lib.pcd_small_batch_rows(self._h))
 
     def kernel_name(self, list_program):
         """name of the kernel decode calls launch for the SC (False) or the list (True) program, as rocprofv3 shows it"""

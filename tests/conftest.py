@@ -38,3 +38,15 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _throughput_kernels_for_small_test_batches():
+    """The library routes calls of up to a few hundred rows to a low-latency sibling geometry (pcd_small_batch_rows).  The
+    suite's batches are small on purpose, and most tests are about the throughput kernels, so new decoders get a threshold of 0
+    here; the tests of the routing itself set pypolar_amd.SMALL_BATCH_ROWS = None."""
+    import pypolar_amd
+    old = pypolar_amd.SMALL_BATCH_ROWS
+    pypolar_amd.SMALL_BATCH_ROWS = 0
+    yield
+    pypolar_amd.SMALL_BATCH_ROWS = old

@@ -856,3 +856,37 @@ def test_large_host_batch_goes_through_the_pinned_ring(built_library):
     out, ok = dq.decode_batch(rows8)
     idx = np.arange(rows8.shape[0]) % fq.count
     assert np.array_equal(out, fq.out[idx]) and np.array_equal(ok.astype(np.uint8), fq.ok[idx])
+
+
+@pytest.mark.parametrize("name", ["cfg2_n1024_k512_sc_awgn.bin", "cfg3_n1024_k512_l8_crc24_awgn.bin", "cfg4_n1024_k176_l8_crc11_awgn.bin",
+                                  "mix_n1024_k512_l8_crc24_awgn.bin", "char_cfg3_n1024_k512_l8_crc24.bin", "cfg5_n4096_k2048_l32_crc32_awgn.bin"])
+def test_small_batches_take_the_low_latency_geometry_with_identical_results(built_library, name):
+    """pcd_small_batch_rows: calls of one .. a few hundred rows (the reference's interface is one codeword per call,
+    decoder_python.cc:41-74) run on a sibling handle with one codeword per wavefront; bytes, verdicts and metrics are the
+    reference's either way, for host and device pointers, at the threshold and one row above it"""
+    import pypolar_amd
+    import torch
+    fx = gio.load(os.path.join(gio.GOLDEN_DIR, name))[0]
+    pypolar_amd.SMALL_BATCH_ROWS = None          # (the library's own routing)
+    d = pypolar_amd.PolarDecoder(fx.N, fx.L, fx.frozen, fx.dectype)
+    d.setErrorDetection(fx.crc_size, fx.crc_type)
+    thr = d.small_batch_rows()
+    assert thr >= 256, thr                        # (these decoders run on wave-packed kernels: they have a sibling)
+    x = fx.llr.astype(np.int8) if fx.dectype == "char" else fx.llr
+    for rows in (1, 3, 17):
+        out, ok, met = d.decode_batch(np.ascontiguousarray(x[:rows]), return_metrics=True)
+        assert np.array_equal(out, fx.out[:rows]) and np.array_equal(ok.astype(np.uint8), fx.ok[:rows])
+        if fx.L > 1 and fx.dectype != "mixed":
+            assert np.array_equal(met.view(np.uint32), fx.metrics[:rows].view(np.uint32))
+    # across the threshold, device pointers: thr rows (sibling) and thr + 1 rows (throughput kernels) agree row by row
+    d.set_small_batch_rows(40)
+    xd = torch.from_numpy(np.ascontiguousarray(x[:41])).cuda()
+    a = d.decode_batch(xd[:40])
+    b = d.decode_batch(xd)
+    torch.cuda.synchronize()
+    assert bool((a[0] == b[0][:40]).all()) and bool((a[1] == b[1][:40]).all())
+    assert np.array_equal(b[0].cpu().numpy(), fx.out[:41])
+    d.set_small_batch_rows(0)
+    c = d.decode_batch(xd[:5])
+    torch.cuda.synchronize()
+    assert np.array_equal(c[0].cpu().numpy(), fx.out[:5])
