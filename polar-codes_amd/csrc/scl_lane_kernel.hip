@@ -53,6 +53,14 @@
 #define LN_LCL 3
 #endif
 #define LN_GEO_DEFAULT (LN_LOGN == 10 && LN_LCL == 3)
+// LN_PKFMA: the g's four v_fma_f32 as two v_pk_fma_f32 (and a + b as v_pk_add_f32).  At one wave per SIMD an instruction of any
+// kind takes one 4-cycle issue slot, a packed one included (measured on cfg 5: ten instead of twelve instructions per g block of the
+// top-of-tree pass = +1.7 %), and the packed fma is the same fused operation per component: results unchanged bit for bit.
+// (A/B on one box with the packed forms in every g and a + b: cfg 3 36.82 -> 37.27, cfg 4 47.7 -> 48.7, cfg 5 1.378 -> 1.415,
+//  cfg3_i8 27.85 -> 28.07 M cw/s.  -DLN_PKFMA=0 restores the scalar forms.)
+#ifndef LN_PKFMA
+#define LN_PKFMA 1
+#endif
 #ifdef LN_KERNEL_NAME
 // (the stubs of the other geometries -- and of the float decoder on int8 rows -- name their kernel and launcher themselves:
 //  LN_KERNEL_NAME, LN_LAUNCH_NAME, LN_ARENA_NAME)
@@ -185,6 +193,20 @@ __device__ __forceinline__ uint32_t rd_lane(uint32_t addr)
     "v_bfi_b32 v[" D_ "+2], %[am], v[" D_ "+2], %[t2]\n\t"       \
     "v_bfi_b32 v[" D_ "+3], %[am], v[" D_ "+3], %[t3]\n\t"
 // text of g over 4 consecutive elements whose inputs are in place: v[D+k] = g(v[D+k], v[B+k], bit E+k of %[w])
+#if LN_PKFMA
+// (packed: the +-1.0 factors pair up in v[254:255], free while a walk runs -- the stage registers end at v253)
+#define LN_G4T(D_, B_, S0, S1, S2, S3)                            \
+    "v_lshlrev_b32 %[t0], " #S0 ", %[w]\n\t"                     \
+    "v_lshlrev_b32 %[t1], " #S1 ", %[w]\n\t"                     \
+    "v_and_or_b32 v254, %[t0], %[sm], 1.0\n\t"                   \
+    "v_and_or_b32 v255, %[t1], %[sm], 1.0\n\t"                   \
+    "v_lshlrev_b32 %[t2], " #S2 ", %[w]\n\t"                     \
+    "v_lshlrev_b32 %[t3], " #S3 ", %[w]\n\t"                     \
+    "v_pk_fma_f32 v[" D_ ":" D_ "+1], v[" D_ ":" D_ "+1], v[254:255], v[" B_ ":" B_ "+1]\n\t" \
+    "v_and_or_b32 v254, %[t2], %[sm], 1.0\n\t"                   \
+    "v_and_or_b32 v255, %[t3], %[sm], 1.0\n\t"                   \
+    "v_pk_fma_f32 v[" D_ "+2:" D_ "+3], v[" D_ "+2:" D_ "+3], v[254:255], v[" B_ "+2:" B_ "+3]\n\t"
+#else
 #define LN_G4T(D_, B_, S0, S1, S2, S3)                            \
     "v_lshlrev_b32 %[t0], " #S0 ", %[w]\n\t"                     \
     "v_lshlrev_b32 %[t1], " #S1 ", %[w]\n\t"                     \
@@ -198,6 +220,7 @@ __device__ __forceinline__ uint32_t rd_lane(uint32_t addr)
     "v_fma_f32 v[" D_ "+1], v[" D_ "+1], %[t1], v[" B_ "+1]\n\t" \
     "v_fma_f32 v[" D_ "+2], v[" D_ "+2], %[t2], v[" B_ "+2]\n\t" \
     "v_fma_f32 v[" D_ "+3], v[" D_ "+3], %[t3], v[" B_ "+3]\n\t"
+#endif
 
 template <int G, int D, int A, int B>
 __device__ __forceinline__ void f_block(uint32_t absmask)
@@ -236,10 +259,17 @@ template <int T>
 __device__ __forceinline__ void g0_reg()
 {
     constexpr int h = 1 << (T - 1), A = RS(T), D = RS(T - 1);
+#if LN_PKFMA
+    static_for<h / 2>([&](auto I) {  // (every stage's registers start at an even number, h >= 2)
+        constexpr int i = 2 * decltype(I)::value;
+        asm volatile("v_pk_add_f32 v[%0:%0+1], v[%1:%1+1], v[%2:%2+1]" ::"n"(D + i), "n"(A + i), "n"(A + h + i));
+    });
+#else
     static_for<h>([&](auto I) {
         constexpr int i = decltype(I)::value;
         asm volatile("v_add_f32 v[%0], v[%1], v[%2]" ::"n"(D + i), "n"(A + i), "n"(A + h + i));
     });
+#endif
 }
 // g over G consecutive elements, inputs fetched from lane addr / 4 (ds_bpermute): a lands in v[D+k], b in a temporary.
 // u: the left child's bits, bit k = element k of this block
@@ -352,8 +382,13 @@ __device__ __forceinline__ void g7_round(uint32_t addr, uint32_t w, uint32_t sig
 {
     uint32_t t0, t1, t2, t3;
     if constexpr (ZERO) {
+#if LN_PKFMA
+#define LN_ADD4(o) "v_pk_add_f32 v[%[d]+" #o ":%[d]+" #o "+1], v[%[d]+" #o ":%[d]+" #o "+1], v[%[t]+" #o ":%[t]+" #o "+1]\n\t" \
+                   "v_pk_add_f32 v[%[d]+" #o "+2:%[d]+" #o "+3], v[%[d]+" #o "+2:%[d]+" #o "+3], v[%[t]+" #o "+2:%[t]+" #o "+3]\n\t"
+#else
 #define LN_ADD4(o) "v_add_f32 v[%[d]+" #o "], v[%[d]+" #o "], v[%[t]+" #o "]\n\t" "v_add_f32 v[%[d]+" #o "+1], v[%[d]+" #o "+1], v[%[t]+" #o "+1]\n\t" \
                    "v_add_f32 v[%[d]+" #o "+2], v[%[d]+" #o "+2], v[%[t]+" #o "+2]\n\t" "v_add_f32 v[%[d]+" #o "+3], v[%[d]+" #o "+3], v[%[t]+" #o "+3]\n\t"
+#endif
         asm volatile(LN_RD2(0) LN_RD2(1) LN_RD2(2) LN_RD2(3) LN_RD2(4) LN_RD2(5) LN_RD2(6) LN_RD2(7)
                      "s_waitcnt lgkmcnt(14)\n\t" LN_ADD4(0) "s_waitcnt lgkmcnt(12)\n\t" LN_ADD4(4)
                      "s_waitcnt lgkmcnt(10)\n\t" LN_ADD4(8) "s_waitcnt lgkmcnt(8)\n\t" LN_ADD4(12)
@@ -1612,6 +1647,20 @@ __device__ __forceinline__ void vt_step(uint32_t wa, uint32_t wb, uint32_t wc, u
                                         float m128 = 0.0f)
 {
     uint32_t t0, t1, t2, t3;
+#if LN_PKFMA
+// (packed: the pair of +-1.0 factors in v[126:127] -- the bit registers of the stages <= 7 are dead during this pass)
+#define LN_VG(D_, B_, W_)                                          \
+    "v_lshlrev_b32 %[t0], 31, " W_ "\n\t"                         \
+    "v_lshlrev_b32 %[t1], 30, " W_ "\n\t"                         \
+    "v_and_or_b32 v126, %[t0], %[sm], 1.0\n\t"                    \
+    "v_and_or_b32 v127, %[t1], %[sm], 1.0\n\t"                    \
+    "v_lshlrev_b32 %[t2], 29, " W_ "\n\t"                         \
+    "v_lshlrev_b32 %[t3], 28, " W_ "\n\t"                         \
+    "v_pk_fma_f32 v[" D_ ":" D_ "+1], v[" D_ ":" D_ "+1], v[126:127], v[" B_ ":" B_ "+1]\n\t" \
+    "v_and_or_b32 v126, %[t2], %[sm], 1.0\n\t"                    \
+    "v_and_or_b32 v127, %[t3], %[sm], 1.0\n\t"                    \
+    "v_pk_fma_f32 v[" D_ "+2:" D_ "+3], v[" D_ "+2:" D_ "+3], v[126:127], v[" B_ "+2:" B_ "+3]\n\t"
+#else
 #define LN_VG(D_, B_, W_)                                          \
     "v_lshlrev_b32 %[t0], 31, " W_ "\n\t"                         \
     "v_lshlrev_b32 %[t1], 30, " W_ "\n\t"                         \
@@ -1625,6 +1674,7 @@ __device__ __forceinline__ void vt_step(uint32_t wa, uint32_t wb, uint32_t wc, u
     "v_fma_f32 v[" D_ "+1], v[" D_ "+1], %[t1], v[" B_ "+1]\n\t"  \
     "v_fma_f32 v[" D_ "+2], v[" D_ "+2], %[t2], v[" B_ "+2]\n\t"  \
     "v_fma_f32 v[" D_ "+3], v[" D_ "+3], %[t3], v[" B_ "+3]\n\t"
+#endif
 #if LN_I8ROWS
     vt_widen<SET>();
 #endif
@@ -1851,6 +1901,20 @@ __device__ __forceinline__ void op_vt(Path& p, uint32_t off, const RowT* chan, u
 // c (the same 16 bytes per lane), the step of chunk c + 32 reads the slot back (into v[104 .. 107]: the bit registers of the
 // stages <= 7 are dead during this op), and leaves f there.  NS register sets of 4 * 2^LV registers from v128 on: the loads of
 // step c + NS - 1 are issued in front of step c.
+#if LN_PKFMA
+// (the four fma as two v_pk_fma_f32, the +-1.0 factors built in the free registers v[124 .. 127])
+#define LN_VGS(D_, B_, W_)                                        \
+    "v_lshlrev_b32 v124, %[s0], " W_ "\n\t"                      \
+    "v_lshlrev_b32 v125, %[s1], " W_ "\n\t"                      \
+    "v_lshlrev_b32 v126, %[s2], " W_ "\n\t"                      \
+    "v_lshlrev_b32 v127, %[s3], " W_ "\n\t"                      \
+    "v_and_or_b32 v124, v124, %[sm], 1.0\n\t"                    \
+    "v_and_or_b32 v125, v125, %[sm], 1.0\n\t"                    \
+    "v_and_or_b32 v126, v126, %[sm], 1.0\n\t"                    \
+    "v_and_or_b32 v127, v127, %[sm], 1.0\n\t"                    \
+    "v_pk_fma_f32 v[" D_ ":" D_ "+1], v[" D_ ":" D_ "+1], v[124:125], v[" B_ ":" B_ "+1]\n\t" \
+    "v_pk_fma_f32 v[" D_ "+2:" D_ "+3], v[" D_ "+2:" D_ "+3], v[126:127], v[" B_ "+2:" B_ "+3]"
+#else
 #define LN_VGS(D_, B_, W_)                                        \
     "v_lshlrev_b32 %[t0], %[s0], " W_ "\n\t"                     \
     "v_lshlrev_b32 %[t1], %[s1], " W_ "\n\t"                     \
@@ -1864,6 +1928,7 @@ __device__ __forceinline__ void op_vt(Path& p, uint32_t off, const RowT* chan, u
     "v_fma_f32 v[" D_ "+1], v[" D_ "+1], %[t1], v[" B_ "+1]\n\t" \
     "v_fma_f32 v[" D_ "+2], v[" D_ "+2], %[t2], v[" B_ "+2]\n\t" \
     "v_fma_f32 v[" D_ "+3], v[" D_ "+3], %[t3], v[" B_ "+3]"
+#endif
 constexpr int VTG_H = 104;  // v[104 .. 107]: the parked stage-8 chunk of the second half's steps
 constexpr int VTG_W = 108;  // v[108 .. 122]: the bit words of the current group of eight steps (word i of the op: v[108 + i])
 constexpr int VTG_A = 240;  // a[240 .. 254]: the words of the NEXT group land here (the compiler's spills stay below a104)

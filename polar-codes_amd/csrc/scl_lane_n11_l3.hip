@@ -1,7 +1,9 @@
 // lane-per-path list kernel, N = 2048, up to 8 paths (8 codewords per wave): scl_lane_kernel.hip under another geometry
 #define LN_LOGN 11
 #define LN_LCL 3
+#ifndef LN_BIG
 #define LN_BIG 1
+#endif
 #define LN_KERNEL_NAME scl_lane_n11_l3_kernel
 #define LN_LAUNCH_NAME launch_scl_lane_n11_l3
 #define LN_ARENA_NAME scl_lane_n11_l3_arena_words

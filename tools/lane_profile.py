@@ -10,7 +10,15 @@ import golden_io as gio
 import pypolar_amd
 os.environ.setdefault('PCD_ABLATE', '256')
 names = {73: "WALK", 64: 'VT', 65: 'F', 66: 'G', 67: 'G0', 68: 'C', 69: 'R0', 70: 'R1', 71: 'REP', 72: 'SPC', 0: 'END'}
-fx = gio.load_named(sys.argv[1] if len(sys.argv) > 1 else "cfg3_n1024_k512_l8_crc24_awgn.bin")
+if len(sys.argv) > 1 and ":" in sys.argv[1]:  # N:K:L -- a BB code with CRC-8 and AWGN rows instead of a fixture
+    from types import SimpleNamespace
+    _N, _K, _L = (int(v) for v in sys.argv[1].split(":"))
+    _rng = np.random.default_rng(1)
+    _fz = np.asarray(pypolar_amd.frozen_bits(_N, _K, 0.0, "BB"), dtype=np.uint32)
+    _llr = ((1.0 + 0.7 * _rng.standard_normal((16, _N))) * np.where(_rng.random((16, _N)) < 0.5, 1, -1)).astype(np.float32)
+    fx = SimpleNamespace(N=_N, L=_L, frozen=_fz, crc_size=8, crc_type="crc", llr=_llr)
+else:
+    fx = gio.load_named(sys.argv[1] if len(sys.argv) > 1 else "cfg3_n1024_k512_l8_crc24_awgn.bin")
 dectype = os.environ.get('LANE_PROFILE_TYPE', 'float')  # char: the int8 decoder (PCD_FORCE_LANE=1), the row is rounded to int8 values (x 8)
 if dectype == 'char':
     os.environ['PCD_FORCE_LANE'] = '1'
