@@ -179,6 +179,24 @@ __device__ __forceinline__ uint32_t rd_lane(uint32_t addr)
 
 // ---- f / g blocks on registers ----------------------------------------------------------------------------------------
 // text of f over 4 consecutive elements: v[D+k] = f(v[A+k], v[B+k]), D may equal A (the xor is taken first)
+#if LN_PKFMA
+// (packed: the sign of a product IS the xor of the signs -- zeros, denormals and infinities included --, so one v_pk_mul_f32
+//  replaces two v_xor_b32: ten instructions per block instead of twelve.  LN_FPAIR: a free even register pair for the products --
+//  v[254:255] while a walk runs (the stage registers end at v253), v[126:127] in the top-of-tree passes, whose register sets reach
+//  v255 while the bit registers v[104 .. 127] are dead.)
+#define LN_FPAIR "254"
+#define LN_F4T(D_, A_, B_)                                                                               \
+    "v_pk_mul_f32 v[" LN_FPAIR ":" LN_FPAIR "+1], v[" A_ ":" A_ "+1], v[" B_ ":" B_ "+1]\n\t"          \
+    "v_min_f32_e64 v[" D_ "], |v[" A_ "]|, |v[" B_ "]|\n\t"                                             \
+    "v_min_f32_e64 v[" D_ "+1], |v[" A_ "+1]|, |v[" B_ "+1]|\n\t"                                       \
+    "v_bfi_b32 v[" D_ "], %[am], v[" D_ "], v[" LN_FPAIR "]\n\t"                                        \
+    "v_bfi_b32 v[" D_ "+1], %[am], v[" D_ "+1], v[" LN_FPAIR "+1]\n\t"                                  \
+    "v_pk_mul_f32 v[" LN_FPAIR ":" LN_FPAIR "+1], v[" A_ "+2:" A_ "+3], v[" B_ "+2:" B_ "+3]\n\t"      \
+    "v_min_f32_e64 v[" D_ "+2], |v[" A_ "+2]|, |v[" B_ "+2]|\n\t"                                       \
+    "v_min_f32_e64 v[" D_ "+3], |v[" A_ "+3]|, |v[" B_ "+3]|\n\t"                                       \
+    "v_bfi_b32 v[" D_ "+2], %[am], v[" D_ "+2], v[" LN_FPAIR "]\n\t"                                    \
+    "v_bfi_b32 v[" D_ "+3], %[am], v[" D_ "+3], v[" LN_FPAIR "+1]\n\t"
+#else
 #define LN_F4T(D_, A_, B_)                                       \
     "v_xor_b32 %[t0], v[" A_ "], v[" B_ "]\n\t"                  \
     "v_xor_b32 %[t1], v[" A_ "+1], v[" B_ "+1]\n\t"              \
@@ -192,6 +210,7 @@ __device__ __forceinline__ uint32_t rd_lane(uint32_t addr)
     "v_bfi_b32 v[" D_ "+1], %[am], v[" D_ "+1], %[t1]\n\t"       \
     "v_bfi_b32 v[" D_ "+2], %[am], v[" D_ "+2], %[t2]\n\t"       \
     "v_bfi_b32 v[" D_ "+3], %[am], v[" D_ "+3], %[t3]\n\t"
+#endif
 // text of g over 4 consecutive elements whose inputs are in place: v[D+k] = g(v[D+k], v[B+k], bit E+k of %[w])
 #if LN_PKFMA
 // (packed: the +-1.0 factors pair up in v[254:255], free while a walk runs -- the stage registers end at v253)
@@ -233,12 +252,20 @@ __device__ __forceinline__ void f_block(uint32_t absmask)
                      : [d] "n"(D), [a] "n"(A), [b] "n"(B), [am] "s"(absmask));
     } else {
         asm volatile(
+#if LN_PKFMA
+            "v_pk_mul_f32 v[254:255], v[%[a]:%[a]+1], v[%[b]:%[b]+1]\n\t"
+            "v_min_f32_e64 v[%[d]], |v[%[a]]|, |v[%[b]]|\n\t"
+            "v_min_f32_e64 v[%[d]+1], |v[%[a]+1]|, |v[%[b]+1]|\n\t"
+            "v_bfi_b32 v[%[d]], %[am], v[%[d]], v254\n\t"
+            "v_bfi_b32 v[%[d]+1], %[am], v[%[d]+1], v255"
+#else
             "v_xor_b32 %[t0], v[%[a]], v[%[b]]\n\t"
             "v_xor_b32 %[t1], v[%[a]+1], v[%[b]+1]\n\t"
             "v_min_f32_e64 v[%[d]], |v[%[a]]|, |v[%[b]]|\n\t"
             "v_min_f32_e64 v[%[d]+1], |v[%[a]+1]|, |v[%[b]+1]|\n\t"
             "v_bfi_b32 v[%[d]], %[am], v[%[d]], %[t0]\n\t"
             "v_bfi_b32 v[%[d]+1], %[am], v[%[d]+1], %[t1]"
+#endif
             : [t0] "=&v"(t0), [t1] "=&v"(t1)
             : [d] "n"(D), [a] "n"(A), [b] "n"(B), [am] "s"(absmask));
     }
@@ -1583,6 +1610,10 @@ __device__ __forceinline__ void op_combine(Path& p, uint32_t side)
     }
 }
 
+#if LN_PKFMA
+#undef LN_FPAIR
+#define LN_FPAIR "126"  // (the top-of-tree passes: see LN_F4T)
+#endif
 // int8 channel rows: a dword of four LLRs in v[R] -> four floats in v[R .. R + 3] (v_cvt_f32_i32 on a sign-extended byte)
 #define LN_WIDEN4(R_)                                                                                                   \
     "v_cvt_f32_i32_sdwa v[" R_ "+3], sext(v[" R_ "]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3\n\t"           \
@@ -2290,6 +2321,10 @@ __device__ __forceinline__ void leaf_r0_high(Path& p, uint32_t side, uint32_t of
 #undef LN_VGS
 #endif  // LN_LOGN != 10
 #undef LN_WIDEN4
+#if LN_PKFMA
+#undef LN_FPAIR
+#define LN_FPAIR "254"  // (walks again)
+#endif
 
 // stage 8 (arena column) -> stage 7 (LDS column): kind 0 = F, 1 = G (column of the slot owner), 2 = a + b (= G with zero
 // bits).  Eight steps per batch: their sixteen 16-byte loads go out together into v[128 .. 191] (dead stages), the steps
