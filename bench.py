@@ -146,6 +146,12 @@ CONFIGS = {
                  name="5G-table N=1024 K=176 SCL L=8 + CRC-11, batch=2^19 per GPU (2^22 over 8)"),
     "cfg5": dict(N=4096, K=2048, L=32, dsnr=0.0, crc=32, crc_type="crc", ebn0=1.5, log2_batch=15,
                  name="N=4096 K=2048 SCL L=32 + CRC-32C, batch=2^15 per GPU (2^18 over 8)"),
+    # cells of the reference's own benchmark grid (benchmark/main_benchmark.cpp:405-500) that the round-4 geometries of the
+    # lane-per-path kernel serve; not BASELINE configurations -- for profiles (tools/collect_profiles.sh)
+    "n512_l8": dict(N=512, K=256, L=8, dsnr=0.0, crc=8, crc_type="crc", ebn0=2.0, log2_batch=18, name="N=512 K=256 SCL L=8 + CRC-8, batch=2^18"),
+    "n2048_l8": dict(N=2048, K=1024, L=8, dsnr=0.0, crc=8, crc_type="crc", ebn0=2.0, log2_batch=17, name="N=2048 K=1024 SCL L=8 + CRC-8, batch=2^17"),
+    "n1024_l16": dict(N=1024, K=512, L=16, dsnr=0.0, crc=8, crc_type="crc", ebn0=2.0, log2_batch=17, name="N=1024 K=512 SCL L=16 + CRC-8, batch=2^17"),
+    "n1024_l32": dict(N=1024, K=512, L=32, dsnr=0.0, crc=8, crc_type="crc", ebn0=2.0, log2_batch=16, name="N=1024 K=512 SCL L=32 + CRC-8, batch=2^16"),
     # secondary workload: rate matching in front of the decoder (PolarCode::Puncturer::depuncture<float>)
     "dep3": dict(N=1024, K=512, L=0, dsnr=0.0, crc=0, crc_type="crc", ebn0=2.0, log2_batch=20, M=864,
                  name="depuncture 864 -> 1024 float LLRs (160 frozen positions removed), batch=2^20"),

@@ -52,7 +52,11 @@
 #ifndef LN_LCL
 #define LN_LCL 3
 #endif
+#ifdef LN_FORCE_GENERIC  // (experiments: the default geometry compiled through the code paths of the other geometries)
+#define LN_GEO_DEFAULT 0
+#else
 #define LN_GEO_DEFAULT (LN_LOGN == 10 && LN_LCL == 3)
+#endif
 // LN_PKFMA: the g's four v_fma_f32 as two v_pk_fma_f32 (and a + b as v_pk_add_f32).  At one wave per SIMD an instruction of any
 // kind takes one 4-cycle issue slot, a packed one included (measured on cfg 5: ten instead of twelve instructions per g block of the
 // top-of-tree pass = +1.7 %), and the packed fma is the same fused operation per component: results unchanged bit for bit.

@@ -17,6 +17,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
 n_cfg = n_rows = n_bad = n_refused = 0
+kernels = {}
 t_print = time.time()
 while time.time() < t_end:
     if time.time() - t_print > 30:
@@ -24,7 +25,10 @@ while time.time() < t_end:
         print(f"... {n_cfg} configurations, {n_rows} rows, {n_bad} mismatching", flush=True)
     logN = int(rng.integers(3, 16))
     L = int(rng.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 8, 11, 16, 24, 32]))
-    if os.environ.get("FUZZ_LANE"):  # only what the lane-per-path list kernel takes: N = 1024, 4 < L <= 8
+    if os.environ.get("FUZZ_LANE") == "geo":  # the round-4 geometries of the lane-per-path kernel: N = 512 .. 4096, L = 5 .. 32
+        logN = int(rng.choice([9, 10, 10, 11, 11, 12]))
+        L = int(rng.choice([5, 7, 8, 8, 9, 12, 16, 16, 17, 24, 32, 32]))
+    elif os.environ.get("FUZZ_LANE"):  # only what the lane-per-path list kernel of round 3 takes: N = 1024, 4 < L <= 8
         logN = 10
         L = int(rng.choice([5, 6, 7, 8, 8, 8]))
     N = 1 << logN
@@ -69,12 +73,18 @@ while time.time() < t_end:
         except ValueError:
             n_refused += 1
         continue
+    # (small batches are routed to a sibling geometry by default: the fuzz of the throughput kernels switches that off, the general
+    #  fuzz takes either side at random)
+    pypolar_amd.SMALL_BATCH_ROWS = 0 if (os.environ.get("FUZZ_LANE") or rng.integers(0, 2)) else None
     try:
         d = pypolar_amd.PolarDecoder(N, L, frozen, dectype)
     except pypolar_amd.PolarAmdError as e:
         if e.code == -9:        # documented capacity limit
             continue
         raise
+    if L > 1:
+        kname = d.kernel_name(True)
+        kernels[kname] = kernels.get(kname, 0) + 1
     d.setErrorDetection(det, typ)
     d.setSystematic(sysm)
     want_m = L > 1 and dectype == "float"
@@ -93,3 +103,4 @@ while time.time() < t_end:
         n_bad += 1
         print(f"MISMATCH N={N} K={K} L={L} kind={kind} det={det} sys={sysm} i8={i8} type={dectype} B={B}: {bad} bad rows")
 print(f"configurations {n_cfg}, rows {n_rows}, refused by both builders {n_refused}, mismatching configurations {n_bad}")
+print("list kernels:", ", ".join(f"{k} {v}" for k, v in sorted(kernels.items())))
