@@ -416,6 +416,10 @@ def pmc_issue(config, log2b, kernel_substr, codewords):
                 "salu_frac": (per["SQ_INSTS_SALU"] + per["SQ_INSTS_BRANCH"]) / insts, "valu_frac": per["SQ_INSTS_VALU"] / insts,
                 "wait_frac": per["SQ_WAIT_ANY"] / per["SQ_WAVE_CYCLES"],
                 "active_frac": per["SQ_ACTIVE_INST_ANY"] / per["SQ_WAVE_CYCLES"],
+                # how far from the one-wave issue wall the kernel runs: a wave alone on its SIMD issues one instruction of any
+                # kind per 4 cycles (MI355X_MICROARCH.md), SQ_WAVE_CYCLES counts quad-cycles, so instructions / SQ_WAVE_CYCLES
+                # = (instructions x 4 cycles) / wave cycles.  Meaningful for the one-wave-per-SIMD kernels (lane / pair).
+                "issue_bound_frac": insts / per["SQ_WAVE_CYCLES"],
                 "source": "rocprofv3 --pmc " + " ".join(names) + " (one child pass, 1 step)"}
     except Exception as e:  # noqa: BLE001
         print(f"[bench] PMC pass (SQ) failed: {e}", file=sys.stderr)
