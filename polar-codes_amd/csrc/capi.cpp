@@ -993,8 +993,9 @@ int decode_host_pipelined(pcd_decoder* d, const void* llr, bool i8, size_t rows,
         d->h_res_cap = res_bytes;
     }
     uint8_t* const h_out = d->h_res;
-    uint8_t* const h_ok = d->h_res + out_bytes;
-    float* const h_met = reinterpret_cast<float*>(d->h_res + ((out_bytes + rows + 15) & ~(size_t)15));
+    // (the staging buffer exists only when the results are streamed: no pointer arithmetic on a null base otherwise)
+    uint8_t* const h_ok = stream_results ? d->h_res + out_bytes : nullptr;
+    float* const h_met = stream_results ? reinterpret_cast<float*>(d->h_res + ((out_bytes + rows + 15) & ~(size_t)15)) : nullptr;
     if (!d->s_out) HIP_TRY(hipStreamCreateWithFlags(&d->s_out, hipStreamNonBlocking));
     if (!d->s_in) {
         HIP_TRY(hipStreamCreateWithFlags(&d->s_in, hipStreamNonBlocking));

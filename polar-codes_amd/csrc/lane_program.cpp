@@ -25,6 +25,15 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
     };
     bool right_half = false;  // the root's G has been seen
     bool isg_at[16] = { false };  // other block lengths: what the last op seen at stage t >= 9 was (true: a G)
+    // N >= 2048: a leaf of 512 / 1024 LLRs -- the kernel recomputes its block from the channel row (off bit l = the op at stage
+    // logN - l is a G, for the stages logN .. stage + 1)
+    auto high_leaf = [&](const Ins& x) { return x.stage > 8 && logN >= 11 && x.stage <= 10 && x.stage < logN; };
+    auto high_gm = [&](unsigned stage) {
+        unsigned gm = 0;
+        for (unsigned t = stage + 1u; t <= logN; ++t)
+            if (isg_at[t]) gm |= 1u << (logN - t);
+        return gm;
+    };
     for (size_t k = 0; k < v.size(); ++k) {
         const Ins& x = v[k];
         switch (x.op) {
@@ -39,8 +48,10 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
                 isg_at[x.stage] = isg;
                 if (x.stage > 9) {  // must be followed by the F of the stage below, or by an all-frozen leaf of 512 / 1024 LLRs
                     if (k + 1 >= v.size() || v[k + 1].stage + 1u != x.stage) return false;
-                    const bool r0_high = v[k + 1].op == SCL_R0 && logN >= 11 && v[k + 1].stage <= 10 && v[k + 1].stage + 1u <= logN - 0u && v[k + 1].stage < logN;
-                    if (v[k + 1].op != SCL_F && !r0_high) return false;
+                    const uint8_t nop = v[k + 1].op;
+                    const bool leaf_high = (nop == SCL_R0 || nop == SCL_R1 || nop == SCL_SPC || (chr && nop == SCL_REP)) && logN >= 11 && v[k + 1].stage <= 10 &&
+                                           v[k + 1].stage < logN;
+                    if (nop != SCL_F && !leaf_high) return false;
                     continue;
                 }
                 unsigned gm = 0;
@@ -79,13 +90,8 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
             put(LN_C, x.stage, x.side, 0);
             break;
         case SCL_R0:
-            if (x.stage > 8 && logN >= 11 && x.stage <= 10 && x.stage < logN) {
-                // an all-frozen leaf of 512 / 1024 LLRs: recomputed from the channel row by the kernel; off bit l = the op at
-                // stage logN - l is a G (the stages logN .. stage + 1)
-                unsigned gm = 0;
-                for (unsigned t = x.stage + 1u; t <= logN; ++t)
-                    if (isg_at[t]) gm |= 1u << (logN - t);
-                put(LN_R0, x.stage, x.side, gm);
+            if (high_leaf(x)) {
+                put(LN_R0, x.stage, x.side, high_gm(x.stage));
                 if (needs_hi) *needs_hi = true;
                 break;
             }
@@ -93,16 +99,31 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
             put(LN_R0, x.stage, x.side, 0);
             break;
         case SCL_R1:
+            if (high_leaf(x)) {
+                put(LN_R1, x.stage, x.side, high_gm(x.stage));
+                if (needs_hi) *needs_hi = true;
+                break;
+            }
             if (x.stage > 8 || x.stage < 1) return false;
             if (x.stage == 8 && needs_big) *needs_big = true;  // (a forking leaf of 256 LLRs: the BIG instantiation of the kernel)
             put(LN_R1, x.stage, x.side, 0);
             break;
         case SCL_SPC:
+            if (high_leaf(x)) {
+                put(LN_SPC, x.stage, x.side, high_gm(x.stage));
+                if (needs_hi) *needs_hi = true;
+                break;
+            }
             if (x.stage > 8 || x.stage < 2) return false;
             if (x.stage == 8 && needs_big) *needs_big = true;
             put(LN_SPC, x.stage, x.side, 0);
             break;
         case SCL_REP:
+            if (chr && high_leaf(x)) {
+                put(LN_REP, x.stage, x.side, high_gm(x.stage));
+                if (needs_hi) *needs_hi = true;
+                break;
+            }
             if (x.stage > (chr ? 8u : 2u) || x.stage < 1) return false;  // (int8 decoder: repetition leaves at every size)
             put(LN_REP, x.stage, x.side, 0);
             break;
@@ -114,7 +135,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
     // the virtual rows that pass would have produced come from an op of their own
     if (out.ins.empty()) return false;
     if (out.ins[0].op != LN_VT) {
-        if (!(logN >= 11 && out.ins[0].op == LN_R0 && out.ins[0].stage > 8)) return false;
+        if (!(logN >= 11 && out.ins[0].op >= LN_R0 && out.ins[0].op <= LN_SPC && out.ins[0].stage > 8)) return false;
         Ins i;
         i.op = (uint8_t)LN_VROWS;
         i.stage = (uint8_t)logN;

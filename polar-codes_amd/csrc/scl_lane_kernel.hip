@@ -1467,6 +1467,11 @@ __device__ __forceinline__ void fork_tail(Path& p, uint32_t T, uint32_t side, We
     // fork record of this lane's path: the new hosts of its children read it
     uint4* rec = reinterpret_cast<uint4*>(p.lds + SCR_FORK + p.lane * 8);
     const uint32_t packed = (wi[0] & 0xFFu) | ((wi[1] & 0xFFu) << 8) | ((wi[2] & 0xFFu) << 16) | ((wi[3] & 0xFFu) << 24);
+#if LN_LOGN >= 11 && LN_HILEAF
+    if (T >= 9u)  // (a block of 512 / 1024 LLRs: 16-bit weak indices; the sign words are in the arena already, leaf_scan_high)
+        rec[0] = make_uint4(0u, (wi[0] & 0xFFFFu) | (wi[1] << 16), par, (wi[2] & 0xFFFFu) | (wi[3] << 16));
+    else
+#endif
     rec[0] = make_uint4(ws.sg[0], packed, par, ws.sg[1]);
 #if LN_BIG
     if (T >= 7u) rec[1] = make_uint4(ws.sg[2], ws.sg[3], 0u, 0u);
@@ -1493,6 +1498,35 @@ __device__ __forceinline__ void fork_tail(Path& p, uint32_t T, uint32_t side, We
         fl[2] = fl[3] = 0;
     }
     constexpr int NF = SPC ? 4 : 2;
+#if LN_LOGN >= 11 && LN_HILEAF
+    if (T >= 9u) {
+        // the source path's sign words (its column of this leaf's output area, where its scan left them) with the candidate's flips,
+        // eight words at a time: every lane reads a batch before any lane writes it, so the rewrite in place is safe
+        const uint32_t ix[4] = { s0.y & 0xFFFFu, s0.y >> 16, s0.w & 0xFFFFu, s0.w >> 16 };
+        uint32_t ln = (uint32_t)p.lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t area = T == 9u ? (side ? AR_BR(9) : AR_BL(9)) : (side ? AR_BR(10) : AR_BL(10));
+        const uint32_t* sp = p.arena + area + src;
+        uint32_t* dp = p.arena + area + ln;
+        const uint32_t nw = 1u << (T - 5u);
+#pragma unroll 1
+        for (uint32_t i0 = 0; i0 < nw; i0 += 8) {
+            uint32_t wd[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wd[i] = sp[(i0 + (uint32_t)i) * 64u];
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wd[i] ^= ((ix[k] >> 5) == i0 + (uint32_t)i) ? (fl[k] << (ix[k] & 31u)) : 0u;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (all loads of the batch have landed in every lane)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dp[(i0 + (uint32_t)i) * 64u] = wd[i];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+#endif
     uint32_t w[4] = { s0.x, s0.w, 0u, 0u };
 #if LN_BIG
     if (T == 8u) {  // a block of 256 LLRs: eight words, to the arena like the other bits of that stage
@@ -2147,12 +2181,14 @@ struct SinkMin0 {
 // The pass itself.  TOP: the stage of the source row (LOGN: the channel row; lower: a virtual row), TOUT: the stage of the block
 // it produces chunk by chunk (8: the top-of-tree pass), LV = TOP - TOUT levels; gm bit l: the op at stage TOP - l is a g.
 // 2^TOUT / 4 steps in groups of eight (one bit word per block and group), NS register sets.
-template <int TOP, int TOUT, bool CH, typename RT, typename SINK>
+// (NSO: another number of register sets than VtgGeo's -- the leaves above stage 8 run with two: their sinks are large, and every
+//  set is another copy of them)
+template <int TOP, int TOUT, bool CH, typename RT, typename SINK, int NSO = 0>
 __device__ __forceinline__ void vtg_core(Path& p, uint32_t gm, const RT* chan, uint32_t absmask, uint32_t signmask, SINK& sink)
 {
     constexpr int LV = TOP - TOUT;
     using G = VtgGeo<LV>;
-    constexpr int NS = G::NS, SW = G::SW;
+    constexpr int NS = NSO ? NSO : G::NS, SW = G::SW;
     constexpr uint32_t NG = (1u << TOUT) / 32u;  // groups of eight steps
     // the g that has just been executed is the one at the lowest stage: its left child's bits are this lane's own
     if (gm) p.set_field((uint32_t)TOP - (31u - (uint32_t)__builtin_clz(gm)));
@@ -2282,31 +2318,66 @@ __device__ __forceinline__ void op_vtg(Path& p, uint32_t off, const RowT* chan, 
     }
 }
 #if LN_LOGN >= 11 && LN_HILEAF
+// RateOneDecoder / SpcDecoder (scl_avx_float.cpp:353-413, 498-621) on a block of 512 / 1024 LLRs (rates above 1/2 at N >= 2048), first
+// half: the pass recomputes the block chunk by chunk; the sink collects the hard decisions -- a word per eight steps, written to
+// the lane's own column of the leaf's output area, which fork_tail then rewrites in place with the chosen candidate's flips -- and
+// runs the weak-LLR scan of findWeakLlrs on the magnitudes.  ws.sg[0] ends up as the XOR of all sign words (the parity SPC needs).
+template <bool CH>
+struct SinkScan {
+    WeakScan* ws;
+    uint32_t* dst;  // own column of the output area: word i at dst[i * 64]
+    uint32_t word, par;
+    __device__ __forceinline__ void pre(uint32_t) const {}
+    template <int S, int PAR>
+    __device__ __forceinline__ void take(uint32_t c)
+    {
+        const uint32_t e[4] = { rdu<S>(), rdu<S + 1>(), rdu<S + 2>(), rdu<S + 3>() };
+        const uint32_t sh = 4u * (c & 7u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t a = e[i] & 0x7FFFFFFFu;
+            if constexpr (CH) a = a < 0x42FE0000u ? a : 0x42FE0000u;  // (int8 decoder: abs(max(x, -127)))
+            word |= (e[i] >> 31) << (sh + (uint32_t)i);
+            if (c == 0u) ws->hv[i] = a;
+            else ws->tail(a, 4u * c + (uint32_t)i);
+        }
+        if ((c & 7u) == 7u) {
+            dst[(c >> 3) * 64u] = word;
+            par ^= word;
+            word = 0;
+        }
+    }
+};
+// the int8 decoder's repetition leaf at these sizes (scl_fip_char.cpp:497-547): exact sums of min(x, 0) and of x
+struct SinkRep {
+    float zs, xs;
+    __device__ __forceinline__ void pre(uint32_t) const {}
+    template <int S, int PAR>
+    __device__ __forceinline__ void take(uint32_t)
+    {
+        const float a = rdf<S>(), b = rdf<S + 1>(), c = rdf<S + 2>(), d = rdf<S + 3>();
+        zs += (min0(a) + min0(b)) + (min0(c) + min0(d));
+        xs += (a + b) + (c + d);
+    }
+};
+// the block of a leaf at stage T = 9 / 10, recomputed from the channel row through all LOGN - T levels (off bit l: the op at stage
+// LOGN - l is a g) and handed to the sink chunk by chunk.  (Always from the channel row, not from a virtual row, and with two
+// register sets: one instantiation of the pass per (stage, sink) -- these leaves run once or twice per codeword.)
+template <int T, bool CH, typename SINK>
+__device__ __forceinline__ void high_pass(Path& p, uint32_t off, const RowT* chan, uint32_t absmask, uint32_t signmask, SINK& sink)
+{
+    vtg_core<LOGN, T, CH, RowT, SINK, 2>(p, off & ((1u << (LOGN - T)) - 1u), chan, absmask, signmask, sink);
+}
 // RateZeroDecoder::decode scl_avx_float.cpp:316-337 on a block of 512 / 1024 LLRs (stage T = 9, 10: the low rates at N >= 2048).
 // The block is never stored: the pass recomputes it from the channel row -- or from the highest virtual row it can use -- and
 // the sink adds up min(x, 0) in the reference's order; the output bits are zeros.  off bit l: the op at stage LOGN - l is a g.
-template <int T, int L0, bool CH>
-__device__ __forceinline__ void r0_high_from(Path& p, uint32_t gm, const RowT* chan, const float* vrow, uint32_t absmask, uint32_t signmask, SinkMin0& sink)
-{
-    if constexpr (L0 == 0) vtg_core<LOGN, T, CH, RowT>(p, gm, chan, absmask, signmask, sink);
-    else vtg_core<LOGN - L0, T, CH, float>(p, gm >> L0, vrow + vrow_off(LOGN - L0), absmask, signmask, sink);
-}
 template <int T, bool CH>
 __device__ __forceinline__ void leaf_r0_high(Path& p, uint32_t side, uint32_t off, const RowT* chan, uint32_t absmask, uint32_t signmask)
 {
-    constexpr int LVR = LOGN - T;
-    const uint32_t gm = off & ((1u << LVR) - 1u);
-    const float* const vrow = reinterpret_cast<const float*>(p.arena + AR_VROW) + ((uint32_t)p.lane >> LCL) * VROW_FLOATS;
     SinkMin0 sink;
 #pragma unroll
     for (int j = 0; j < 8; ++j) sink.acc[j] = 0.0f;
-    const uint32_t l0 = gm ? (uint32_t)__builtin_ctz(gm) : (uint32_t)LVR;  // leading f levels: path-independent
-    switch (l0) {
-    case 0: r0_high_from<T, 0, CH>(p, gm, chan, vrow, absmask, signmask, sink); break;
-    case 1: r0_high_from<T, 1, CH>(p, gm, chan, vrow, absmask, signmask, sink); break;
-    case 2: if constexpr (LVR >= 2) r0_high_from<T, 2, CH>(p, gm, chan, vrow, absmask, signmask, sink); break;
-    default: if constexpr (LVR >= 3) r0_high_from<T, 3, CH>(p, gm, chan, vrow, absmask, signmask, sink); break;
-    }
+    high_pass<T, CH>(p, off, chan, absmask, signmask, sink);
     const float* a = sink.acc;
     p.metric = p.metric + (((((((a[0] + a[1]) + a[2]) + a[3]) + a[4]) + a[5]) + a[6]) + a[7]);
     uint32_t ln = (uint32_t)p.lane;
@@ -2318,6 +2389,41 @@ __device__ __forceinline__ void leaf_r0_high(Path& p, uint32_t side, uint32_t of
         o[(i + 1) * 64] = 0u;
         o[(i + 2) * 64] = 0u;
         o[(i + 3) * 64] = 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <int T, bool CH>
+__device__ __forceinline__ void leaf_scan_high(Path& p, uint32_t side, uint32_t off, const RowT* chan, uint32_t absmask, uint32_t signmask, WeakScan& ws)
+{
+    ws.init();
+    uint32_t ln = (uint32_t)p.lane;
+    asm volatile("" : "+v"(ln));
+    SinkScan<CH> sink{ &ws, p.arena + (side ? AR_BR(T) : AR_BL(T)) + ln, 0u, 0u };
+    high_pass<T, CH>(p, off, chan, absmask, signmask, sink);
+    ws.sg[0] = sink.par;
+    ws.sg[1] = ws.sg[2] = ws.sg[3] = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <int T, bool CH>
+__device__ __forceinline__ void leaf_rep_high(Path& p, uint32_t side, uint32_t off, const RowT* chan, uint32_t absmask, uint32_t signmask, const Stamps& sm)
+{
+    SinkRep sink{ 0.0f, 0.0f };
+    high_pass<T, CH>(p, off, chan, absmask, signmask, sink);
+    float cm[2];
+    cm[0] = p.metric + sink.zs;
+    cm[1] = p.metric - (sink.xs - sink.zs);
+    uint32_t src, cand;
+    select_fork<2>(p, cm, src, cand, sm);
+    uint32_t ln = (uint32_t)p.lane;
+    asm volatile("" : "+v"(ln));
+    uint32_t* o = p.arena + (side ? AR_BR(T) : AR_BL(T)) + ln;
+    const uint32_t w = cand ? 0xFFFFFFFFu : 0u;
+#pragma unroll 1
+    for (uint32_t i = 0; i < ar_bitwords(T); i += 4) {
+        o[(i + 0) * 64] = w;
+        o[(i + 1) * 64] = w;
+        o[(i + 2) * 64] = w;
+        o[(i + 3) * 64] = w;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -2659,7 +2765,11 @@ void scl_lane_kernel(const DecodeParams P)
                     switch (lcode) {  // (flat: see the G step)
 #if LN_LOGN >= 11 && LN_HILEAF
                     case 0x19: leaf_r0_high<9, CH>(p, lside, off, chan, absmask, signmask); break;
-                    case 0x1A: if constexpr (LOGN >= 12) leaf_r0_high<(LOGN >= 12 ? 10 : 9), CH>(p, lside, off, chan, absmask, signmask); break;
+                    case 0x1A: leaf_r0_high<10, CH>(p, lside, off, chan, absmask, signmask); break;
+                    case 0x29: if constexpr (CH) leaf_rep_high<9, CH>(p, lside, off, chan, absmask, signmask, sm); break;
+                    case 0x2A: if constexpr (CH) leaf_rep_high<10, CH>(p, lside, off, chan, absmask, signmask, sm); break;
+                    case 0x39: leaf_scan_high<9, CH>(p, lside, off, chan, absmask, signmask, ws); break;
+                    case 0x3A: leaf_scan_high<10, CH>(p, lside, off, chan, absmask, signmask, ws); break;
 #endif
                     case 0x18: leaf_r0<8>(p, lside); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
                     case 0x17: leaf_r0<7>(p, lside); break;

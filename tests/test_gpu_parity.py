@@ -335,7 +335,11 @@ LANE_GEO_CODES = [(512, 256, 8, "BB"), (512, 128, 6, "BB"), (512, 256, 16, "BB")
                   (2048, 1024, 8, "BB"), (2048, 512, 7, "BE"), (2048, 1500, 8, "BB"), (2048, 1024, 16, "BB"), (2048, 700, 24, "BB"), (2048, 1024, 8, "rand"),
                   (4096, 2048, 8, "BB"), (4096, 2048, 16, "BB"), (4096, 2048, 32, "BB"), (4096, 2048, 20, "BE"),
                   # low rates: an all-frozen leaf of 512 / 1024 LLRs, recomputed from the channel row (the *_hi kernels)
-                  (4096, 1400, 32, "BB"), (2048, 256, 8, "BB"), (4096, 512, 16, "BB"), (4096, 256, 8, "BE"), (2048, 128, 32, "BB")]
+                  (4096, 1400, 32, "BB"), (2048, 256, 8, "BB"), (4096, 512, 16, "BB"), (4096, 256, 8, "BE"), (2048, 128, 32, "BB"),
+                  (2048, 72, 17, "BB"), (2048, 72, 8, "BB"),      # (an all-frozen leaf of 1024 LLRs at N = 2048: found by the round-4 fuzz)
+                  # high rates: RateOne / SPC leaves of 512 / 1024 LLRs (scan sink of the pass, sign words rewritten in place)
+                  (2048, 1664, 8, "BB"), (2048, 1920, 16, "BB"), (2048, 1800, 32, "BE"), (4096, 2304, 8, "BB"), (4096, 2816, 16, "BB"),
+                  (4096, 3328, 32, "BB"), (4096, 3840, 8, "BE"), (4096, 3000, 17, "BB")]
 
 
 @pytest.mark.parametrize("N,K,L,kind", LANE_GEO_CODES, ids=[f"N{n}_K{k}_L{l}_{c}" for n, k, l, c in LANE_GEO_CODES])
@@ -358,8 +362,8 @@ def test_lane_kernel_geometries(built_library, N, K, L, kind):
     eighths = (np.round(awgn[: rows // 2] * 8) / 8).astype(np.float32)    # quantised: equal metrics at most forks
     llr = np.concatenate([awgn, noise, ties, eighths])
     d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
-    if kind == "BB" and 2 * K <= N:
-        assert d.kernel_name(True).startswith("scl_lane_"), d.kernel_name(True)   # (expressible: the new kernels run; a RateOne / SPC leaf above stage 8 -- high rates at N >= 2048 -- keeps the path-group kernels)
+    if kind in ("BB", "BE"):
+        assert d.kernel_name(True).startswith("scl_lane_"), d.kernel_name(True)   # (every construction of this list is expressible: the lane kernels run)
     for systematic in (True, False):
         e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, 8, llr, systematic, "float")
         d.setErrorDetection(8, "crc")
@@ -370,7 +374,8 @@ def test_lane_kernel_geometries(built_library, N, K, L, kind):
         assert np.array_equal(met.view(np.uint32), e_met.view(np.uint32)), "path metrics differ from the oracle's"
 
 
-LANE_GEO_CHAR_CODES = [(512, 200, 32), (1024, 512, 16), (1024, 512, 32), (2048, 1024, 8), (2048, 1024, 16), (2048, 700, 32), (2048, 256, 8), (4096, 1024, 8)]
+LANE_GEO_CHAR_CODES = [(512, 200, 32), (1024, 512, 16), (1024, 512, 32), (2048, 1024, 8), (2048, 1024, 16), (2048, 700, 32), (2048, 256, 8), (4096, 1024, 8),
+                       (2048, 1800, 8), (4096, 3000, 8), (4096, 2560, 32), (2048, 256, 16)]   # (leaves of 512 / 1024 LLRs, the repetition leaf included)
 
 
 @pytest.mark.parametrize("N,K,L", LANE_GEO_CHAR_CODES, ids=[f"N{n}_K{k}_L{l}" for n, k, l in LANE_GEO_CHAR_CODES])
@@ -853,9 +858,10 @@ def test_large_host_batch_goes_through_the_pinned_ring(built_library):
     dq = _decoder(fq)
     reps = 120000 // fq.count + 1
     rows8 = np.tile(fq.llr.astype(np.int8), (reps, 1))[:120001]     # 117 MiB of int8 rows
-    out, ok = dq.decode_batch(rows8)
+    out, ok, met = dq.decode_batch(rows8, return_metrics=True)      # (int8 rows: the results are streamed through the pinned staging buffer, metrics included)
     idx = np.arange(rows8.shape[0]) % fq.count
     assert np.array_equal(out, fq.out[idx]) and np.array_equal(ok.astype(np.uint8), fq.ok[idx])
+    assert np.array_equal(met.view(np.uint32), fq.metrics[idx].view(np.uint32))
 
 
 @pytest.mark.parametrize("name", ["cfg2_n1024_k512_sc_awgn.bin", "cfg3_n1024_k512_l8_crc24_awgn.bin", "cfg4_n1024_k176_l8_crc11_awgn.bin",

@@ -361,7 +361,8 @@ def test_lane_kernel_rule(built_library, dectype, K, kind, lane):
     (2048, 8, 1024, "scl_lane_n11_l3_kernel"), (2048, 16, 1024, "scl_lane_n11_l4_kernel"), (2048, 20, 1024, "scl_lane_n11_l5_kernel"),
     (4096, 6, 2048, "scl_lane_n12_l3_kernel"), (4096, 16, 2048, "scl_lane_n12_l4_kernel"), (4096, 32, 2048, "scl_lane_n12_l5_kernel"),
     (4096, 32, 1024, "scl_lane_n12_l5_hi_kernel"), (2048, 8, 256, "scl_lane_n11_l3_hi_kernel"),   # low rates: an all-frozen leaf of 512 / 1024 LLRs
-    (4096, 32, 3000, "scl_decode_kernel"),   # a RateOne / SPC leaf above stage 8: the lowering cannot express the tree
+    (4096, 32, 3000, "scl_lane_n12_l5_hi_kernel"), (2048, 16, 1800, "scl_lane_n11_l4_hi_kernel"),   # high rates: RateOne / SPC leaves of 512 / 1024 LLRs
+    (2048, 8, 72, "scl_lane_n11_l3_hi_kernel"),   # half of the code word frozen: an all-frozen leaf of 1024 LLRs at N = 2048
     (1024, 4, 512, "scl_decode_kernel"), (8192, 8, 4096, "scl_decode_kernel"), (256, 8, 128, "scl_decode_kernel"),
     (512, 8, 32, "scl_decode_kernel")])      # fewer than 48 leaves
 def test_kernel_name_reports_the_side_of_the_geometry_rules(built_library, N, L, K, name):
