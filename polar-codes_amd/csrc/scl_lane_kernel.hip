@@ -2635,6 +2635,10 @@ void scl_lane_kernel(const DecodeParams P)
             //  geometries the compiler otherwise keeps -- and spills to scratch -- dozens of precomputed 64-bit column addresses)
 #if defined(LN_OPAQUE_LANE) && LN_OPAQUE_LANE == 1
             asm volatile("" : "+v"(p.lane));
+#elif defined(LN_OPAQUE_LANE) && LN_OPAQUE_LANE == 3
+            asm volatile("" : "+s"(p.arena), "+v"(chan));
+#elif defined(LN_OPAQUE_LANE) && LN_OPAQUE_LANE == 4
+            asm volatile("" : "+s"(p.arena));
 #else
             asm volatile("" : "+v"(p.lane), "+v"(p.q), "+v"(p.g0), "+v"(p.self4));
 #endif
