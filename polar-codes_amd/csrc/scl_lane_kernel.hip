@@ -62,6 +62,13 @@
 // top-of-tree pass = +1.7 %), and the packed fma is the same fused operation per component: results unchanged bit for bit.
 // (A/B on one box with the packed forms in every g and a + b: cfg 3 36.82 -> 37.27, cfg 4 47.7 -> 48.7, cfg 5 1.378 -> 1.415,
 //  cfg3_i8 27.85 -> 28.07 M cw/s.  -DLN_PKFMA=0 restores the scalar forms.)
+// LN_LINKEY: linear selection keys (select_fork).  On where it was measured to pay (A/B on one box, rate 1/2, AWGN at 2 dB):
+// 32 lanes at N = 2048 / 4096 + 4 ... 5 % (cfg 5: 1.43 -> 1.50 M cw/s).  16 lanes, N <= 1024 and the 8-lane kernels at
+// N = 2048 / 4096: the two reductions in front of the merge network cost a lone wave more than the rarer exact-metric fix-ups /
+// tie emulations save (- 0.5 ... - 5 %).
+#ifndef LN_LINKEY
+#define LN_LINKEY (!LN_CHAR && LN_LCL == 5 && LN_LOGN >= 11)
+#endif
 #ifndef LN_PKFMA
 #define LN_PKFMA 1
 #endif
@@ -481,6 +488,12 @@ __device__ __forceinline__ uint32_t cw_min(uint32_t v)
     v = umin(v, dpp_u32<0x4E>(v));
     return umin(v, dpp_u32<0x141>(v));
 }
+__device__ __forceinline__ uint32_t cw_max(uint32_t v)
+{
+    v = umax(v, dpp_u32<0xB1>(v));
+    v = umax(v, dpp_u32<0x4E>(v));
+    return umax(v, dpp_u32<0x141>(v));
+}
 __device__ __forceinline__ uint32_t cw_add(uint32_t v)
 {
     v += dpp_u32<0xB1>(v);
@@ -499,6 +512,18 @@ __device__ __forceinline__ uint32_t cw_min(uint32_t v)
     if constexpr (LC > 16) {
         const auto s = __builtin_amdgcn_permlane16_swap(v, v, false, false);
         v = umin(s[0], s[1]);
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t cw_max(uint32_t v)
+{
+    v = umax(v, dpp_u32<0xB1>(v));
+    v = umax(v, dpp_u32<0x4E>(v));
+    v = umax(v, dpp_u32<0x141>(v));
+    v = umax(v, dpp_u32<0x140>(v));
+    if constexpr (LC > 16) {
+        const auto s = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        v = umax(s[0], s[1]);
     }
     return v;
 }
@@ -523,6 +548,19 @@ struct Stamps {
     uint32_t ab = 0;  // diagnostics: parts to run twice (PCD_ABLATE bits 16 .. 19)
     __device__ __forceinline__ void mark(int k) const
     {
+#ifdef LN_STAMP_SELECT  // (diagnostics: the four stamps go to the parts of select_fork instead -- alt())
+        return;
+#endif
+        if (sub) {
+            const uint64_t t = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) sub[k] = (uint32_t)(t - t0);
+        }
+    }
+    __device__ __forceinline__ void alt(int k) const
+    {
+#ifndef LN_STAMP_SELECT
+        return;
+#endif
         if (sub) {
             const uint64_t t = __builtin_amdgcn_s_memtime();
             if (threadIdx.x == 0) sub[k] = (uint32_t)(t - t0);
@@ -888,6 +926,7 @@ template <int C>
 __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint32_t& src, uint32_t& cand, const Stamps& sm)
 {
     constexpr uint32_t INF = 0xFFFFFFFFu;
+    sm.alt(0);
     const bool live = p.pl < p.P;
     const uint32_t np = (p.P * (uint32_t)C < p.L) ? p.P * (uint32_t)C : p.L;
     // the candidates' exact metrics go to the scratch: the new host of a path reads the one it was given
@@ -904,8 +943,31 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     }
     const uint32_t qc = live ? ((uint32_t)p.q << 3) : INF;  // (dead lanes: every key becomes INF)
     uint32_t k[8];
+#if LN_LINKEY
+    // linear keys (see the 16 / 32-lane form below): the distance to the best metric of the codeword, 25 bits over the span of the
+    // candidates that can be chosen.  At N >= 2048 a sixth of the forks otherwise holds two chosen candidates whose metrics agree
+    // in the 26 leading bits (a path and its weakest LLR of hundreds flipped) and runs the full tie emulation, 3 - 5 k cycles each.
+    const bool full = p.P == p.L;  // (wave uniform)
+    uint32_t bb = fbits(cm[0]), bw = fbits(cm[C - 1]);
+    if constexpr (C == 2) {
+        bb = umin(fbits(cm[0]), fbits(cm[1]));
+        bw = umax(fbits(cm[0]), fbits(cm[1]));
+    }
+    const uint32_t hiu = cw_min(live ? bb : INF), lou = cw_max(live ? (full ? bb : bw) : 0u);
+    const float hi = bitsf(hiu);
+    const uint32_t er = umax(fbits(hi - bitsf(lou)) >> 23, 24u);
+    const float kscale = bitsf((278u - er) << 23);  // 2^(24 - exponent): span * kscale in [2^24, 2^25)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (c < C) {
+            const float t = fminf((hi - cm[c < C ? c : 0]) * kscale, 67108860.0f);
+            k[c] = ((uint32_t)t << 6) | qc | (uint32_t)c;
+        } else k[c] = INF;
+    }
+#else
 #pragma unroll
     for (int c = 0; c < 8; ++c) k[c] = c < C ? ((fbits(cm[c < C ? c : 0]) & ~63u) | qc | (uint32_t)c) : INF;
+#endif
     if constexpr (C == 2) cex(k[0], k[1]);
     if constexpr (C == 8) cex(k[3], k[4]);
     uint32_t own[C];
@@ -923,6 +985,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     merge_level<C, 0xB1>(k);
     merge_level<(2 * C < 8 ? 2 * C : 8), 0x4E>(k);
     merge_level<(4 * C < 8 ? 4 * C : 8), 0x141>(k);
+    sm.alt(1);
     // exactness: neighbours among the np chosen differ above the payload bits, and nobody outside them is at or below
     // the last one (nme = number of this lane's candidates at or below it).
     uint32_t dmin = INF;
@@ -938,6 +1001,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     const bool cut_tie = cw_add(nme) != np;
     uint32_t mykey = pick8(k, (uint32_t)p.q);
     const bool seated = (uint32_t)p.q < np;
+    sm.alt(2);
     if (ballot64((dmin < 64u) || cut_tie) != 0) {  // (wave uniform; rare on real-valued input)
         // Equal metrics.  The merge order is the stable one (value, then position in the candidate array); the reference's
         // selection sort leaves it only where a swap carries a candidate past its equals: a chosen candidate that has an
@@ -946,8 +1010,17 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
         // clear, as with quantised LLRs): the merge result stands.  Otherwise the literal emulation decides -- over the
         // chosen candidates alone where that is exact (select_chosen), over all of them where not.
         uint32_t low = 0;
+#if LN_LINKEY
+#pragma unroll
+        for (int c = 0; c < C; ++c) {  // (the linear keys are the whole metric when no distance lost a fraction or was clamped)
+            const float t = (hi - cm[c]) * kscale;
+            low |= fbits(__builtin_amdgcn_fractf(t)) | (t >= 67108860.0f ? 1u : 0u);
+        }
+        low = low != 0u ? 1u : 0u;
+#else
 #pragma unroll
         for (int c = 0; c < C; ++c) low |= fbits(cm[c]);
+#endif
         const uint32_t q = (uint32_t)p.q;
         const uint32_t prev = dpp_u32<0x111>(mykey), next = dpp_u32<0x101>(mykey);  // ranks q - 1 and q + 1 (row_shr / row_shl)
         const bool equal = (q > 0u && (mykey ^ prev) < 64u) || (q + 1u < np && (mykey ^ next) < 64u) || (cut_tie && (mykey | 63u) == kc63);
@@ -972,6 +1045,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
             else mykey = select_chosen<C>(p, mykey, at, seated, np, zkey);
         }
     }
+    sm.alt(3);
     sm.mark(2);
     src = seated ? ((uint32_t)p.g0 | ((mykey >> 3) & 7u)) : (uint32_t)p.lane;
     cand = mykey & 7u;
@@ -1040,6 +1114,7 @@ template <int C>
 __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint32_t& src, uint32_t& cand, const Stamps& sm)
 {
     constexpr uint32_t INF = 0xFFFFFFFFu;
+    sm.alt(0);
     const bool live = p.pl < p.P;
     const uint32_t np = (p.P * (uint32_t)C < p.L) ? p.P * (uint32_t)C : p.L;
     // the candidates' exact metrics go to the scratch: the new host of a path reads the one it was given
@@ -1056,8 +1131,37 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     }
     const uint32_t qc = live ? ((uint32_t)p.q << 3) : INF;  // (dead lanes: every key becomes INF)
     uint32_t k[8];
+#if LN_LINKEY
+    // Keys.  The 24 - LCL leading bits of the metric resolve |metric| * 2^-15: at 16 / 32 paths most forks then hold two chosen
+    // candidates with the same key -- a path's own metric and the one with its weakest LLR flipped, whose magnitude in a block
+    // of hundreds of LLRs is tiny -- and take the exact-metric fix-up below (88 % of the forks of cfg 5, a tenth of them the tie
+    // emulations).  Any monotone map of the metric is a valid key, so the keys are linear instead: the distance to the best metric
+    // of the codeword, scaled so that the span of the candidates that can be chosen fills 23 bits (span * 2^-23: two to three
+    // decimal orders finer).  That span: with a full list (P = L) the paths' best candidates -- they are L candidates, so the
+    // L-th best of all is among or above them --, before that all candidates.  Metrics are <= 0 and never -0 (sums that start at
+    // +0), larger is better, so float bits ascend with the distance as the distance itself does; fl(hi - x) is monotone and
+    // injective in x.  No branch on the list state: a taken branch costs a lone wave its instruction buffer.
+    const bool full = p.P == p.L;  // (wave uniform)
+    uint32_t bb = fbits(cm[0]), bw = fbits(cm[C - 1]);  // best / worst candidate of the lane (C = 2: the repetition pair is not ordered)
+    if constexpr (C == 2) {
+        bb = umin(fbits(cm[0]), fbits(cm[1]));
+        bw = umax(fbits(cm[0]), fbits(cm[1]));
+    }
+    const uint32_t hiu = cw_min(live ? bb : INF), lou = cw_max(live ? (full ? bb : bw) : 0u);
+    const float hi = bitsf(hiu);
+    const uint32_t er = umax(fbits(hi - bitsf(lou)) >> 23, 22u);  // biased exponent of the span (clamped: a span of 0 still gives a finite scale)
+    const float kscale = bitsf((276u - er) << 23);                 // 2^(22 - exponent): span * kscale in [2^22, 2^23)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (c < C) {
+            const float t = fminf((hi - cm[c < C ? c : 0]) * kscale, 16777214.0f);  // (candidates far outside the span share the last key; INF stays above it)
+            k[c] = ((uint32_t)t << PB) | qc | (uint32_t)c;
+        } else k[c] = INF;
+    }
+#else
 #pragma unroll
     for (int c = 0; c < 8; ++c) k[c] = c < C ? ((fbits(cm[c < C ? c : 0]) & ~PBM) | qc | (uint32_t)c) : INF;
+#endif
     if constexpr (C == 2) cex(k[0], k[1]);
     if constexpr (C == 8) cex(k[3], k[4]);
     uint32_t own[C];
@@ -1087,6 +1191,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
         cross_rev_min<0>(k);
         group_clean(k, p.lane);
     }
+    sm.alt(1);
     // the sorted list of the codeword: ranks [codeword][LC] in the scratch, written by the first group
     const uint32_t cwbase = SCR_SEL + (uint32_t)(p.lane >> LCL) * (uint32_t)LC;
     if ((uint32_t)p.q < (uint32_t)(LC / 8)) {
@@ -1107,6 +1212,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     for (int c = 0; c < C; ++c) nme += (own[c] <= kcm) ? 1u : 0u;
     const bool cut_tie = cw_add(nme) != np;
     const bool seated = q < np;
+    sm.alt(2);
     bool resolved = false;
     if (ballot64(near) != 0 && ballot64(cut_tie) == 0) {
         // Keys that agree above the payload bits while the cut is clean.  With 16 / 32 paths this happens in a good part of the
@@ -1141,8 +1247,18 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     if (!resolved && ballot64(near || cut_tie) != 0) {  // (wave uniform)
         // Equal metrics: see the 8-lane form above.
         uint32_t low = 0;
+#if LN_LINKEY
+        // (the linear keys are the whole metric when no distance lost a fraction or was clamped)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float t = (hi - cm[c]) * kscale;
+            low |= fbits(__builtin_amdgcn_fractf(t)) | (t >= 16777214.0f ? 1u : 0u);
+        }
+        low = low != 0u ? 1u : 0u;
+#else
 #pragma unroll
         for (int c = 0; c < C; ++c) low |= fbits(cm[c]);
+#endif
         const bool equal = (q > 0u && (mykey ^ prev) <= PBM) || (q + 1u < np && (mykey ^ next) <= PBM) || (cut_tie && (mykey | PBM) == kcm);
         const uint32_t at = array_pos<C>(mykey);
         const bool moved = seated && equal && at < q;
@@ -1163,6 +1279,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
             else mykey = select_chosen<C>(p, mykey, at, seated, np, zkey);
         }
     }
+    sm.alt(3);
     sm.mark(2);
     src = seated ? ((uint32_t)p.g0 | ((mykey >> 3) & (uint32_t)(LC - 1))) : (uint32_t)p.lane;
     cand = mykey & 7u;
@@ -2583,6 +2700,9 @@ __device__ __forceinline__ void op_fg_reg(Path& p, uint32_t absmask, uint32_t si
 // =====================================================================================================================
 // CH: the int8 list decoder SclFipChar.  LN_I8ROWS: the channel rows are int8 and are widened in the top-of-tree pass (always
 // for CH; the float decoder called with int8 rows -- decode_vector(const char*) -- has its own translation units)
+#if !defined(LN_OPAQUE_LANE) && !LN_GEO_DEFAULT && LN_LOGN == 10
+#define LN_OPAQUE_LANE 3  // (N = 1024 with 16 / 32 lanes: the arena and row pointers are enough -- no scratch, + 2.4 %, A/B on one box)
+#endif
 template <bool DIAG, bool CH = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(lane::KV)))
 void scl_lane_kernel(const DecodeParams P)

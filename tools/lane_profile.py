@@ -58,3 +58,10 @@ for line in open('/tmp/lane_sub.txt'):
 print("segments (cycles summed over the pass; PCD_ABLATE=256): walk + leaf scan | weak search + candidates | merge + ties | seats + state | bits")
 for k, v in sub.items():
     print(f"{k:5s} n={v[5]:3d} ", " ".join(f"{x:8d}" for x in v[:5]))
+if os.environ.get('LANE_PROFILE_HIST'):  # distribution of the fourth segment (LN_STAMP_SELECT builds: near-tie fix-up + tie tiers of select_fork) over the forks
+    seg3 = sorted(int(l.split()[6]) - int(l.split()[5]) for l in open('/tmp/lane_sub.txt') if int(l.split()[6]) != 0)
+    n = len(seg3)
+    print("forks", n, "fourth segment: min", seg3[0], "median", seg3[n // 2], "p75", seg3[3 * n // 4], "p90", seg3[9 * n // 10], "max", seg3[-1])
+    print("  below 300 cycles:", sum(1 for v in seg3 if v < 300), " 300-2000:", sum(1 for v in seg3 if 300 <= v < 2000), " 2000-6000:", sum(1 for v in seg3 if 2000 <= v < 6000), " above:", sum(1 for v in seg3 if v >= 6000))
+    print("  ", seg3)
+
