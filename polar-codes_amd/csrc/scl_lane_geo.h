@@ -1,16 +1,19 @@
 // The lane-per-path list kernel under its other geometries (scl_lane_kernel.hip compiled once per translation unit
-// scl_lane_n<logN>_l<lcl>[_char].hip): block length N = 2^logN, LC = 2^lcl lanes -- list positions -- per codeword, 64 / LC
-// codewords per wave.  The default geometry (N = 1024, 8 lanes: launch_scl_lane and its three siblings in kernels.h) is not
-// part of this list.  X(logN, lcl): the float decoder's kernels; Y(logN, lcl): the int8 decoder's.
+// scl_lane_n<logN>_l<lcl>[_char].hip): block length N = 2^logN, LC = 2^lcl lanes -- list positions -- per codeword (2 .. 32: list
+// sizes 2, 3 .. 4, 5 .. 8, 9 .. 16, 17 .. 32), 64 / LC codewords per wave.  The default geometry (N = 1024, 8 lanes: launch_scl_lane and its three siblings in kernels.h) is not
+// part of this list; N = 4096 with two lanes (32 codewords of 16 KB per wave, 7.9 against 12.9 M cw/s on the path groups) is not built.
+// X(logN, lcl): the float decoder's kernels; Y(logN, lcl): the int8 decoder's.
 #pragma once
 #include "kernels.h"
 
-#define PAMD_LANE_GEOS(X) X(12, 5) X(10, 4) X(10, 5) X(11, 3) X(9, 3) X(9, 4) X(9, 5) X(11, 4) X(11, 5) X(12, 3) X(12, 4)
-#define PAMD_LANE_GEOS_CHAR(Y) Y(9, 3) Y(9, 4) Y(9, 5) Y(10, 4) Y(10, 5) Y(11, 3) Y(11, 4) Y(11, 5) Y(12, 3) Y(12, 4) Y(12, 5)
+#define PAMD_LANE_GEOS(X) X(12, 5) X(10, 4) X(10, 5) X(11, 3) X(9, 3) X(9, 4) X(9, 5) X(11, 4) X(11, 5) X(12, 3) X(12, 4) \
+    X(9, 1) X(9, 2) X(10, 1) X(10, 2) X(11, 1) X(11, 2) X(12, 2)
+#define PAMD_LANE_GEOS_CHAR(Y) Y(9, 3) Y(9, 4) Y(9, 5) Y(10, 4) Y(10, 5) Y(11, 3) Y(11, 4) Y(11, 5) Y(12, 3) Y(12, 4) Y(12, 5) \
+    Y(9, 1) Y(9, 2) Y(10, 1) Y(10, 2) Y(11, 1) Y(11, 2) Y(12, 2)
 // N >= 2048 with an all-frozen leaf of 512 / 1024 LLRs in the tree (low rates): the same kernels with that leaf, as translation
 // units of their own (scl_lane_n<logN>_l<lcl>_hi.hip) -- the code it adds moved cfg 5 by 2.5 % when it sat in the one kernel
-#define PAMD_LANE_GEOS_HI(Z) Z(11, 3) Z(11, 4) Z(11, 5) Z(12, 3) Z(12, 4) Z(12, 5)
-#define PAMD_LANE_GEOS_CHAR_HI(W) W(11, 3) W(11, 4) W(11, 5) W(12, 3) W(12, 4) W(12, 5)
+#define PAMD_LANE_GEOS_HI(Z) Z(11, 3) Z(11, 4) Z(11, 5) Z(12, 3) Z(12, 4) Z(12, 5) Z(11, 1) Z(11, 2) Z(12, 2)
+#define PAMD_LANE_GEOS_CHAR_HI(W) W(11, 3) W(11, 4) W(11, 5) W(12, 3) W(12, 4) W(12, 5) W(11, 1) W(11, 2) W(12, 2)
 
 namespace pamd {
 

@@ -480,25 +480,29 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
-// all-reduce over the 8 lanes of a codeword (DPP: lane ^ 1, lane ^ 2, then the mirrored lane of the other quad)
-#if LN_LCL == 3
+// all-reduce over the 8 lanes of a codeword (DPP: lane ^ 1, lane ^ 2, then the mirrored lane of the other quad); 4 / 2 lanes: the
+// first two / the first step
+#if LN_LCL <= 3
 __device__ __forceinline__ uint32_t cw_min(uint32_t v)
 {
     v = umin(v, dpp_u32<0xB1>(v));
-    v = umin(v, dpp_u32<0x4E>(v));
-    return umin(v, dpp_u32<0x141>(v));
+    if constexpr (LC >= 4) v = umin(v, dpp_u32<0x4E>(v));
+    if constexpr (LC >= 8) v = umin(v, dpp_u32<0x141>(v));
+    return v;
 }
 __device__ __forceinline__ uint32_t cw_max(uint32_t v)
 {
     v = umax(v, dpp_u32<0xB1>(v));
-    v = umax(v, dpp_u32<0x4E>(v));
-    return umax(v, dpp_u32<0x141>(v));
+    if constexpr (LC >= 4) v = umax(v, dpp_u32<0x4E>(v));
+    if constexpr (LC >= 8) v = umax(v, dpp_u32<0x141>(v));
+    return v;
 }
 __device__ __forceinline__ uint32_t cw_add(uint32_t v)
 {
     v += dpp_u32<0xB1>(v);
-    v += dpp_u32<0x4E>(v);
-    return v + dpp_u32<0x141>(v);
+    if constexpr (LC >= 4) v += dpp_u32<0x4E>(v);
+    if constexpr (LC >= 8) v += dpp_u32<0x141>(v);
+    return v;
 }
 #else
 // (16 lanes: + the mirrored lane of the row; 32 lanes: + the other row of the pair -- v_permlane16_swap with both operands the
@@ -594,6 +598,9 @@ struct Path {
 #else
 // Other geometries: fields of LCL bits; the stages 2 .. 7 in `slot`, the stages 8 .. LOGN in `slot2` (up to 5 x 5 bits each way)
 struct Path {
+#ifdef LN_STAMP_VT
+    uint32_t* vt_sub = nullptr;  // (diagnostics: where the steps of the top-of-tree pass spend their cycles)
+#endif
     float metric;
     uint32_t slot, slot2;
     uint32_t pl;     // position in the reference's path list; >= P: not a live path
@@ -914,7 +921,8 @@ __device__ __forceinline__ uint32_t pick8(const uint32_t (&k)[8], uint32_t q)
     return b2 ? c1 : c0;
 }
 
-#if LN_LCL == 3
+#if LN_LCL <= 3
+// (2 / 4 lanes per codeword -- list sizes 2 and 3 .. 4 --: the same with one / two merge levels)
 // Chooses the np = min(L, P * C) best candidates of every codeword and re-seats the paths BY RANK: lane q of the codeword
 // hosts the path at position q of the reference's list afterwards (p.pl == q for the np live lanes; what a path owns is
 // found through its slot word, so a path changes lanes at the price of one ds_bpermute), taken from lane `src`
@@ -975,16 +983,16 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     for (int c = 0; c < C; ++c) own[c] = k[c];
     if (sm.ab & 131072u) {  // (diagnostics: the merge network twice)
         merge_level<C, 0xB1>(k);
-        merge_level<(2 * C < 8 ? 2 * C : 8), 0x4E>(k);
-        merge_level<(4 * C < 8 ? 4 * C : 8), 0x141>(k);
+        if constexpr (LC >= 4) merge_level<(2 * C < 8 ? 2 * C : 8), 0x4E>(k);
+        if constexpr (LC >= 8) merge_level<(4 * C < 8 ? 4 * C : 8), 0x141>(k);
         asm volatile("" : "+v"(k[0]), "+v"(k[7]));
 #pragma unroll
         for (int c = 0; c < 8; ++c) k[c] = c < C ? own[c] : INF;
         asm volatile("" : "+v"(k[0]), "+v"(k[1]));
     }
     merge_level<C, 0xB1>(k);
-    merge_level<(2 * C < 8 ? 2 * C : 8), 0x4E>(k);
-    merge_level<(4 * C < 8 ? 4 * C : 8), 0x141>(k);
+    if constexpr (LC >= 4) merge_level<(2 * C < 8 ? 2 * C : 8), 0x4E>(k);
+    if constexpr (LC >= 8) merge_level<(4 * C < 8 ? 4 * C : 8), 0x141>(k);
     sm.alt(1);
     // exactness: neighbours among the np chosen differ above the payload bits, and nobody outside them is at or below
     // the last one (nme = number of this lane's candidates at or below it).
@@ -2038,6 +2046,35 @@ __device__ __forceinline__ void op_vt_first(Path& p, const RowT* chan, uint32_t 
     p.set_field(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#elif LN_LCL < 3
+// (4 / 2 lanes per codeword: lane q does the steps j = q + LC i, 8 / 16 of them, four sets at a time)
+template <bool CH>
+__device__ __forceinline__ void op_vt_first(Path& p, const RowT* chan, uint32_t absmask, uint32_t signmask)
+{
+    const uint32_t* s8base = p.arena + AR_S8;
+    uint32_t s8off = (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
+    uint32_t s7addr = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
+    const RowT* rowp = chan + 4 * p.q;
+#pragma unroll 1
+    for (uint32_t b = 0; b < 8u / (uint32_t)LC; ++b) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vt_load<VT_SET0>(rowp);
+        vt_load<VT_SET1>(rowp + 4 * LC);
+        vt_load<VT_SET2>(rowp + 8 * LC);
+        vt_load<VT_SET3>(rowp + 12 * LC);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vt_step<VT_SET0, false, false, true, CH>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off, s8base, s7addr, p.c127, p.m128);
+        vt_step<VT_SET1, false, false, true, CH>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 1024u * LC, s8base, s7addr + 1024u * LC, p.c127, p.m128);
+        vt_step<VT_SET2, false, false, true, CH>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 2048u * LC, s8base, s7addr + 2048u * LC, p.c127, p.m128);
+        vt_step<VT_SET3, false, false, true, CH>(0, 0, 0, 0, 0, 0, absmask, signmask, s8off + 3072u * LC, s8base, s7addr + 3072u * LC, p.c127, p.m128);
+        rowp += 16 * LC;
+        s8off += 4096u * (uint32_t)LC;
+        s7addr += 4096u * (uint32_t)LC;
+    }
+    p.set_field(8);
+    p.set_field(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 #else
 // (16 / 32 lanes per codeword: lane q does the steps j = q, q + LC, ... < 32)
 template <bool CH>
@@ -2318,6 +2355,9 @@ __device__ __forceinline__ void vtg_core(Path& p, uint32_t gm, const RT* chan, u
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing older in flight: the counted waits below see only this op's accesses)
     vtg_words_issue<LV, TOUT>(gm, bo, 0, abase);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LN_STAMP_VT
+    uint32_t vt_acc[4] = { 0u, 0u, 0u, 0u };
+#endif
     const RT* const rowlast = chan + 4 * (8 * NG - 1);
     static_for<NS - 1>([&](auto J) { vtg_load<128 + SW * decltype(J)::value, LV, TOUT>(chan + 4 * decltype(J)::value); });
     const RT* rowp = chan + 4 * (NS - 1);  // the row at the chunk of the next step to be loaded
@@ -2331,17 +2371,40 @@ __device__ __forceinline__ void vtg_core(Path& p, uint32_t gm, const RT* chan, u
             static_for<NS>([&](auto J) {
                 constexpr int j = decltype(J)::value;
                 const uint32_t c = 8u * g + i + (uint32_t)j;
+#ifdef LN_STAMP_VT
+                const uint64_t ta = __builtin_amdgcn_s_memtime();
+#endif
                 sink.pre(c);
                 vtg_load<128 + SW * ((j + NS - 1) % NS), LV, TOUT>(rowp < rowlast ? rowp : rowlast);
                 rowp += 4;
+#ifdef LN_STAMP_VT
+                const uint64_t tb = __builtin_amdgcn_s_memtime();
+#endif
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * G::NR) : "memory");
+#ifdef LN_STAMP_VT
+                const uint64_t tc = __builtin_amdgcn_s_memtime();
+#endif
                 vtg_widen<128 + SW * j, LV, RT>();
                 vtg_levels<128 + SW * j, LV, CH>(gm, 31u - 4u * ((i + (uint32_t)j) & 7u), absmask, signmask, p.c127, p.m128);
+#ifdef LN_STAMP_VT
+                const uint64_t td = __builtin_amdgcn_s_memtime();
+#endif
                 sink.template take<128 + SW * j, (j & 1)>(c);
+#ifdef LN_STAMP_VT
+                const uint64_t te = __builtin_amdgcn_s_memtime();
+                vt_acc[0] += (uint32_t)(tb - ta);
+                vt_acc[1] += (uint32_t)(tc - tb);
+                vt_acc[2] += (uint32_t)(td - tc);
+                vt_acc[3] += (uint32_t)(te - td);
+#endif
             });
         }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef LN_STAMP_VT
+    if (p.vt_sub && threadIdx.x == 0)
+        for (int i = 0; i < 4; ++i) p.vt_sub[i] = vt_acc[i];
+#endif
 }
 template <int TOP, bool CH, typename RT>
 __device__ __forceinline__ void op_vtg_t(Path& p, uint32_t gm, const RT* chan, uint32_t absmask, uint32_t signmask)
@@ -2770,6 +2833,9 @@ void scl_lane_kernel(const DecodeParams P)
             if (DIAG && P.cycles && grp == 0) t_start = __builtin_amdgcn_s_memtime();
             Stamps sm{ nullptr, t_start, DIAG ? P.ablate : 0u };
             if (DIAG && P.cycles && grp == 0 && (P.ablate & 256u)) sm.sub = P.cycles + P.prog_len + 4 * pc;  // (PCD_ABLATE=256: phase stamps)
+#ifdef LN_STAMP_VT
+            p.vt_sub = sm.sub;
+#endif
             bool is_leaf = false;
             uint32_t fkind = 0;  // forking leaf: 1 RateOne, 2 SPC
             uint32_t lk = 0, lst = st, lside = side;  // leaf to run behind the switch: kind, stage, side

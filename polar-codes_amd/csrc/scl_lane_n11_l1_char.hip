@@ -1,0 +1,9 @@
+// lane-per-path list kernel of the int8 decoder (SclFipChar), N = 2048, up to 2 paths: scl_lane_kernel.hip under another geometry
+#define LN_LOGN 11
+#define LN_LCL 1
+#define LN_BIG 1
+#define LN_CHAR 1
+#define LN_KERNEL_NAME scl_lane_n11_l1_char_kernel
+#define LN_LAUNCH_NAME launch_scl_lane_n11_l1_char
+#define LN_ARENA_NAME scl_lane_n11_l1_char_arena_words
+#include "scl_lane_kernel.hip"

@@ -339,7 +339,11 @@ LANE_GEO_CODES = [(512, 256, 8, "BB"), (512, 128, 6, "BB"), (512, 256, 16, "BB")
                   (2048, 72, 17, "BB"), (2048, 72, 8, "BB"),      # (an all-frozen leaf of 1024 LLRs at N = 2048: found by the round-4 fuzz)
                   # high rates: RateOne / SPC leaves of 512 / 1024 LLRs (scan sink of the pass, sign words rewritten in place)
                   (2048, 1664, 8, "BB"), (2048, 1920, 16, "BB"), (2048, 1800, 32, "BE"), (4096, 2304, 8, "BB"), (4096, 2816, 16, "BB"),
-                  (4096, 3328, 32, "BB"), (4096, 3840, 8, "BE"), (4096, 3000, 17, "BB")]
+                  (4096, 3328, 32, "BB"), (4096, 3840, 8, "BE"), (4096, 3000, 17, "BB"),
+                  # 2 / 4 lanes per codeword (list sizes 2, 3 .. 4: 32 / 16 codewords per wave)
+                  (512, 256, 2, "BB"), (512, 300, 4, "BE"), (1024, 512, 2, "BB"), (1024, 512, 4, "BB"), (1024, 700, 3, "BE"), (1024, 512, 4, "rand"),
+                  (2048, 1024, 2, "BB"), (2048, 1024, 4, "BB"), (2048, 300, 3, "BB"), (2048, 1800, 2, "BE"), (4096, 2048, 4, "BB"), (4096, 3000, 3, "BB"),
+                  (4096, 700, 4, "BE")]
 
 
 @pytest.mark.parametrize("N,K,L,kind", LANE_GEO_CODES, ids=[f"N{n}_K{k}_L{l}_{c}" for n, k, l, c in LANE_GEO_CODES])
@@ -355,7 +359,7 @@ def test_lane_kernel_geometries(built_library, N, K, L, kind):
         frozen = np.sort(rng.choice(N, N - K, replace=False)).astype(np.uint32)
     else:
         frozen = np.asarray(pypolar_amd.frozen_bits(N, K, 0.0, kind), dtype=np.uint32)
-    rows = 21 if N <= 1024 else (13 if N == 2048 else 7)     # (not a multiple of the codewords per wave)
+    rows = (21 if N <= 1024 else (13 if N == 2048 else 7)) + (32 if L <= 4 else 0)     # (not a multiple of the codewords per wave, more than one wave's worth)
     awgn = (1.0 + 0.8 * rng.standard_normal((rows, N))).astype(np.float32) * np.where(rng.random((rows, N)) < 0.5, 1, -1).astype(np.float32)
     noise = rng.standard_normal((rows // 3, N)).astype(np.float32)
     ties = rng.integers(-3, 4, (rows // 2, N)).astype(np.float32)
@@ -375,7 +379,8 @@ def test_lane_kernel_geometries(built_library, N, K, L, kind):
 
 
 LANE_GEO_CHAR_CODES = [(512, 200, 32), (1024, 512, 16), (1024, 512, 32), (2048, 1024, 8), (2048, 1024, 16), (2048, 700, 32), (2048, 256, 8), (4096, 1024, 8),
-                       (2048, 1800, 8), (4096, 3000, 8), (4096, 2560, 32), (2048, 256, 16)]   # (leaves of 512 / 1024 LLRs, the repetition leaf included)
+                       (2048, 1800, 8), (4096, 3000, 8), (4096, 2560, 32), (2048, 256, 16),   # (leaves of 512 / 1024 LLRs, the repetition leaf included)
+                       (512, 256, 2), (1024, 512, 4), (1024, 512, 2), (2048, 1024, 3), (2048, 256, 2), (4096, 2048, 4), (4096, 3000, 4)]   # (2 / 4 lanes per codeword)
 
 
 @pytest.mark.parametrize("N,K,L", LANE_GEO_CHAR_CODES, ids=[f"N{n}_K{k}_L{l}" for n, k, l in LANE_GEO_CHAR_CODES])

@@ -64,4 +64,14 @@ if os.environ.get('LANE_PROFILE_HIST'):  # distribution of the fourth segment (L
     print("forks", n, "fourth segment: min", seg3[0], "median", seg3[n // 2], "p75", seg3[3 * n // 4], "p90", seg3[9 * n // 10], "max", seg3[-1])
     print("  below 300 cycles:", sum(1 for v in seg3 if v < 300), " 300-2000:", sum(1 for v in seg3 if 300 <= v < 2000), " 2000-6000:", sum(1 for v in seg3 if 2000 <= v < 6000), " above:", sum(1 for v in seg3 if v >= 6000))
     print("  ", seg3)
+if os.environ.get('LANE_PROFILE_VT'):  # LN_STAMP_VT builds: the four stamps of a top-of-tree pass are sums over its steps: issue of the loads | wait for the rows | levels | sink
+    acc = [0, 0, 0, 0, 0, 0]
+    for l in open('/tmp/lane_sub.txt'):
+        o, s_, c, a, b, c2, d2 = (int(x) for x in l.split())
+        if names.get(o) == 'VT':
+            for i, v in enumerate((a, b, c2, d2)):
+                acc[i] += v
+            acc[4] += c
+            acc[5] += 1
+    print("VT passes", acc[5], "cycles", acc[4], ": load issue", acc[0], "| wait for the rows", acc[1], "| levels", acc[2], "| sink", acc[3], "| outside the steps", acc[4] - sum(acc[:4]))
 

@@ -25,6 +25,8 @@ for N in NS:
             continue                                  # log2 N * log2 L > 64: PCD_ERR_CAPACITY
         work = N * (1 if L == 1 else 8 * L)          # keep each launch in the 5-100 ms range, >= 4 passes of the grid
         B = int(min(1 << 20, max(1 << 14, (1 << 36) // (work * 64))))
+        if os.environ.get("SWEEP_LOG2B"):            # a fixed batch instead (the lane kernels with 16 / 32 codewords per wave want >= 2^17 rows to fill the chip)
+            B = 1 << int(os.environ["SWEEP_LOG2B"])
         llr, info = bench.make_batch(cfg, frozen, B, dev, seed=5)
         d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
         d.setErrorDetection(cfg["crc"], "crc")

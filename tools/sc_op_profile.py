@@ -26,11 +26,11 @@ for o, s, c in zip(ops, st, cyc):
     agg[(int(o), int(s))][0] += 1
     agg[(int(o), int(s))][1] += int(c)
 for (o, s), (n, c) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"{names.get(o, o):10s} stage {s:2d}  n={n:3d} cycles={c:7d} ({100 * c / tot:5.1f}%) avg={c / n:7.0f}")
+    print(f"{str(names.get(o, o)):10s} stage {s:2d}  n={n:3d} cycles={c:7d} ({100 * c / tot:5.1f}%) avg={c / n:7.0f}")
 byop = defaultdict(lambda: [0, 0])
 for (o, s), (n, c) in agg.items():
     byop[o][0] += n
     byop[o][1] += c
 print()
 for o, (n, c) in sorted(byop.items(), key=lambda kv: -kv[1][1]):
-    print(f"{names.get(o, o):10s} n={n:3d} cycles={c:7d} ({100 * c / tot:5.1f}%) avg={c / n:7.0f}")
+    print(f"{str(names.get(o, o)):10s} n={n:3d} cycles={c:7d} ({100 * c / tot:5.1f}%) avg={c / n:7.0f}")
