@@ -65,7 +65,8 @@
 // LN_LINKEY: linear selection keys (select_fork).  On where it was measured to pay (A/B on one box, rate 1/2, AWGN at 2 dB):
 // 32 lanes at N = 2048 / 4096 + 4 ... 5 % (cfg 5: 1.43 -> 1.50 M cw/s).  16 lanes, N <= 1024 and the 8-lane kernels at
 // N = 2048 / 4096: the two reductions in front of the merge network cost a lone wave more than the rarer exact-metric fix-ups /
-// tie emulations save (- 0.5 ... - 5 %).
+// tie emulations save (- 0.5 ... - 5 %).  (A variant that carried the scale from fork to fork instead of reducing it in front of
+// every network was exact and changed none of these numbers: the reductions are not what the map costs at N = 1024.)
 #ifndef LN_LINKEY
 #define LN_LINKEY (!LN_CHAR && LN_LCL == 5 && LN_LOGN >= 11)
 #endif
@@ -951,7 +952,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     }
     const uint32_t qc = live ? ((uint32_t)p.q << 3) : INF;  // (dead lanes: every key becomes INF)
     uint32_t k[8];
-#if LN_LINKEY
+#if LN_LINKEY == 1
     // linear keys (see the 16 / 32-lane form below): the distance to the best metric of the codeword, 25 bits over the span of the
     // candidates that can be chosen.  At N >= 2048 a sixth of the forks otherwise holds two chosen candidates whose metrics agree
     // in the 26 leading bits (a path and its weakest LLR of hundreds flipped) and runs the full tie emulation, 3 - 5 k cycles each.
@@ -1018,7 +1019,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
         // clear, as with quantised LLRs): the merge result stands.  Otherwise the literal emulation decides -- over the
         // chosen candidates alone where that is exact (select_chosen), over all of them where not.
         uint32_t low = 0;
-#if LN_LINKEY
+#if LN_LINKEY == 1
 #pragma unroll
         for (int c = 0; c < C; ++c) {  // (the linear keys are the whole metric when no distance lost a fraction or was clamped)
             const float t = (hi - cm[c]) * kscale;
@@ -1139,7 +1140,7 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
     }
     const uint32_t qc = live ? ((uint32_t)p.q << 3) : INF;  // (dead lanes: every key becomes INF)
     uint32_t k[8];
-#if LN_LINKEY
+#if LN_LINKEY == 1
     // Keys.  The 24 - LCL leading bits of the metric resolve |metric| * 2^-15: at 16 / 32 paths most forks then hold two chosen
     // candidates with the same key -- a path's own metric and the one with its weakest LLR flipped, whose magnitude in a block
     // of hundreds of LLRs is tiny -- and take the exact-metric fix-up below (88 % of the forks of cfg 5, a tenth of them the tie
@@ -2763,8 +2764,10 @@ __device__ __forceinline__ void op_fg_reg(Path& p, uint32_t absmask, uint32_t si
 // =====================================================================================================================
 // CH: the int8 list decoder SclFipChar.  LN_I8ROWS: the channel rows are int8 and are widened in the top-of-tree pass (always
 // for CH; the float decoder called with int8 rows -- decode_vector(const char*) -- has its own translation units)
-#if !defined(LN_OPAQUE_LANE) && !LN_GEO_DEFAULT && LN_LOGN == 10
-#define LN_OPAQUE_LANE 3  // (N = 1024 with 16 / 32 lanes: the arena and row pointers are enough -- no scratch, + 2.4 %, A/B on one box)
+#if !defined(LN_OPAQUE_LANE) && !LN_GEO_DEFAULT && (LN_LOGN == 10 || (LN_LOGN >= 11 && LN_LCL == 5 && !LN_HILEAF && !LN_CHAR))
+// (N = 1024 outside the default geometry: the arena and row pointers are enough -- no scratch, + 2.4 %, A/B on one box; 32 lanes
+//  at N = 2048 / 4096 without the leaves above stage 8: + 0.3 %, no scratch either)
+#define LN_OPAQUE_LANE 3
 #endif
 template <bool DIAG, bool CH = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(lane::KV)))

@@ -380,7 +380,7 @@ def test_lane_kernel_geometries(built_library, N, K, L, kind):
 
 LANE_GEO_CHAR_CODES = [(512, 200, 32), (1024, 512, 16), (1024, 512, 32), (2048, 1024, 8), (2048, 1024, 16), (2048, 700, 32), (2048, 256, 8), (4096, 1024, 8),
                        (2048, 1800, 8), (4096, 3000, 8), (4096, 2560, 32), (2048, 256, 16),   # (leaves of 512 / 1024 LLRs, the repetition leaf included)
-                       (512, 256, 2), (1024, 512, 4), (1024, 512, 2), (2048, 1024, 3), (2048, 256, 2), (4096, 2048, 4), (4096, 3000, 4)]   # (2 / 4 lanes per codeword)
+                       (512, 200, 2), (1024, 512, 4), (1024, 512, 2), (2048, 1024, 3), (2048, 256, 2), (4096, 2048, 4), (4096, 3000, 4)]   # (2 / 4 lanes per codeword)
 
 
 @pytest.mark.parametrize("N,K,L", LANE_GEO_CHAR_CODES, ids=[f"N{n}_K{k}_L{l}" for n, k, l in LANE_GEO_CHAR_CODES])

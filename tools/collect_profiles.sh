@@ -8,7 +8,7 @@ TAG=${1:-r03}; shift; CFGS=${@:-cfg3 cfg2 cfg4 cfg5 cfg3_i8 cfg2_i8}
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/profiles_$TAG; mkdir -p $O
 for CFG in $CFGS; do
   LB=18
-  case $CFG in cfg5) LB=13;; cfg4) LB=17;; esac
+  case $CFG in cfg5) LB=13;; cfg4) LB=17;; n1024_l16|n1024_l32|n2048_l8) LB=16;; esac
   # the kernel the decoder of this config launches, as the library reports it (pcd_kernel_name)
   KER=$(python3 $R/bench.py --config $CFG --kernel-name)
   python3 $R/bench.py --config $CFG --cpu-seconds 5 > $O/${TAG}_${CFG}_bench.json 2> $O/${CFG}_bench.err
