@@ -763,14 +763,15 @@ int run_sc_pair(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     if (const char* e = PAMD_ENV("PCD_PAIR_BLOCKS_PER_CU")) per_cu = (unsigned)std::max(1, std::min(4, std::atoi(e)));  // experiments
     unsigned grid = std::max(1u, std::min(need, (unsigned)d->num_cu * per_cu));
     if (const char* e = PAMD_ENV("PCD_PAIR_GRID")) grid = (unsigned)std::max(1, std::atoi(e));  // experiments
-    HIP_TRY(pamd::launch_sc_pair(P, i8, d->pair_big, grid, st));
+    if (d->logN == 9) HIP_TRY(pamd::launch_sc_pair_n9(P, i8, d->pair_big, grid, st));
+    else HIP_TRY(pamd::launch_sc_pair(P, i8, d->pair_big, grid, st));
     return PCD_OK;
 }
 
 int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
     // (fp32 or int8 rows for the float decoder; the int8 decoder sees int8 rows only: float rows were converted by the caller)
-    if (d->has_pair && (i8 || d->dectype != 0)) return run_sc_pair(d, P, i8, st);
+    if (d->has_pair && (i8 || d->dectype != 0) && !(d->logN == 9 && i8)) return run_sc_pair(d, P, i8, st);  // (N = 512: fp32 rows only)
     P.prog = d->d_sc_prog;
     P.prog_len = (uint32_t)d->sc_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->sc_wave_words;
@@ -1487,7 +1488,7 @@ int pcd_kernel_name(const pcd_decoder* d, int list, char* buf, size_t cap)
             name = "scl_decode_kernel";
     } else {
         if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
-        name = d->has_pair ? "sc_pair_kernel" : "sc_decode_kernel";
+        name = d->has_pair ? (d->logN == 9 ? "sc_pair_n9_kernel" : "sc_pair_kernel") : "sc_decode_kernel";
     }
     std::snprintf(buf, cap, "%s", name);
     return PCD_OK;

@@ -25,6 +25,15 @@
 // order -- the 8 strided accumulators of fold8 are 4 per lane (acc[s] of lane p is AVX lane (s & 1) + 4 (s >> 1) + 2 p),
 // every cross-lane sum the reference takes is a sum of one value per lane (commutative) or is rebuilt in full in both lanes.
 #define PAMD_POLAR_F_MINF 1
+// PR_LOGN (sc_pair_n9.hip): the same source for N = 512 -- the channel row IS local stage 8: it is fetched into the AGPRs once per
+// codeword (whole lines, transposed through the LDS like the pass of N = 1024) and the tree below is the same; float decoder, fp32 rows.
+#ifndef PR_LOGN
+#define PR_LOGN 10
+#endif
+#ifndef PR_KERNEL_NAME
+#define PR_KERNEL_NAME sc_pair_kernel
+#define PR_LAUNCH_NAME launch_sc_pair
+#endif
 #include "device_common.h"
 #include "pair_runs.inc"
 
@@ -34,6 +43,8 @@ namespace pamd {
 namespace pair {
 
 // ---- register map (per lane) ---------------------------------------------------------------------------------------
+constexpr int PLOGN = PR_LOGN;             // log2 of the block length: 10, or 9 (the channel row is local stage 8)
+constexpr int NWL = (1 << PLOGN) / 64;     // words of the code word per lane
 constexpr int KV = 104;      // the compiler's VGPR budget: v0 .. v103
 constexpr int RBL0 = 104;    // left-child / root output bits of local stage T <= 5: v[104 + T]
 constexpr int RBR0 = 110;    // right-child output bits of stage T <= 5: v[110 + T]
@@ -542,6 +553,60 @@ __device__ __forceinline__ void op_top(const TopAddr& A, const uint32_t* lds, in
         top_step<KIND, l>(A, w[l >> 1], absmask, signmask);
     });
 }
+
+#if PR_LOGN == 9
+// ---- N = 512: the channel row -> the AGPRs (local stage 8), line by line through the same transposition ---------------------------
+template <int L_>
+__device__ __forceinline__ void top_copy_load(const TopAddr& A)
+{
+    constexpr int S = 128 + 32 * (L_ & 1);
+    const float *r0 = A.rp[0], *r1 = A.rp[1], *r2 = A.rp[2], *r3 = A.rp[3];
+    asm volatile("global_load_dwordx4 v[%[s]:%[s]+3], %[r0], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+4:%[s]+7], %[r1], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+8:%[s]+11], %[r2], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+12:%[s]+15], %[r3], off offset:%[o]"
+                 :
+                 : [s] "n"(S), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [o] "n"(128 * L_)
+                 : "memory");
+}
+template <int L_>
+__device__ __forceinline__ void top_copy_step(const TopAddr& A)
+{
+    constexpr int S = 128 + 32 * (L_ & 1), BUF = 8192 * (L_ & 1);
+    {
+        const uint32_t w0 = A.wa[0], w1 = A.wa[1], w2 = A.wa[2], w3 = A.wa[3];
+        asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
+                     "ds_write_b128 %[w0], v[%[s]:%[s]+3] offset:%[b]\n\t"
+                     "ds_write_b128 %[w1], v[%[s]+4:%[s]+7] offset:%[b]\n\t"
+                     "ds_write_b128 %[w2], v[%[s]+8:%[s]+11] offset:%[b]\n\t"
+                     "ds_write_b128 %[w3], v[%[s]+12:%[s]+15] offset:%[b]"
+                     :
+                     : [s] "n"(S), [b] "n"(BUF), [wt] "n"(L_ < 15 ? 4 : 0), [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3)
+                     : "memory");
+    }
+    if constexpr (L_ + 2 <= 15) top_copy_load<L_ + 2>(A);
+    {
+        const uint32_t r0 = A.ra[0], r1 = A.ra[1], r2 = A.ra[2], r3 = A.ra[3], r4 = A.ra[4], r5 = A.ra[5], r6 = A.ra[6], r7 = A.ra[7];
+#define PR_RD(k) "ds_read_b64 v[%[x]+2*" #k ":%[x]+2*" #k "+1], %[r" #k "] offset:%[b]\n\t"
+#define PR_WA(k) "v_accvgpr_write_b32 a[%[o]+" #k "], v[%[x]+" #k "]\n\t"
+        asm volatile(PR_RD(0) PR_RD(1) PR_RD(2) PR_RD(3) PR_RD(4) PR_RD(5) PR_RD(6) PR_RD(7) "s_waitcnt lgkmcnt(0)\n\t"
+                     PR_WA(0) PR_WA(1) PR_WA(2) PR_WA(3) PR_WA(4) PR_WA(5) PR_WA(6) PR_WA(7) PR_WA(8) PR_WA(9) PR_WA(10) PR_WA(11) PR_WA(12)
+                     PR_WA(13) PR_WA(14) "v_accvgpr_write_b32 a[%[o]+15], v[%[x]+15]"
+                     :
+                     : [x] "n"(TOP_WORK), [o] "n"(16 * L_), [b] "n"(BUF), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [r4] "v"(r4),
+                       [r5] "v"(r5), [r6] "v"(r6), [r7] "v"(r7)
+                     : "memory");
+#undef PR_WA
+#undef PR_RD
+    }
+}
+__device__ __forceinline__ void op_top_copy(const TopAddr& A)
+{
+    top_copy_load<0>(A);
+    top_copy_load<1>(A);
+    static_for<16>([&](auto Q) { top_copy_step<decltype(Q)::value>(A); });
+}
+#endif
 
 // ---- the same pass for int8 rows (FastSscFipChar: a row is 1024 bytes = 8 lines) -----------------------------------------
 // Line step LS = lines LS and LS + 4 of every row (positions 128 LS .. and 512 + 128 LS ..) through the same LDS image; BOTH
@@ -1424,7 +1489,7 @@ __device__ __forceinline__ void op_rone9(const TopAddr& A, uint32_t* lds, int la
 // BIG: with the leaves above 128 positions (a property of the code: the host picks the instantiation per decoder)
 template <bool CH, bool I8, bool BIG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(pair::KV)))
-void sc_pair_kernel(const DecodeParams P)
+void PR_KERNEL_NAME(const DecodeParams P)
 {
     using namespace pair;
     // (dynamic: with a static 40 KB the compiler derives one wave per SIMD from the LDS size and then ignores the VGPR cap)
@@ -1473,6 +1538,9 @@ void sc_pair_kernel(const DecodeParams P)
                 TA.rp[i] = reinterpret_cast<const float*>(P.llr) + (size_t)rr * N + 4u * ((uint32_t)lane & 7u);
         }
 
+#if PR_LOGN == 9
+        op_top_copy(TA);  // local stage 8 = the channel row
+#endif
         uint64_t nraw = prog[0];
         for (uint32_t pc = 0;; ++pc) {
             const uint64_t raw = nraw;
@@ -1503,7 +1571,11 @@ void sc_pair_kernel(const DecodeParams P)
                 // (ONE flat switch per step: nested if / switch ladders make the compiler thread flag registers through a
                 //  structured control flow graph -- dozens of scalar instructions per step)
                 switch ((((upk >> (2u * i)) & 3u) << 4) | (c0 + i)) {
+#if PR_LOGN == 10
                 case 0x19: op_combine<9, false>(lds, lane, side); break;
+                case 0x29: op_combine<9, true>(lds, lane, side); break;
+                case 0x39: op_rone9<CH, I8>(TA, lds, lane, side, absmask, signmask, S); break;
+#endif
                 case 0x18: op_combine<8, false>(lds, lane, side); break;
                 case 0x17: op_combine<7, false>(lds, lane, side); break;
                 case 0x16: op_combine<6, false>(lds, lane, side); break;
@@ -1511,7 +1583,6 @@ void sc_pair_kernel(const DecodeParams P)
                 case 0x14: op_combine<4, false>(lds, lane, side); break;
                 case 0x13: op_combine<3, false>(lds, lane, side); break;
                 case 0x12: op_combine<2, false>(lds, lane, side); break;
-                case 0x29: op_combine<9, true>(lds, lane, side); break;
                 case 0x28: op_combine<8, true>(lds, lane, side); break;
                 case 0x27: op_combine<7, true>(lds, lane, side); break;
                 case 0x26: op_combine<6, true>(lds, lane, side); break;
@@ -1519,7 +1590,6 @@ void sc_pair_kernel(const DecodeParams P)
                 case 0x24: op_combine<4, true>(lds, lane, side); break;
                 case 0x23: op_combine<3, true>(lds, lane, side); break;
                 case 0x22: op_combine<2, true>(lds, lane, side); break;
-                case 0x39: op_rone9<CH, I8>(TA, lds, lane, side, absmask, signmask, S); break;
                 case 0x38: op_rone8<CH>(lds, lane, lane16, side, absmask, signmask, S); break;
                 case 0x37: op_rone7(lds, lane, lane16, side, absmask, signmask); break;
                 case 0x36: op_rone<6>(lds, lane, side, signmask); break;
@@ -1542,7 +1612,11 @@ void sc_pair_kernel(const DecodeParams P)
                 if ((P.ablate & 512u) && d1 - i <= 6u) continue;
 #endif
                 switch ((kind << 4) | (d1 - i)) {
+#if PR_LOGN == 10
                 case 0x09: dn_top<CH, I8, 0>(TA, lds, lane, absmask, signmask, S); break;
+                case 0x19: dn_top<CH, I8, 1>(TA, lds, lane, absmask, signmask, S); break;
+                case 0x29: dn_top<CH, I8, 2>(TA, lds, lane, absmask, signmask, S); break;
+#endif
                 case 0x08: op_s8<CH, 0>(lane16, absmask, signmask, S); break;
                 case 0x07: dn_s7<CH, 0>(lane16, absmask, signmask, S); break;
                 case 0x06: dn_f<CH, 6>(absmask, S); break;
@@ -1550,7 +1624,6 @@ void sc_pair_kernel(const DecodeParams P)
                 case 0x04: dn_f<CH, 4>(absmask, S); break;
                 case 0x03: dn_f<CH, 3>(absmask, S); break;
                 case 0x02: dn_f<CH, 2>(absmask, S); break;
-                case 0x19: dn_top<CH, I8, 1>(TA, lds, lane, absmask, signmask, S); break;
                 case 0x18: op_s8<CH, 1>(lane16, absmask, signmask, S); break;
                 case 0x17: dn_s7<CH, 1>(lane16, absmask, signmask, S); break;
                 case 0x16: dn_g<CH, 6>(signmask, S); break;
@@ -1558,7 +1631,6 @@ void sc_pair_kernel(const DecodeParams P)
                 case 0x14: dn_g<CH, 4>(signmask, S); break;
                 case 0x13: dn_g<CH, 3>(signmask, S); break;
                 case 0x12: dn_g<CH, 2>(signmask, S); break;
-                case 0x29: dn_top<CH, I8, 2>(TA, lds, lane, absmask, signmask, S); break;
                 case 0x28: op_s8<CH, 2>(lane16, absmask, signmask, S); break;
                 case 0x27: dn_s7<CH, 2>(lane16, absmask, signmask, S); break;
                 case 0x26: dn_g0<CH, 6>(S); break;
@@ -1675,14 +1747,14 @@ void sc_pair_kernel(const DecodeParams P)
         if (P.ablate & 4u) continue;  // (cost hunt: no epilogue)
 #endif
         // ---- output: FastSscAvxFloat::decode :940-955 -------------------------------------------------------------------
-        // this lane's half of the code word, local order: 16 words
-        uint32_t x[16];
+        // this lane's half of the code word, local order: 16 words (N = 512: 8, the root's block is a stage-8 left block)
+        uint32_t x[NWL];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = lds[LDS_X + i * 64 + lane];
+        for (int i = 0; i < NWL; ++i) x[i] = lds[(PLOGN == 10 ? LDS_X : LDS_B8L) + i * 64 + lane];
         if (!P.systematic) {  // re-encode u = x G (butterfly_fip.cpp:15-63) in the local order: position distance 1 = local bit
                               // distance 1, 2 = the other lane, 2^k (k >= 2) = local distance 2^(k-1)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < NWL; ++i) {
                 uint32_t v = x[i];
                 v ^= (v >> 1) & 0x55555555u;
                 const uint32_t o = px(v);
@@ -1694,15 +1766,15 @@ void sc_pair_kernel(const DecodeParams P)
                 x[i] = v;
             }
 #pragma unroll
-            for (int hw = 1; hw < 16; hw <<= 1) {
+            for (int hw = 1; hw < NWL; hw <<= 1) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
+                for (int i = 0; i < NWL; ++i)
                     if (!(i & hw)) x[i] ^= x[i + hw];
             }
         }
-        // Interleave: lane p takes the code words 16 p .. 16 p + 15 (positions 512 p ..): word 2k + hf of them = the half
-        // hf of the local word 8 p + k of BOTH lanes, pairs of bits alternating
-        uint32_t rw[16];
+        // Interleave: lane p takes the code words 16 p .. 16 p + 15 (positions 512 p ..; N = 512: 8 p .., 256 p ..): word 2k + hf of them =
+        // the half hf of the local word 8 p + k of BOTH lanes, pairs of bits alternating
+        uint32_t rw[NWL];
         {
             const bool odd = L.p != 0;
             auto spread = [](uint32_t v) {  // 16 bits -> pairs of bits to the low half of every nibble
@@ -1711,8 +1783,8 @@ void sc_pair_kernel(const DecodeParams P)
                 return (v | (v << 2)) & 0x33333333u;
             };
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t keep = odd ? x[8 + k] : x[k], send = odd ? x[k] : x[8 + k];
+            for (int k = 0; k < NWL / 2; ++k) {
+                const uint32_t keep = odd ? x[NWL / 2 + k] : x[k], send = odd ? x[k] : x[NWL / 2 + k];
                 const uint32_t recv = px(send);
                 const uint32_t ev = odd ? recv : keep, ov = odd ? keep : recv;  // the even lane's word, the odd lane's word
                 rw[2 * k] = spread(ev & 0xFFFFu) | (spread(ov & 0xFFFFu) << 2);
@@ -1730,11 +1802,11 @@ void sc_pair_kernel(const DecodeParams P)
         for (uint32_t j = L.p; j <= nwords; j += 2) il[j * 32 + cw] = 0;
         WAVE_SYNC();
         {
-            const uint4* ext = reinterpret_cast<const uint4*>(P.ext) + 32u * L.p;  // (two uint4 per code word of 32 bits)
+            const uint4* ext = reinterpret_cast<const uint4*>(P.ext) + 2u * (uint32_t)NWL * L.p;  // (two uint4 per code word of 32 bits)
             uint64_t acc = 0;
             uint32_t cur = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < NWL; ++i) {
                 const uint4 ea = ext[2 * i], eb = ext[2 * i + 1];  // mask, base, mv0, mv1 | mv2, mv3, mv4, pad
                 const uint32_t mask = ea.x, base = ea.y;
                 const uint32_t mv[5] = { ea.z, ea.w, eb.x, eb.y, eb.z };
@@ -1788,6 +1860,7 @@ void sc_pair_kernel(const DecodeParams P)
     }
 }
 
+#if PR_LOGN == 10
 // (explicit instantiations in this order: the code object then starts with the kernels of the BASELINE configurations, and what is
 //  added behind them does not move them -- their speed depends on where their code sits)
 template __global__ void sc_pair_kernel<false, false, false>(const DecodeParams);
@@ -1810,5 +1883,18 @@ hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned
     else launch_sc_pair_t<false>(P, i8rows, grid, st);
     return hipGetLastError();
 }
+
+#else
+// N = 512: the float decoder on fp32 rows
+template __global__ void PR_KERNEL_NAME<false, false, false>(const DecodeParams);
+template __global__ void PR_KERNEL_NAME<false, false, true>(const DecodeParams);
+hipError_t PR_LAUNCH_NAME(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st)
+{
+    if (P.chr || i8rows || P.logN != (uint32_t)pair::PLOGN) return hipErrorInvalidValue;
+    if (big) hipLaunchKernelGGL((PR_KERNEL_NAME<false, false, true>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    else hipLaunchKernelGGL((PR_KERNEL_NAME<false, false, false>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    return hipGetLastError();
+}
+#endif
 
 }  // namespace pamd

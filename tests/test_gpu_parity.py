@@ -475,6 +475,44 @@ def test_pair_kernel_codes(built_library, K, dsnr, kind):
             assert np.array_equal(ok.astype(np.uint8), e_ok[:cnt])
 
 
+PAIR_CODES_512 = [(256, 0.0, "BB"), (200, 0.0, "BB"), (320, 1.0, "BB"), (88, 0.0, "BE"), (256, 2.0, "BB"), (150, -1.0, "BB"), (384, 0.0, "BB"),
+                  (128, 1.0, "BB"), (50, 0.0, "BB"), (450, 2.0, "BB"), (256, 0.0, "BE"), (224, 0.5, "BB")]
+
+
+@pytest.mark.parametrize("K,dsnr,kind", PAIR_CODES_512, ids=[f"K{k}_{c}_{d}" for k, d, c in PAIR_CODES_512])
+def test_pair_kernel_codes_n512(built_library, K, dsnr, kind):
+    """The same kernel at N = 512 (sc_pair_n9_kernel, round 4: the channel row is local stage 8 -- fetched into the AGPRs once per
+    codeword --, float decoder, fp32 rows; int8 rows and whatever its lowering cannot express run on sc_decode_kernel): rates and
+    constructions, AWGN / noise / tie rows with negative zeros, ragged batches, systematic and not, with and without a detector."""
+    import pypolar_amd
+    N = 512
+    rng = np.random.default_rng(K + int(10 * dsnr) + 11)
+    frozen = np.asarray(pypolar_amd.frozen_bits(N, K, dsnr, kind), dtype=np.uint32)
+    rows = 70
+    awgn = (1.0 + 0.8 * rng.standard_normal((rows, N))).astype(np.float32) * np.where(rng.random((rows, N)) < 0.5, 1, -1).astype(np.float32)
+    noise = rng.standard_normal((13, N)).astype(np.float32)
+    ties = rng.integers(-3, 4, (22, N)).astype(np.float32)
+    half = (rng.integers(-6, 7, (16, N)) / 2.0).astype(np.float32)
+    half[half == 0] = -0.0
+    llr = np.concatenate([awgn, noise, ties, half])
+    for systematic, det in ((True, 8), (False, 32), (True, 0)):
+        e_out, e_ok, _ = ob.decode_batch(N, 1, frozen, det, llr, systematic, "float")
+        d = pypolar_amd.PolarDecoder(N, 1, frozen, "float")
+        d.setErrorDetection(det, "crc")
+        d.setSystematic(systematic)
+        if (K, kind, dsnr) == (256, "BB", 0.0):
+            assert d.kernel_name(False) == "sc_pair_n9_kernel"
+        for cnt in (len(llr), 1, 33):
+            out, ok = d.decode_batch(llr[:cnt])
+            assert np.array_equal(out, e_out[:cnt]), (K, dsnr, kind, systematic, det, cnt)
+            assert np.array_equal(ok.astype(np.uint8), e_ok[:cnt])
+        if det == 8:  # int8 rows into the same decoder: the other kernel, the same answers
+            rows8 = ties.astype(np.int8)
+            e8, eok8, _ = ob.decode_batch(N, 1, frozen, det, rows8.astype(np.float32), systematic, "float")
+            o8, ok8 = d.decode_batch(rows8)
+            assert np.array_equal(o8, e8) and np.array_equal(ok8.astype(np.uint8), eok8)
+
+
 def test_pair_kernel_int8_rows_into_the_float_decoder(built_library):
     """decode_vector(const char*) of the float decoder (the values converted, float arithmetic; fastssc_avx_float.cpp:940-955 via
     FloatContainer::insertCharLlr): int8 rows must decode like the same values as fp32 rows, here on the two-lanes-per-codeword

@@ -322,7 +322,7 @@ def test_sc_builder_refuses_the_sets_the_reference_refuses(built_library):
 
 
 @pytest.mark.parametrize("N,L,cw,groups", [
-    (128, 1, 8, 1), (256, 1, 8, 1), (512, 1, 4, 1), (1024, 1, 32, 1), (4096, 1, 4, 1),       # SC: 8 lanes per codeword up to 256, 2 lanes at N = 1024 (sc_pair_kernel)
+    (128, 1, 8, 1), (256, 1, 8, 1), (512, 1, 32, 1), (1024, 1, 32, 1), (4096, 1, 4, 1),       # SC: 8 lanes per codeword up to 256, 2 lanes at N = 512 / 1024 (sc_pair_kernel)
     (256, 2, 8, 16), (256, 4, 4, 16), (8192, 3, 2, 8),                                        # path groups: 4 lanes per path up to N = 2048 for L <= 4 (N < 512 and > 4096 only, since round 4)
     (1024, 8, 8, 64), (1024, 5, 8, 64),                                                       # lane-per-path kernel: N = 1024, 4 < L <= 8
     (512, 8, 8, 64), (2048, 8, 8, 64), (4096, 8, 8, 64),                                      # ... and, since round 4, N = 512 / 2048 / 4096
@@ -378,13 +378,16 @@ def test_kernel_name_reports_the_side_of_the_geometry_rules(built_library, N, L,
     assert d.kernel_name(True) == name
     sc = pypolar_amd.PolarDecoder(1024, 1, frozen_bits(1024, 512, 0.0, "BB"), "float")
     assert sc.kernel_name(False) == "sc_pair_kernel"
+    assert pypolar_amd.PolarDecoder(512, 1, frozen_bits(512, 256, 0.0, "BB"), "float").kernel_name(False) == "sc_pair_n9_kernel"   # (round 4)
+    assert pypolar_amd.PolarDecoder(512, 1, frozen_bits(512, 256, 0.0, "BB"), "char").kernel_name(False) == "sc_decode_kernel"    # (the int8 decoder: N = 1024 only)
+    assert pypolar_amd.PolarDecoder(2048, 1, frozen_bits(2048, 1024, 0.0, "BB"), "float").kernel_name(False) == "sc_decode_kernel"
     with pytest.raises(Exception):   # (PCD_ERR_INVALID_ARG: this decoder has no list program)
         sc.kernel_name(True)
 
 
 @pytest.mark.parametrize("dectype", ["float", "char"])
 def test_pair_kernel_takes_the_trees_it_can_express(built_library, dectype):
-    """host side of the two-lanes-per-codeword SC kernel (pair_program.cpp, lower_pair): N = 1024 only, ROne nodes at every
+    """host side of the two-lanes-per-codeword SC kernel (pair_program.cpp, lower_pair): N = 1024 (and 512, float decoder), ROne nodes at every
     stage, leaves up to 512 positions (above 128 in separate instantiations of the kernel, picked per decoder); whatever else
     a construction needs (a double-SPC leaf above 128 positions) keeps sc_decode_kernel -- no GPU needed:
     pcd_launch_info reports the geometry the host picked"""
@@ -399,8 +402,10 @@ def test_pair_kernel_takes_the_trees_it_can_express(built_library, dectype):
     assert on_pair >= 18, on_pair                                      # (20 constructions)
     for K in (512, 400, 640):                                           # the BASELINE code and its neighbours must be on it
         assert pypolar_amd.PolarDecoder(1024, 1, frozen_bits(1024, K, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] == 32
-    for N in (512, 2048):                                               # other block lengths: sc_decode_kernel
-        assert pypolar_amd.PolarDecoder(N, 1, frozen_bits(N, N // 2, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] == 4
+    for N in (256, 2048):                                               # other block lengths: sc_decode_kernel
+        assert pypolar_amd.PolarDecoder(N, 1, frozen_bits(N, N // 2, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] in (4, 8)
+    # N = 512 (round 4, sc_pair_n9.hip): the float decoder only
+    assert pypolar_amd.PolarDecoder(512, 1, frozen_bits(512, 256, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] == (32 if dectype == "float" else 4)
 
 
 def test_code_objects_keep_the_build_contracts(built_library):
@@ -418,7 +423,7 @@ def test_code_objects_keep_the_build_contracts(built_library):
     rows, problems = codeobj.analyse(pypolar_amd.library_path())
     assert not problems, "\n".join(problems)
     names = " ".join(r["kernel"] for r in rows)
-    for k in ("scl_lane_kernel", "scl_lane_char_kernel", "scl_lane_char_big_kernel", "scl_lane_big_kernel", "sc_pair_kernel", "sc_decode_kernel",
+    for k in ("scl_lane_kernel", "scl_lane_char_kernel", "scl_lane_char_big_kernel", "scl_lane_big_kernel", "sc_pair_kernel", "sc_pair_n9_kernel", "sc_decode_kernel",
               "scl_decode_kernel", "encode_kernel"):
         assert k in names, k   # (the check saw the kernels it is about)
     assert sum(r["long_branches"] for r in rows) > 0   # (... and long branches exist: the pattern match is alive)

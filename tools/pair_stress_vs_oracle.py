@@ -1,6 +1,6 @@
 """The two-lanes-per-codeword SC kernels (float and int8, N = 1024) against the oracle on random, tie-heavy and extreme rows over
 many rates and constructions (run on the GPU box; the oracle is the checker).  Every row: bytes and verdict must be equal.
-usage: python tools/pair_stress_vs_oracle.py [rows_per_case]"""
+usage: [PAIR_N=512] python tools/pair_stress_vs_oracle.py [rows_per_case]"""
 import os
 import sys
 
@@ -13,10 +13,10 @@ from pypolar_amd.construction import frozen_bits
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rng = np.random.default_rng(4711)
-N = 1024
+N = int(os.environ.get("PAIR_N", "1024"))   # 512: sc_pair_n9_kernel (float decoder)
 bad = cases = onpair = 0
-for dectype in ("float", "char"):
-    for K in list(range(40, 1000, 24)) + [512]:
+for dectype in (("float", "char") if N == 1024 else ("float",)):
+    for K in list(range(40 * N // 1024 + 8, N - 20, 24 * N // 1024)) + [N // 2]:
         for dsnr, kind in ((0.0, "BB"), (2.0, "BB"), (-1.5, "BB"), (1.0, "BE")):
             try:
                 frozen = np.asarray(frozen_bits(N, K, dsnr, kind), dtype=np.uint32)
