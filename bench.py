@@ -152,6 +152,7 @@ CONFIGS = {
     "n2048_l8": dict(N=2048, K=1024, L=8, dsnr=0.0, crc=8, crc_type="crc", ebn0=2.0, log2_batch=17, name="N=2048 K=1024 SCL L=8 + CRC-8, batch=2^17"),
     "n1024_l16": dict(N=1024, K=512, L=16, dsnr=0.0, crc=8, crc_type="crc", ebn0=2.0, log2_batch=17, name="N=1024 K=512 SCL L=16 + CRC-8, batch=2^17"),
     "n1024_l32": dict(N=1024, K=512, L=32, dsnr=0.0, crc=8, crc_type="crc", ebn0=2.0, log2_batch=16, name="N=1024 K=512 SCL L=32 + CRC-8, batch=2^16"),
+    "n512_sc": dict(N=512, K=256, L=1, dsnr=0.0, crc=0, crc_type="crc", ebn0=2.0, log2_batch=20, name="N=512 K=256 SC (Fast-SSC), batch=2^20"),
     "n1024_l4": dict(N=1024, K=512, L=4, dsnr=0.0, crc=8, crc_type="crc", ebn0=2.0, log2_batch=18, name="N=1024 K=512 SCL L=4 + CRC-8, batch=2^18"),
     "n1024_l2": dict(N=1024, K=512, L=2, dsnr=0.0, crc=8, crc_type="crc", ebn0=2.0, log2_batch=19, name="N=1024 K=512 SCL L=2 + CRC-8, batch=2^19"),
     # secondary workload: rate matching in front of the decoder (PolarCode::Puncturer::depuncture<float>)

@@ -771,7 +771,7 @@ int run_sc_pair(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 int run_sc(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
 {
     // (fp32 or int8 rows for the float decoder; the int8 decoder sees int8 rows only: float rows were converted by the caller)
-    if (d->has_pair && (i8 || d->dectype != 0) && !(d->logN == 9 && i8)) return run_sc_pair(d, P, i8, st);  // (N = 512: fp32 rows only)
+    if (d->has_pair && (i8 || d->dectype != 0)) return run_sc_pair(d, P, i8, st);
     P.prog = d->d_sc_prog;
     P.prog_len = (uint32_t)d->sc_prog.ins.size() - 1u;  // (without the closing OP_END)
     P.wave_lds_words = d->sc_wave_words;

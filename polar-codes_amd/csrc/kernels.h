@@ -66,7 +66,7 @@ unsigned scl_lane_arena_words();
 // the lane kernel; single-wave workgroups with 40 KB of dynamic LDS
 // big: the code has a leaf above 128 positions (lower_pair reports it): the instantiation that carries those leaves
 hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
-// ... N = 512 (sc_pair_n9.hip): the float decoder on fp32 rows; hipErrorInvalidValue for anything else
+// ... N = 512 (sc_pair_n9.hip)
 hipError_t launch_sc_pair_n9(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
 // CharContainer::insertLlr(const float*) (bitcontainer.cpp:449-516, N >= 8): round to nearest even, saturate to int8
 hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st);

@@ -26,7 +26,7 @@
 // every cross-lane sum the reference takes is a sum of one value per lane (commutative) or is rebuilt in full in both lanes.
 #define PAMD_POLAR_F_MINF 1
 // PR_LOGN (sc_pair_n9.hip): the same source for N = 512 -- the channel row IS local stage 8: it is fetched into the AGPRs once per
-// codeword (whole lines, transposed through the LDS like the pass of N = 1024) and the tree below is the same; float decoder, fp32 rows.
+// codeword (whole lines, transposed through the LDS like the pass of N = 1024; int8 rows widened on the way) and the tree below is the same.
 #ifndef PR_LOGN
 #define PR_LOGN 10
 #endif
@@ -733,6 +733,80 @@ __device__ __forceinline__ void op_top8(const TopAddr& A, const uint32_t* lds, i
     top8_step<SAT, KIND, 2>(A, sh0, sh1, w, absmask, signmask, S);
     top8_step<SAT, KIND, 3>(A, sh0, sh1, w, absmask, signmask, S);
 }
+
+#if PR_LOGN == 9
+// ---- N = 512, int8 rows (512 bytes = 4 lines): line by line into the AGPRs, widened on the way -------------------------------------
+template <int LS>
+__device__ __forceinline__ void top8_copy_load(const TopAddr& A)
+{
+    constexpr int S = 128 + 32 * (LS & 1);
+    const float *r0 = A.rp[0], *r1 = A.rp[1], *r2 = A.rp[2], *r3 = A.rp[3];
+    asm volatile("global_load_dwordx4 v[%[s]:%[s]+3], %[r0], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+4:%[s]+7], %[r1], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+8:%[s]+11], %[r2], off offset:%[o]\n\t"
+                 "global_load_dwordx4 v[%[s]+12:%[s]+15], %[r3], off offset:%[o]"
+                 :
+                 : [s] "n"(S), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [o] "n"(128 * LS)
+                 : "memory");
+}
+template <int LS, int Q>
+__device__ __forceinline__ void top8_copy_quarter(const TopAddr& A, uint32_t sh0, uint32_t sh1)
+{
+    constexpr int BUF = 8192 * (LS & 1);
+    {
+        const uint32_t ra = A.ra[2 * Q], rb = A.ra[2 * Q + 1];
+        asm volatile("ds_read_b128 v[%[w]:%[w]+3], %[ra] offset:%[b]\n\t"
+                     "ds_read_b128 v[%[w]+4:%[w]+7], %[rb] offset:%[b]\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     :
+                     : [w] "n"(T8_W), [b] "n"(BUF), [ra] "v"(ra), [rb] "v"(rb)
+                     : "memory");
+    }
+    static_for<8>([&](auto K) {  // word k -> this lane's two values
+        constexpr int k = decltype(K)::value;
+        const uint32_t a0 = sh0, a1 = sh1;
+        asm volatile("v_bfe_i32 v[%[d]], v[%[s]], %[a0], 8\n\t"
+                     "v_bfe_i32 v[%[d]+1], v[%[s]], %[a1], 8\n\t"
+                     "v_cvt_f32_i32 v[%[d]], v[%[d]]\n\t"
+                     "v_cvt_f32_i32 v[%[d]+1], v[%[d]+1]\n\t"
+                     "v_accvgpr_write_b32 a[%[o]], v[%[d]]\n\t"
+                     "v_accvgpr_write_b32 a[%[o]+1], v[%[d]+1]"
+                     :
+                     : [d] "n"(T8_A + 2 * k), [s] "n"(T8_W + k), [o] "n"(64 * LS + 16 * Q + 2 * k), [a0] "v"(a0), [a1] "v"(a1));
+    });
+}
+template <int LS>
+__device__ __forceinline__ void top8_copy_step(const TopAddr& A, uint32_t sh0, uint32_t sh1)
+{
+    constexpr int SL = 128 + 32 * (LS & 1), BUF = 8192 * (LS & 1);
+    {
+        const uint32_t w0 = A.wa[0], w1 = A.wa[1], w2 = A.wa[2], w3 = A.wa[3];
+        asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
+                     "ds_write_b128 %[w0], v[%[s]:%[s]+3] offset:%[b]\n\t"
+                     "ds_write_b128 %[w1], v[%[s]+4:%[s]+7] offset:%[b]\n\t"
+                     "ds_write_b128 %[w2], v[%[s]+8:%[s]+11] offset:%[b]\n\t"
+                     "ds_write_b128 %[w3], v[%[s]+12:%[s]+15] offset:%[b]"
+                     :
+                     : [s] "n"(SL), [b] "n"(BUF), [wt] "n"(LS < 3 ? 4 : 0), [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3)
+                     : "memory");
+    }
+    if constexpr (LS + 2 <= 3) top8_copy_load<LS + 2>(A);
+    top8_copy_quarter<LS, 0>(A, sh0, sh1);
+    top8_copy_quarter<LS, 1>(A, sh0, sh1);
+    top8_copy_quarter<LS, 2>(A, sh0, sh1);
+    top8_copy_quarter<LS, 3>(A, sh0, sh1);
+}
+__device__ __forceinline__ void op_top8_copy(const TopAddr& A, int lane)
+{
+    top8_copy_load<0>(A);
+    top8_copy_load<1>(A);
+    const uint32_t sh0 = 16u * ((uint32_t)lane & 1u), sh1 = sh0 + 8u;
+    top8_copy_step<0>(A, sh0, sh1);
+    top8_copy_step<1>(A, sh0, sh1);
+    top8_copy_step<2>(A, sh0, sh1);
+    top8_copy_step<3>(A, sh0, sh1);
+}
+#endif
 
 // ---- partial sums ---------------------------------------------------------------------------------------------------------
 template <int T>
@@ -1539,7 +1613,8 @@ void PR_KERNEL_NAME(const DecodeParams P)
         }
 
 #if PR_LOGN == 9
-        op_top_copy(TA);  // local stage 8 = the channel row
+        if constexpr (I8) op_top8_copy(TA, lane);  // local stage 8 = the channel row
+        else op_top_copy(TA);
 #endif
         uint64_t nraw = prog[0];
         for (uint32_t pc = 0;; ++pc) {
@@ -1885,14 +1960,25 @@ hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned
 }
 
 #else
-// N = 512: the float decoder on fp32 rows
+// N = 512
 template __global__ void PR_KERNEL_NAME<false, false, false>(const DecodeParams);
+template __global__ void PR_KERNEL_NAME<true, true, false>(const DecodeParams);
+template __global__ void PR_KERNEL_NAME<false, true, false>(const DecodeParams);
 template __global__ void PR_KERNEL_NAME<false, false, true>(const DecodeParams);
+template __global__ void PR_KERNEL_NAME<true, true, true>(const DecodeParams);
+template __global__ void PR_KERNEL_NAME<false, true, true>(const DecodeParams);
+template <bool BIG>
+static void launch_sc_pair_n9_t(const DecodeParams& P, bool i8rows, unsigned grid, hipStream_t st)
+{
+    if (P.chr) hipLaunchKernelGGL((PR_KERNEL_NAME<true, true, BIG>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    else if (i8rows) hipLaunchKernelGGL((PR_KERNEL_NAME<false, true, BIG>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    else hipLaunchKernelGGL((PR_KERNEL_NAME<false, false, BIG>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+}
 hipError_t PR_LAUNCH_NAME(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st)
 {
-    if (P.chr || i8rows || P.logN != (uint32_t)pair::PLOGN) return hipErrorInvalidValue;
-    if (big) hipLaunchKernelGGL((PR_KERNEL_NAME<false, false, true>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
-    else hipLaunchKernelGGL((PR_KERNEL_NAME<false, false, false>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
+    if (P.logN != (uint32_t)pair::PLOGN) return hipErrorInvalidValue;
+    if (big) launch_sc_pair_n9_t<true>(P, i8rows, grid, st);
+    else launch_sc_pair_n9_t<false>(P, i8rows, grid, st);
     return hipGetLastError();
 }
 #endif

@@ -1,4 +1,4 @@
-// two-lanes-per-codeword SC kernel, N = 512: sc_pair_kernel.hip with the channel row as local stage 8 (float decoder, fp32 rows)
+// two-lanes-per-codeword SC kernel, N = 512: sc_pair_kernel.hip with the channel row as local stage 8 (float and int8 decoder, fp32 and int8 rows)
 #define PR_LOGN 9
 #define PR_KERNEL_NAME sc_pair_n9_kernel
 #define PR_LAUNCH_NAME launch_sc_pair_n9

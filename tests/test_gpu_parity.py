@@ -482,7 +482,7 @@ PAIR_CODES_512 = [(256, 0.0, "BB"), (200, 0.0, "BB"), (320, 1.0, "BB"), (88, 0.0
 @pytest.mark.parametrize("K,dsnr,kind", PAIR_CODES_512, ids=[f"K{k}_{c}_{d}" for k, d, c in PAIR_CODES_512])
 def test_pair_kernel_codes_n512(built_library, K, dsnr, kind):
     """The same kernel at N = 512 (sc_pair_n9_kernel, round 4: the channel row is local stage 8 -- fetched into the AGPRs once per
-    codeword --, float decoder, fp32 rows; int8 rows and whatever its lowering cannot express run on sc_decode_kernel): rates and
+    codeword, int8 rows widened on the way --; whatever its lowering cannot express runs on sc_decode_kernel): rates and
     constructions, AWGN / noise / tie rows with negative zeros, ragged batches, systematic and not, with and without a detector."""
     import pypolar_amd
     N = 512
@@ -506,11 +506,19 @@ def test_pair_kernel_codes_n512(built_library, K, dsnr, kind):
             out, ok = d.decode_batch(llr[:cnt])
             assert np.array_equal(out, e_out[:cnt]), (K, dsnr, kind, systematic, det, cnt)
             assert np.array_equal(ok.astype(np.uint8), e_ok[:cnt])
-        if det == 8:  # int8 rows into the same decoder: the other kernel, the same answers
+        if det == 8:  # int8 rows into the same decoder (the <false, true> instantiations), and the int8 decoder on them
             rows8 = ties.astype(np.int8)
             e8, eok8, _ = ob.decode_batch(N, 1, frozen, det, rows8.astype(np.float32), systematic, "float")
             o8, ok8 = d.decode_batch(rows8)
             assert np.array_equal(o8, e8) and np.array_equal(ok8.astype(np.uint8), eok8)
+            wide = np.clip(np.rint(8.0 * awgn), -128, 127).astype(np.int8)
+            rowsc = np.concatenate([rows8, wide])
+            ec, eokc, _ = ob.decode_batch(N, 1, frozen, det, rowsc.astype(np.float32), systematic, "char")
+            dc = pypolar_amd.PolarDecoder(N, 1, frozen, "char")
+            dc.setErrorDetection(det, "crc")
+            dc.setSystematic(systematic)
+            oc, okc = dc.decode_batch(rowsc)
+            assert np.array_equal(oc, ec) and np.array_equal(okc.astype(np.uint8), eokc)
 
 
 def test_pair_kernel_int8_rows_into_the_float_decoder(built_library):

@@ -379,7 +379,7 @@ def test_kernel_name_reports_the_side_of_the_geometry_rules(built_library, N, L,
     sc = pypolar_amd.PolarDecoder(1024, 1, frozen_bits(1024, 512, 0.0, "BB"), "float")
     assert sc.kernel_name(False) == "sc_pair_kernel"
     assert pypolar_amd.PolarDecoder(512, 1, frozen_bits(512, 256, 0.0, "BB"), "float").kernel_name(False) == "sc_pair_n9_kernel"   # (round 4)
-    assert pypolar_amd.PolarDecoder(512, 1, frozen_bits(512, 256, 0.0, "BB"), "char").kernel_name(False) == "sc_decode_kernel"    # (the int8 decoder: N = 1024 only)
+    assert pypolar_amd.PolarDecoder(512, 1, frozen_bits(512, 256, 0.0, "BB"), "char").kernel_name(False) == "sc_pair_n9_kernel"
     assert pypolar_amd.PolarDecoder(2048, 1, frozen_bits(2048, 1024, 0.0, "BB"), "float").kernel_name(False) == "sc_decode_kernel"
     with pytest.raises(Exception):   # (PCD_ERR_INVALID_ARG: this decoder has no list program)
         sc.kernel_name(True)
@@ -387,7 +387,7 @@ def test_kernel_name_reports_the_side_of_the_geometry_rules(built_library, N, L,
 
 @pytest.mark.parametrize("dectype", ["float", "char"])
 def test_pair_kernel_takes_the_trees_it_can_express(built_library, dectype):
-    """host side of the two-lanes-per-codeword SC kernel (pair_program.cpp, lower_pair): N = 1024 (and 512, float decoder), ROne nodes at every
+    """host side of the two-lanes-per-codeword SC kernel (pair_program.cpp, lower_pair): N = 1024 and 512, ROne nodes at every
     stage, leaves up to 512 positions (above 128 in separate instantiations of the kernel, picked per decoder); whatever else
     a construction needs (a double-SPC leaf above 128 positions) keeps sc_decode_kernel -- no GPU needed:
     pcd_launch_info reports the geometry the host picked"""
@@ -404,8 +404,8 @@ def test_pair_kernel_takes_the_trees_it_can_express(built_library, dectype):
         assert pypolar_amd.PolarDecoder(1024, 1, frozen_bits(1024, K, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] == 32
     for N in (256, 2048):                                               # other block lengths: sc_decode_kernel
         assert pypolar_amd.PolarDecoder(N, 1, frozen_bits(N, N // 2, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] in (4, 8)
-    # N = 512 (round 4, sc_pair_n9.hip): the float decoder only
-    assert pypolar_amd.PolarDecoder(512, 1, frozen_bits(512, 256, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] == (32 if dectype == "float" else 4)
+    # N = 512 (round 4, sc_pair_n9.hip)
+    assert pypolar_amd.PolarDecoder(512, 1, frozen_bits(512, 256, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] == 32
 
 
 def test_code_objects_keep_the_build_contracts(built_library):

@@ -13,9 +13,9 @@ from pypolar_amd.construction import frozen_bits
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rng = np.random.default_rng(4711)
-N = int(os.environ.get("PAIR_N", "1024"))   # 512: sc_pair_n9_kernel (float decoder)
+N = int(os.environ.get("PAIR_N", "1024"))   # 512: sc_pair_n9_kernel
 bad = cases = onpair = 0
-for dectype in (("float", "char") if N == 1024 else ("float",)):
+for dectype in ("float", "char"):
     for K in list(range(40 * N // 1024 + 8, N - 20, 24 * N // 1024)) + [N // 2]:
         for dsnr, kind in ((0.0, "BB"), (2.0, "BB"), (-1.5, "BB"), (1.0, "BE")):
             try:
