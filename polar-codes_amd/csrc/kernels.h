@@ -66,8 +66,10 @@ unsigned scl_lane_arena_words();
 // the lane kernel; single-wave workgroups with 40 KB of dynamic LDS
 // big: the code has a leaf above 128 positions (lower_pair reports it): the instantiation that carries those leaves
 hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
-// ... N = 512 (sc_pair_n9.hip)
+// ... N = 512 / 256 / 128 (sc_pair_n9 / n8 / n7.hip)
 hipError_t launch_sc_pair_n9(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
+hipError_t launch_sc_pair_n8(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
+hipError_t launch_sc_pair_n7(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
 // CharContainer::insertLlr(const float*) (bitcontainer.cpp:449-516, N >= 8): round to nearest even, saturate to int8
 hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st);
 hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,

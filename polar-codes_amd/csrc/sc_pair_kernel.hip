@@ -43,7 +43,7 @@ namespace pamd {
 namespace pair {
 
 // ---- register map (per lane) ---------------------------------------------------------------------------------------
-constexpr int PLOGN = PR_LOGN;             // log2 of the block length: 10, or 9 (the channel row is local stage 8)
+constexpr int PLOGN = PR_LOGN;             // log2 of the block length: 10, or 9 / 8 / 7 (the channel row is local stage 8 / 7 / 6)
 constexpr int NWL = (1 << PLOGN) / 64;     // words of the code word per lane
 constexpr int KV = 104;      // the compiler's VGPR budget: v0 .. v103
 constexpr int RBL0 = 104;    // left-child / root output bits of local stage T <= 5: v[104 + T]
@@ -554,8 +554,31 @@ __device__ __forceinline__ void op_top(const TopAddr& A, const uint32_t* lds, in
     });
 }
 
-#if PR_LOGN == 9
-// ---- N = 512: the channel row -> the AGPRs (local stage 8), line by line through the same transposition ---------------------------
+#if PR_LOGN < 10
+// ---- N = 512 / 256 / 128: the channel row IS local stage 8 / 7 / 6 -- it goes, line by line through the same transposition, into the
+// AGPRs / the lane's LDS column / v[190 ..) (the staging buffers of N = 256 sit in the rows of the stage-8 bits, which that length never uses)
+constexpr int CP_LINES = (4 << PR_LOGN) / 128;                       // 128-byte lines per fp32 row
+constexpr int STG_STRIDE = PR_LOGN == 8 ? 4096 : 8192;               // staging buffer of line L at STG_STRIDE * (L & 1)
+// work registers of a line (N = 128: the destination is v[190 .. 253] itself, so they sit below it -- v[144 .. 159], and the converted
+// int8 values in the bit registers v[104 .. 119], which nothing has written yet)
+constexpr int CPX = PR_LOGN == 7 ? 144 : 192, CP8W = PR_LOGN == 7 ? 144 : 192, CP8A = PR_LOGN == 7 ? 104 : 208;
+template <int O, int X>
+__device__ __forceinline__ void copy_sink16(uint32_t col)  // v[X .. X + 15] = the local values O .. O + 15
+{
+    if constexpr (PR_LOGN == 9) {
+        static_for<16>([&](auto I) { asm volatile("v_accvgpr_write_b32 a[%0], v[%1]" ::"n"(O + decltype(I)::value), "n"(X + decltype(I)::value)); });
+    } else if constexpr (PR_LOGN == 8) {
+        asm volatile("ds_write_b128 %[c], v[%[x]:%[x]+3] offset:%[o]\n\t"
+                     "ds_write_b128 %[c], v[%[x]+4:%[x]+7] offset:%[o]+1024\n\t"
+                     "ds_write_b128 %[c], v[%[x]+8:%[x]+11] offset:%[o]+2048\n\t"
+                     "ds_write_b128 %[c], v[%[x]+12:%[x]+15] offset:%[o]+3072"
+                     :
+                     : [c] "v"(col), [x] "n"(X), [o] "n"(4 * LDS_S7 + (O / 4) * 1024)
+                     : "memory");
+    } else {
+        static_for<16>([&](auto I) { asm volatile("v_mov_b32 v[%0], v[%1]" ::"n"(RS(6) + O + decltype(I)::value), "n"(X + decltype(I)::value)); });
+    }
+}
 template <int L_>
 __device__ __forceinline__ void top_copy_load(const TopAddr& A)
 {
@@ -570,9 +593,9 @@ __device__ __forceinline__ void top_copy_load(const TopAddr& A)
                  : "memory");
 }
 template <int L_>
-__device__ __forceinline__ void top_copy_step(const TopAddr& A)
+__device__ __forceinline__ void top_copy_step(const TopAddr& A, uint32_t col)
 {
-    constexpr int S = 128 + 32 * (L_ & 1), BUF = 8192 * (L_ & 1);
+    constexpr int S = 128 + 32 * (L_ & 1), BUF = STG_STRIDE * (L_ & 1);
     {
         const uint32_t w0 = A.wa[0], w1 = A.wa[1], w2 = A.wa[2], w3 = A.wa[3];
         asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
@@ -581,30 +604,28 @@ __device__ __forceinline__ void top_copy_step(const TopAddr& A)
                      "ds_write_b128 %[w2], v[%[s]+8:%[s]+11] offset:%[b]\n\t"
                      "ds_write_b128 %[w3], v[%[s]+12:%[s]+15] offset:%[b]"
                      :
-                     : [s] "n"(S), [b] "n"(BUF), [wt] "n"(L_ < 15 ? 4 : 0), [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3)
+                     : [s] "n"(S), [b] "n"(BUF), [wt] "n"(L_ < CP_LINES - 1 ? 4 : 0), [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3)
                      : "memory");
     }
-    if constexpr (L_ + 2 <= 15) top_copy_load<L_ + 2>(A);
+    if constexpr (L_ + 2 <= CP_LINES - 1) top_copy_load<L_ + 2>(A);
     {
         const uint32_t r0 = A.ra[0], r1 = A.ra[1], r2 = A.ra[2], r3 = A.ra[3], r4 = A.ra[4], r5 = A.ra[5], r6 = A.ra[6], r7 = A.ra[7];
 #define PR_RD(k) "ds_read_b64 v[%[x]+2*" #k ":%[x]+2*" #k "+1], %[r" #k "] offset:%[b]\n\t"
-#define PR_WA(k) "v_accvgpr_write_b32 a[%[o]+" #k "], v[%[x]+" #k "]\n\t"
-        asm volatile(PR_RD(0) PR_RD(1) PR_RD(2) PR_RD(3) PR_RD(4) PR_RD(5) PR_RD(6) PR_RD(7) "s_waitcnt lgkmcnt(0)\n\t"
-                     PR_WA(0) PR_WA(1) PR_WA(2) PR_WA(3) PR_WA(4) PR_WA(5) PR_WA(6) PR_WA(7) PR_WA(8) PR_WA(9) PR_WA(10) PR_WA(11) PR_WA(12)
-                     PR_WA(13) PR_WA(14) "v_accvgpr_write_b32 a[%[o]+15], v[%[x]+15]"
+        asm volatile(PR_RD(0) PR_RD(1) PR_RD(2) PR_RD(3) PR_RD(4) PR_RD(5) PR_RD(6) PR_RD(7) "s_waitcnt lgkmcnt(0)"
                      :
-                     : [x] "n"(TOP_WORK), [o] "n"(16 * L_), [b] "n"(BUF), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [r4] "v"(r4),
+                     : [x] "n"(CPX), [b] "n"(BUF), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [r4] "v"(r4),
                        [r5] "v"(r5), [r6] "v"(r6), [r7] "v"(r7)
                      : "memory");
-#undef PR_WA
 #undef PR_RD
     }
+    copy_sink16<16 * L_, CPX>(col);
 }
-__device__ __forceinline__ void op_top_copy(const TopAddr& A)
+__device__ __forceinline__ void op_top_copy(const TopAddr& A, uint32_t col)
 {
     top_copy_load<0>(A);
     top_copy_load<1>(A);
-    static_for<16>([&](auto Q) { top_copy_step<decltype(Q)::value>(A); });
+    static_for<CP_LINES>([&](auto Q) { top_copy_step<decltype(Q)::value>(A, col); });
+    if constexpr (PR_LOGN == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 #endif
 
@@ -734,8 +755,9 @@ __device__ __forceinline__ void op_top8(const TopAddr& A, const uint32_t* lds, i
     top8_step<SAT, KIND, 3>(A, sh0, sh1, w, absmask, signmask, S);
 }
 
-#if PR_LOGN == 9
-// ---- N = 512, int8 rows (512 bytes = 4 lines): line by line into the AGPRs, widened on the way -------------------------------------
+#if PR_LOGN < 10
+// ---- ... int8 rows (N bytes = 4 / 2 / 1 lines): the same, widened on the way ---------------------------------------------------------
+constexpr int CP8_LINES = (1 << PR_LOGN) / 128;
 template <int LS>
 __device__ __forceinline__ void top8_copy_load(const TopAddr& A)
 {
@@ -750,16 +772,16 @@ __device__ __forceinline__ void top8_copy_load(const TopAddr& A)
                  : "memory");
 }
 template <int LS, int Q>
-__device__ __forceinline__ void top8_copy_quarter(const TopAddr& A, uint32_t sh0, uint32_t sh1)
+__device__ __forceinline__ void top8_copy_quarter(const TopAddr& A, uint32_t sh0, uint32_t sh1, uint32_t col)
 {
-    constexpr int BUF = 8192 * (LS & 1);
+    constexpr int BUF = STG_STRIDE * (LS & 1);
     {
         const uint32_t ra = A.ra[2 * Q], rb = A.ra[2 * Q + 1];
         asm volatile("ds_read_b128 v[%[w]:%[w]+3], %[ra] offset:%[b]\n\t"
                      "ds_read_b128 v[%[w]+4:%[w]+7], %[rb] offset:%[b]\n\t"
                      "s_waitcnt lgkmcnt(0)"
                      :
-                     : [w] "n"(T8_W), [b] "n"(BUF), [ra] "v"(ra), [rb] "v"(rb)
+                     : [w] "n"(CP8W), [b] "n"(BUF), [ra] "v"(ra), [rb] "v"(rb)
                      : "memory");
     }
     static_for<8>([&](auto K) {  // word k -> this lane's two values
@@ -768,17 +790,17 @@ __device__ __forceinline__ void top8_copy_quarter(const TopAddr& A, uint32_t sh0
         asm volatile("v_bfe_i32 v[%[d]], v[%[s]], %[a0], 8\n\t"
                      "v_bfe_i32 v[%[d]+1], v[%[s]], %[a1], 8\n\t"
                      "v_cvt_f32_i32 v[%[d]], v[%[d]]\n\t"
-                     "v_cvt_f32_i32 v[%[d]+1], v[%[d]+1]\n\t"
-                     "v_accvgpr_write_b32 a[%[o]], v[%[d]]\n\t"
-                     "v_accvgpr_write_b32 a[%[o]+1], v[%[d]+1]"
+                     "v_cvt_f32_i32 v[%[d]+1], v[%[d]+1]"
                      :
-                     : [d] "n"(T8_A + 2 * k), [s] "n"(T8_W + k), [o] "n"(64 * LS + 16 * Q + 2 * k), [a0] "v"(a0), [a1] "v"(a1));
+                     : [d] "n"(CP8A + 2 * k), [s] "n"(CP8W + k), [a0] "v"(a0), [a1] "v"(a1));
     });
+    asm volatile("s_nop 0");
+    copy_sink16<64 * LS + 16 * Q, CP8A>(col);
 }
 template <int LS>
-__device__ __forceinline__ void top8_copy_step(const TopAddr& A, uint32_t sh0, uint32_t sh1)
+__device__ __forceinline__ void top8_copy_step(const TopAddr& A, uint32_t sh0, uint32_t sh1, uint32_t col)
 {
-    constexpr int SL = 128 + 32 * (LS & 1), BUF = 8192 * (LS & 1);
+    constexpr int SL = 128 + 32 * (LS & 1), BUF = STG_STRIDE * (LS & 1);
     {
         const uint32_t w0 = A.wa[0], w1 = A.wa[1], w2 = A.wa[2], w3 = A.wa[3];
         asm volatile("s_waitcnt vmcnt(%[wt])\n\t"
@@ -787,24 +809,22 @@ __device__ __forceinline__ void top8_copy_step(const TopAddr& A, uint32_t sh0, u
                      "ds_write_b128 %[w2], v[%[s]+8:%[s]+11] offset:%[b]\n\t"
                      "ds_write_b128 %[w3], v[%[s]+12:%[s]+15] offset:%[b]"
                      :
-                     : [s] "n"(SL), [b] "n"(BUF), [wt] "n"(LS < 3 ? 4 : 0), [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3)
+                     : [s] "n"(SL), [b] "n"(BUF), [wt] "n"(LS < CP8_LINES - 1 ? 4 : 0), [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3)
                      : "memory");
     }
-    if constexpr (LS + 2 <= 3) top8_copy_load<LS + 2>(A);
-    top8_copy_quarter<LS, 0>(A, sh0, sh1);
-    top8_copy_quarter<LS, 1>(A, sh0, sh1);
-    top8_copy_quarter<LS, 2>(A, sh0, sh1);
-    top8_copy_quarter<LS, 3>(A, sh0, sh1);
+    if constexpr (LS + 2 <= CP8_LINES - 1) top8_copy_load<LS + 2>(A);
+    top8_copy_quarter<LS, 0>(A, sh0, sh1, col);
+    top8_copy_quarter<LS, 1>(A, sh0, sh1, col);
+    top8_copy_quarter<LS, 2>(A, sh0, sh1, col);
+    top8_copy_quarter<LS, 3>(A, sh0, sh1, col);
 }
-__device__ __forceinline__ void op_top8_copy(const TopAddr& A, int lane)
+__device__ __forceinline__ void op_top8_copy(const TopAddr& A, int lane, uint32_t col)
 {
     top8_copy_load<0>(A);
-    top8_copy_load<1>(A);
+    if constexpr (CP8_LINES > 1) top8_copy_load<1>(A);
     const uint32_t sh0 = 16u * ((uint32_t)lane & 1u), sh1 = sh0 + 8u;
-    top8_copy_step<0>(A, sh0, sh1);
-    top8_copy_step<1>(A, sh0, sh1);
-    top8_copy_step<2>(A, sh0, sh1);
-    top8_copy_step<3>(A, sh0, sh1);
+    static_for<CP8_LINES>([&](auto Q) { top8_copy_step<decltype(Q)::value>(A, sh0, sh1, col); });
+    if constexpr (PR_LOGN == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 #endif
 
@@ -1587,12 +1607,12 @@ void PR_KERNEL_NAME(const DecodeParams P)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t r = ((uint32_t)lane >> 3) + 8u * (uint32_t)i, seg = (uint32_t)lane & 7u;
-        TA.wa[i] = 4u * LDS_S7 + r * 128u + ((seg + r + (r >> 3)) & 7u) * 16u;
+        TA.wa[i] = 4u * (PLOGN == 8 ? LDS_B8L : LDS_S7) + r * 128u + ((seg + r + (r >> 3)) & 7u) * 16u;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t r = (uint32_t)lane >> 1;
-        TA.ra[k] = 4u * LDS_S7 + r * 128u + (((uint32_t)k + r + (r >> 3)) & 7u) * 16u + (I8 ? 0u : 8u * L.p);  // (int8 rows: both lanes read the whole unit)
+        TA.ra[k] = 4u * (PLOGN == 8 ? LDS_B8L : LDS_S7) + r * 128u + (((uint32_t)k + r + (r >> 3)) & 7u) * 16u + (I8 ? 0u : 8u * L.p);  // (int8 rows: both lanes read the whole unit)
     }
 
     for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -1612,9 +1632,9 @@ void PR_KERNEL_NAME(const DecodeParams P)
                 TA.rp[i] = reinterpret_cast<const float*>(P.llr) + (size_t)rr * N + 4u * ((uint32_t)lane & 7u);
         }
 
-#if PR_LOGN == 9
-        if constexpr (I8) op_top8_copy(TA, lane);  // local stage 8 = the channel row
-        else op_top_copy(TA);
+#if PR_LOGN < 10
+        if constexpr (I8) op_top8_copy(TA, lane, lane16);  // the channel row = the top local stage
+        else op_top_copy(TA, lane16);
 #endif
         uint64_t nraw = prog[0];
         for (uint32_t pc = 0;; ++pc) {
@@ -1824,8 +1844,12 @@ void PR_KERNEL_NAME(const DecodeParams P)
         // ---- output: FastSscAvxFloat::decode :940-955 -------------------------------------------------------------------
         // this lane's half of the code word, local order: 16 words (N = 512: 8, the root's block is a stage-8 left block)
         uint32_t x[NWL];
+        if constexpr (PLOGN >= 9) {
 #pragma unroll
-        for (int i = 0; i < NWL; ++i) x[i] = lds[(PLOGN == 10 ? LDS_X : LDS_B8L) + i * 64 + lane];
+            for (int i = 0; i < NWL; ++i) x[i] = lds[(PLOGN == 10 ? LDS_X : LDS_B8L) + i * 64 + lane];
+        } else {  // (N = 256 / 128: the root's block is a register block -- 4 / 2 words)
+            static_for<NWL>([&](auto I) { x[decltype(I)::value] = rdu<RB(0, PLOGN - 1) + decltype(I)::value>(); });
+        }
         if (!P.systematic) {  // re-encode u = x G (butterfly_fip.cpp:15-63) in the local order: position distance 1 = local bit
                               // distance 1, 2 = the other lane, 2^k (k >= 2) = local distance 2^(k-1)
 #pragma unroll
@@ -1960,7 +1984,7 @@ hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned
 }
 
 #else
-// N = 512
+// N = 512 / 256 / 128
 template __global__ void PR_KERNEL_NAME<false, false, false>(const DecodeParams);
 template __global__ void PR_KERNEL_NAME<true, true, false>(const DecodeParams);
 template __global__ void PR_KERNEL_NAME<false, true, false>(const DecodeParams);
@@ -1968,7 +1992,7 @@ template __global__ void PR_KERNEL_NAME<false, false, true>(const DecodeParams);
 template __global__ void PR_KERNEL_NAME<true, true, true>(const DecodeParams);
 template __global__ void PR_KERNEL_NAME<false, true, true>(const DecodeParams);
 template <bool BIG>
-static void launch_sc_pair_n9_t(const DecodeParams& P, bool i8rows, unsigned grid, hipStream_t st)
+static void launch_sc_pair_small_t(const DecodeParams& P, bool i8rows, unsigned grid, hipStream_t st)
 {
     if (P.chr) hipLaunchKernelGGL((PR_KERNEL_NAME<true, true, BIG>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
     else if (i8rows) hipLaunchKernelGGL((PR_KERNEL_NAME<false, true, BIG>), dim3(grid), dim3(64), pair::LDS_WORDS * 4, st, P);
@@ -1977,8 +2001,8 @@ static void launch_sc_pair_n9_t(const DecodeParams& P, bool i8rows, unsigned gri
 hipError_t PR_LAUNCH_NAME(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st)
 {
     if (P.logN != (uint32_t)pair::PLOGN) return hipErrorInvalidValue;
-    if (big) launch_sc_pair_n9_t<true>(P, i8rows, grid, st);
-    else launch_sc_pair_n9_t<false>(P, i8rows, grid, st);
+    if (big) launch_sc_pair_small_t<true>(P, i8rows, grid, st);
+    else launch_sc_pair_small_t<false>(P, i8rows, grid, st);
     return hipGetLastError();
 }
 #endif

@@ -479,13 +479,17 @@ PAIR_CODES_512 = [(256, 0.0, "BB"), (200, 0.0, "BB"), (320, 1.0, "BB"), (88, 0.0
                   (128, 1.0, "BB"), (50, 0.0, "BB"), (450, 2.0, "BB"), (256, 0.0, "BE"), (224, 0.5, "BB")]
 
 
-@pytest.mark.parametrize("K,dsnr,kind", PAIR_CODES_512, ids=[f"K{k}_{c}_{d}" for k, d, c in PAIR_CODES_512])
-def test_pair_kernel_codes_n512(built_library, K, dsnr, kind):
-    """The same kernel at N = 512 (sc_pair_n9_kernel, round 4: the channel row is local stage 8 -- fetched into the AGPRs once per
-    codeword, int8 rows widened on the way --; whatever its lowering cannot express runs on sc_decode_kernel): rates and
-    constructions, AWGN / noise / tie rows with negative zeros, ragged batches, systematic and not, with and without a detector."""
+PAIR_SMALL = [(512, k, d, c) for k, d, c in PAIR_CODES_512] + [(256, 128, 0.0, "BB"), (256, 100, 1.0, "BB"), (256, 200, 0.0, "BE"), (256, 60, -1.0, "BB"),
+                                                               (256, 230, 2.0, "BB"), (128, 64, 0.0, "BB"), (128, 40, 1.0, "BE"), (128, 100, 0.0, "BB"), (128, 20, 0.0, "BB")]
+
+
+@pytest.mark.parametrize("N,K,dsnr,kind", PAIR_SMALL, ids=[f"N{n}_K{k}_{c}_{d}" for n, k, d, c in PAIR_SMALL])
+def test_pair_kernel_codes_small_blocks(built_library, N, K, dsnr, kind):
+    """The same kernel at N = 512 / 256 / 128 (sc_pair_n9 / n8 / n7_kernel, round 4: the channel row is local stage 8 / 7 / 6 -- fetched
+    once per codeword into the AGPRs / the LDS column / the registers, int8 rows widened on the way --; whatever its lowering cannot
+    express runs on sc_decode_kernel): rates and constructions, AWGN / noise / tie rows with negative zeros, ragged batches,
+    systematic and not, with and without a detector."""
     import pypolar_amd
-    N = 512
     rng = np.random.default_rng(K + int(10 * dsnr) + 11)
     frozen = np.asarray(pypolar_amd.frozen_bits(N, K, dsnr, kind), dtype=np.uint32)
     rows = 70
@@ -495,13 +499,13 @@ def test_pair_kernel_codes_n512(built_library, K, dsnr, kind):
     half = (rng.integers(-6, 7, (16, N)) / 2.0).astype(np.float32)
     half[half == 0] = -0.0
     llr = np.concatenate([awgn, noise, ties, half])
-    for systematic, det in ((True, 8), (False, 32), (True, 0)):
+    for systematic, det in ((True, 8), (False, 32 if K > 32 else 8), (True, 0)):
         e_out, e_ok, _ = ob.decode_batch(N, 1, frozen, det, llr, systematic, "float")
         d = pypolar_amd.PolarDecoder(N, 1, frozen, "float")
         d.setErrorDetection(det, "crc")
         d.setSystematic(systematic)
-        if (K, kind, dsnr) == (256, "BB", 0.0):
-            assert d.kernel_name(False) == "sc_pair_n9_kernel"
+        if (kind, dsnr) == ("BB", 0.0) and 2 * K == N:
+            assert d.kernel_name(False) == {512: "sc_pair_n9_kernel", 256: "sc_pair_n8_kernel", 128: "sc_pair_n7_kernel"}[N]
         for cnt in (len(llr), 1, 33):
             out, ok = d.decode_batch(llr[:cnt])
             assert np.array_equal(out, e_out[:cnt]), (K, dsnr, kind, systematic, det, cnt)
