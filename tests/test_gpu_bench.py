@@ -59,7 +59,8 @@ def test_default_line_carries_roofline_and_issue(built_library):
 # this round deliver at the same batch size on one MI355X (measured: cfg 3 36.3, cfg 2 394 -- 443 at 2^20 rows --, cfg 5 1.37,
 # cfg3_i8 27.8, cfg 4 46.2 M cw/s at these sizes); the best launch of three tries counts, the clock of a box varies by a few per cent.
 RATE_FLOORS = [("cfg3", 18, 33.0e6, "scl_lane_kernel"), ("cfg2", 18, 370.0e6, "sc_pair_kernel"), ("cfg5", 13, 1.25e6, "scl_lane_n12_l5_kernel"),
-               ("cfg3_i8", 18, 24.5e6, "scl_lane_char_kernel"), ("cfg4", 17, 42.0e6, "scl_lane_kernel"), ("n1024_l4", 18, 56.0e6, "scl_lane_n10_l2_kernel")]
+               ("cfg3_i8", 18, 24.5e6, "scl_lane_char_kernel"), ("cfg4", 17, 42.0e6, "scl_lane_kernel"), ("n1024_l4", 18, 56.0e6, "scl_lane_n10_l2_kernel"),
+               ("n512_sc", 20, 760.0e6, "sc_pair_n9_kernel")]
 
 
 @pytest.mark.parametrize("config,log2b,floor,kernel", RATE_FLOORS, ids=[c for c, _, _, _ in RATE_FLOORS])

@@ -743,7 +743,8 @@ def test_grid_of_block_lengths_list_sizes_and_rates(built_library, N):
     assert combos >= 20
 
 
-@pytest.mark.parametrize("N,L", [(64, 2), (256, 4), (1024, 8), (1024, 32), (4096, 8), (4096, 16)])
+@pytest.mark.parametrize("N,L", [(64, 2), (256, 4), (1024, 8), (1024, 32), (4096, 8), (4096, 16),
+                                 (128, 8), (512, 2), (512, 4), (512, 16), (1024, 4), (2048, 2), (2048, 4)])   # (round 4: the pair kernels below N = 1024 in front of the 2 / 4-lane list kernels)
 def test_mixed_decoder_grid(built_library, N, L):
     """AdaptiveFloat (SC first, list decoding for the rows the detector rejects) against the oracle at several sizes:
     rows near the SC failure threshold so that both branches are taken"""
