@@ -1197,7 +1197,10 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
     if (rc != PCD_OK) return rc;
     pcd_decoder* d = *out;
     // the sibling for small batches (see pcd_decoder::small): only where the main geometry packs codewords into waves
-    if ((d->has_pair || d->has_lane) && !PAMD_ENV("PCD_NO_SMALL")) {
+    // (not for the SC decoders of N <= 256: a lone wave of sc_pair_n8 / n7_kernel finishes its up to 32 codewords as fast as the sibling one --
+    //  tools/latency_small_n.py, us per call from device pointers, pair / sibling: N = 128 29 / 30, N = 256 36 / 37, N = 512 52 / 48)
+    const bool pair_is_quick = d->L <= 1 && d->has_pair && d->logN <= 8;
+    if ((d->has_pair || d->has_lane) && !pair_is_quick && !PAMD_ENV("PCD_NO_SMALL")) {
         pcd_decoder* sm = nullptr;
         if (create_decoder(block_length, list_size, frozen, n_frozen, type, device, true, &sm) == PCD_OK) {
             d->small = sm;
