@@ -1287,8 +1287,13 @@ static int create_decoder(size_t block_length, size_t list_size, const uint32_t*
         // Round 4: the same kernel under other geometries (scl_lane_geo.h) -- N = 512 / 2048 / 4096 and 16 / 32 lanes per codeword;
         // the default geometry keeps its rule, the others take every tree the lowering can express from 48 leaves on.
         const bool geo_default = d->logN == 10 && d->L > 4 && d->L <= 8;
+        // N = 256 / 512 (tools/lane_threshold_small_n.py, 2^18 rows, lane against path groups, M cw/s): the fixed cost of a pass is smaller --
+        // no or one level above stage 8 -- and the line sits lower: N = 256 L = 8: 16 leaves (K = 16) 237 / 284, 22 leaves (K = 32) 200 / 178,
+        // 9 leaves at rate 0.96 169 / 144; N = 512 L = 8: 23 leaves (K = 24) 113 / 158, 32 leaves (K = 48) 110 / 104, 17 leaves at rate 0.94
+        // 75.5 / 67.8; L = 2: the lane kernels win every one of those (N = 256 K = 16: 685 / 584).
+        const unsigned min_leaves = d->logN >= 10 ? 48u : (d->L <= 4 || 2u * d->K >= d->N) ? 0u : (d->logN == 9 ? 28u : 20u);
         if (!small && !geo_default && pamd::find_lane_kernel(d->logN, d->L, chr, false) && !PAMD_ENV("PCD_NO_LANE") &&
-            (d->scl_prog.leaves >= 48u || PAMD_ENV("PCD_FORCE_LANE"))) {
+            (d->scl_prog.leaves >= min_leaves || PAMD_ENV("PCD_FORCE_LANE"))) {
             bool big = false, hi = false;
             if (pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr, &big, &hi)) {
                 if (const pamd::LaneKernel* lk = pamd::find_lane_kernel(d->logN, d->L, chr, hi)) {

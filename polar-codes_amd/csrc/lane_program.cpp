@@ -12,7 +12,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
     out.leaves = scl.leaves;
     out.inner = scl.inner;
     if (needs_big) *needs_big = false;
-    if (logN < 9 || logN > 12) return false;
+    if (logN < 8 || logN > 12) return false;
     const std::vector<Ins>& v = scl.ins;
     auto put = [&](Op op, unsigned stage, unsigned side, unsigned off) {
         Ins i;
@@ -41,6 +41,10 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
         case SCL_F:
         case SCL_G: {
             const bool isg = x.op == SCL_G;
+            if (logN == 8 && x.stage == 8 && !isg) {  // N = 256: stage 8 is the channel row -- the first pass copies it into the arena column of the
+                put(LN_VT, 8, x.side, 0);             // one live path and does this F; the root's G is an ordinary G of stage 8
+                continue;
+            }
             if (logN != 10 && x.stage >= 9) {
                 // N = 512 / 2048 / 4096: every stage above 8 is virtual -- the op of stage 9 becomes ONE pass over the channel row
                 // that recomputes the stages in between (op_vtg); off bit l = the op at stage logN - l is a G
@@ -90,6 +94,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
             put(LN_C, x.stage, x.side, 0);
             break;
         case SCL_R0:
+            if (logN == 8 && x.stage >= 8) return false;  // (N = 256: a leaf that is the whole code)
             if (high_leaf(x)) {
                 put(LN_R0, x.stage, x.side, high_gm(x.stage));
                 if (needs_hi) *needs_hi = true;
@@ -99,6 +104,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
             put(LN_R0, x.stage, x.side, 0);
             break;
         case SCL_R1:
+            if (logN == 8 && x.stage >= 8) return false;
             if (high_leaf(x)) {
                 put(LN_R1, x.stage, x.side, high_gm(x.stage));
                 if (needs_hi) *needs_hi = true;
@@ -109,6 +115,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
             put(LN_R1, x.stage, x.side, 0);
             break;
         case SCL_SPC:
+            if (logN == 8 && x.stage >= 8) return false;
             if (high_leaf(x)) {
                 put(LN_SPC, x.stage, x.side, high_gm(x.stage));
                 if (needs_hi) *needs_hi = true;
@@ -119,6 +126,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
             put(LN_SPC, x.stage, x.side, 0);
             break;
         case SCL_REP:
+            if (logN == 8 && x.stage >= 8) return false;
             if (chr && high_leaf(x)) {
                 put(LN_REP, x.stage, x.side, high_gm(x.stage));
                 if (needs_hi) *needs_hi = true;

@@ -139,7 +139,7 @@ constexpr uint32_t AR_WORDS = AR_DUMP + 16 * 64 * 4;
 // the path -- computed once per codeword by the first pass, every later top-of-tree pass whose upper levels are f's starts
 // from the highest one it can use instead of the channel row.  Per codeword: stage LOGN - 1 first, then LOGN - 2, ...
 constexpr uint32_t AR_VROW = AR_DUMP + 16 * 64 * 4;
-constexpr uint32_t VROW_FLOATS = (1u << LOGN) - 512u;
+constexpr uint32_t VROW_FLOATS = LOGN >= 9 ? (1u << LOGN) - 512u : 0u;  // (N = 256: stage 8 is the channel row, nothing above it)
 __host__ __device__ constexpr uint32_t vrow_off(int t) { return (1u << LOGN) - (2u << t); }  // (floats in front of stage t's row)
 constexpr uint32_t AR_WORDS = AR_VROW + (uint32_t)CPW * VROW_FLOATS;
 #endif
@@ -3102,13 +3102,21 @@ void scl_lane_kernel(const DecodeParams P)
                     for (uint32_t i = 0; i < XW; ++i) {
                         const uint32_t wi = XW * cc + i;
                         uint32_t x;
-                        if constexpr (NCK == 1) x = i < NWH ? (lp[i * 64] ^ rp[i * 64]) : rp[(i - NWH) * 64];
+                        if constexpr (LOGN == 8) x = 0;  // (N = 256: the root's children are stage-7 blocks -- registers, below)
+                        else if constexpr (NCK == 1) x = i < NWH ? (lp[i * 64] ^ rp[i * 64]) : rp[(i - NWH) * 64];
                         else x = lefthalf ? (lp[wi * 64] ^ rp[wi * 64]) : rp[(wi - NWH) * 64];
                         xw[i] = first ? x : (xw[i] ^ x);
                         if ((i & 7u) == 7u) asm volatile("" ::: "memory");  // (eight words at a time: not 64 loads in flight and their registers)
                     }
                 };
                 load_round(ck, true);
+                if constexpr (LOGN == 8) {  // left child's words from the lane that holds them (as COMBINE at stage 8 would), right child's are own
+                    const uint32_t ho = p.owner(8) << 2;
+                    const uint32_t l0 = rd_lane<RBL7>(ho), l1 = rd_lane<RBL7 + 1>(ho), l2 = rd_lane<RBL7 + 2>(ho), l3 = rd_lane<RBL7 + 3>(ho);
+                    const uint32_t r0 = rdu<RBR7>(), r1 = rdu<RBR7 + 1>(), r2 = rdu<RBR7 + 2>(), r3 = rdu<RBR7 + 3>();
+                    xw[0] = l0 ^ r0; xw[1] = l1 ^ r1; xw[2] = l2 ^ r2; xw[3] = l3 ^ r3;
+                    xw[4 % XW] = r0; xw[5 % XW] = r1; xw[6 % XW] = r2; xw[7 % XW] = r3;
+                }
                 if (!P.systematic) {  // re-encode (:731-746): u = x G -- between the rounds, inside the words, between the words
 #pragma unroll 1
                     for (uint32_t cc = ck + 1; cc < NCK; ++cc)
