@@ -2475,6 +2475,28 @@ __device__ __forceinline__ void op_vtg_first(Path& p, const RowT* chan, uint32_t
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
+#if LN_LOGN == 7
+// N = 128: the channel row IS stage 7.  The one live path sits in the first lane of its codeword; the LC lanes of the codeword fetch the
+// row's 32 chunks between them (all loads in flight at once) and write them into that lane's LDS column, where the F of the root finds
+// them -- and, through the slot word every path inherits, the root's G.
+template <bool CH>
+__device__ __forceinline__ void op_copy7(Path& p, const RowT* chan)
+{
+    constexpr int NC = 32 / LC;  // chunks per lane
+    const RowT* rp = chan + 4 * p.q;
+    uint32_t col = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u + (uint32_t)p.q * 1024u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<NC>([&](auto I) { vtg_load<128 + 4 * decltype(I)::value, 0>(rp + 4 * LC * decltype(I)::value); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<NC>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        vtg_widen<128 + 4 * i, 0, RowT>();
+        const uint32_t cc = col;  // (a copy: the asm operands of a generic lambda do not capture)
+        asm volatile("s_nop 0\n\tds_write_b128 %[c], v[%[r]:%[r]+3] offset:%[o]" ::[c] "v"(cc), [r] "n"(128 + 4 * i), [o] "n"(4 * LDS_S7 + 1024 * LC * i) : "memory");
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+#else
 // off: bit l = level l (0 = the channel row's own f / g, i.e. the op of the root) is a g
 template <bool CH>
 __device__ __forceinline__ void op_vtg(Path& p, uint32_t off, const RowT* chan, uint32_t absmask, uint32_t signmask)
@@ -2498,6 +2520,7 @@ __device__ __forceinline__ void op_vtg(Path& p, uint32_t off, const RowT* chan, 
     default: op_vtg_t<LOGN, CH, RowT>(p, gm, chan, absmask, signmask); break;
     }
 }
+#endif
 #if LN_LOGN >= 11 && LN_HILEAF
 // RateOneDecoder / SpcDecoder (scl_avx_float.cpp:353-413, 498-621) on a block of 512 / 1024 LLRs (rates above 1/2 at N >= 2048), first
 // half: the pass recomputes the block chunk by chunk; the sink collects the hard decisions -- a word per eight steps, written to
@@ -2851,6 +2874,8 @@ void scl_lane_kernel(const DecodeParams P)
 #if LN_LOGN == 10
                 if (!(DIAG && (P.ablate & 1u))) op_vt<CH>(p, off, chan, absmask, signmask);
                 if (DIAG && (P.ablate & 1024u)) op_vt<CH>(p, off, chan, absmask, signmask);  // (idempotent: costed by doing it twice)
+#elif LN_LOGN == 7
+                op_copy7<CH>(p, chan);
 #else
                 if (!(DIAG && (P.ablate & 1u))) op_vtg<CH>(p, off, chan, absmask, signmask);
 #endif
@@ -3087,8 +3112,8 @@ void scl_lane_kernel(const DecodeParams P)
             constexpr uint32_t NCK = NWT / XW, NWH = NWT / 2u;
             uint32_t ln = (uint32_t)lane;
             asm volatile("" : "+v"(ln));  // (opaque: see op_combine)
-            const uint32_t* lp0 = p.arena + AR_BL(LOGN - 1) + p.owner(LOGN);
-            const uint32_t* rp0 = p.arena + AR_BR(LOGN - 1) + ln;
+            const uint32_t* lp0 = p.arena + AR_BL(LOGN >= 9 ? LOGN - 1 : 8) + (LOGN >= 9 ? p.owner(LOGN) : 0u);
+            const uint32_t* rp0 = p.arena + AR_BR(LOGN >= 9 ? LOGN - 1 : 8) + ln;
             const uint32_t* ext = P.ext;
             uint64_t acc = 0;
 #pragma unroll 1
@@ -3102,7 +3127,7 @@ void scl_lane_kernel(const DecodeParams P)
                     for (uint32_t i = 0; i < XW; ++i) {
                         const uint32_t wi = XW * cc + i;
                         uint32_t x;
-                        if constexpr (LOGN == 8) x = 0;  // (N = 256: the root's children are stage-7 blocks -- registers, below)
+                        if constexpr (LOGN <= 8) x = 0;  // (N = 256 / 128: the root's children are stage-7 / 6 blocks -- registers, below)
                         else if constexpr (NCK == 1) x = i < NWH ? (lp[i * 64] ^ rp[i * 64]) : rp[(i - NWH) * 64];
                         else x = lefthalf ? (lp[wi * 64] ^ rp[wi * 64]) : rp[(wi - NWH) * 64];
                         xw[i] = first ? x : (xw[i] ^ x);
@@ -3116,6 +3141,11 @@ void scl_lane_kernel(const DecodeParams P)
                     const uint32_t r0 = rdu<RBR7>(), r1 = rdu<RBR7 + 1>(), r2 = rdu<RBR7 + 2>(), r3 = rdu<RBR7 + 3>();
                     xw[0] = l0 ^ r0; xw[1] = l1 ^ r1; xw[2] = l2 ^ r2; xw[3] = l3 ^ r3;
                     xw[4 % XW] = r0; xw[5 % XW] = r1; xw[6 % XW] = r2; xw[7 % XW] = r3;
+                }
+                if constexpr (LOGN == 7) {
+                    const uint32_t ho = p.owner(7) << 2;
+                    const uint32_t l0 = rd_lane<RBL6>(ho), l1 = rd_lane<RBL6 + 1>(ho), r0 = rdu<RBR6>(), r1 = rdu<RBR6 + 1>();
+                    xw[0] = l0 ^ r0; xw[1] = l1 ^ r1; xw[2 % XW] = r0; xw[3 % XW] = r1;
                 }
                 if (!P.systematic) {  // re-encode (:731-746): u = x G -- between the rounds, inside the words, between the words
 #pragma unroll 1

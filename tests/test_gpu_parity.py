@@ -345,7 +345,9 @@ LANE_GEO_CODES = [(512, 256, 8, "BB"), (512, 128, 6, "BB"), (512, 256, 16, "BB")
                   (2048, 1024, 2, "BB"), (2048, 1024, 4, "BB"), (2048, 300, 3, "BB"), (2048, 1800, 2, "BE"), (4096, 2048, 4, "BB"), (4096, 3000, 3, "BB"),
                   (4096, 700, 4, "BE"),
                   # N = 256: stage 8 is the channel row (no top-of-tree pass; the root's children are register blocks)
-                  (256, 128, 8, "BB"), (256, 128, 2, "BB"), (256, 100, 3, "BE"), (256, 64, 16, "BB"), (256, 200, 32, "BB"), (256, 128, 5, "rand"), (256, 230, 8, "BB")]
+                  (256, 128, 8, "BB"), (256, 128, 2, "BB"), (256, 100, 3, "BE"), (256, 64, 16, "BB"), (256, 200, 32, "BB"), (256, 128, 5, "rand"), (256, 230, 8, "BB"),
+                  # N = 128: stage 7 (the LDS column of the first path) is the channel row
+                  (128, 64, 8, "BB"), (128, 64, 2, "BB"), (128, 50, 4, "BE"), (128, 32, 16, "BB"), (128, 100, 32, "BB"), (128, 64, 7, "rand"), (128, 8, 8, "BB")]
 
 
 @pytest.mark.parametrize("N,K,L,kind", LANE_GEO_CODES, ids=[f"N{n}_K{k}_L{l}_{c}" for n, k, l, c in LANE_GEO_CODES])
@@ -383,7 +385,8 @@ def test_lane_kernel_geometries(built_library, N, K, L, kind):
 LANE_GEO_CHAR_CODES = [(512, 200, 32), (1024, 512, 16), (1024, 512, 32), (2048, 1024, 8), (2048, 1024, 16), (2048, 700, 32), (2048, 256, 8), (4096, 1024, 8),
                        (2048, 1800, 8), (4096, 3000, 8), (4096, 2560, 32), (2048, 256, 16),   # (leaves of 512 / 1024 LLRs, the repetition leaf included)
                        (512, 200, 2), (1024, 512, 4), (1024, 512, 2), (2048, 1024, 3), (2048, 256, 2), (4096, 2048, 4), (4096, 3000, 4),   # (2 / 4 lanes per codeword)
-                       (256, 128, 8), (256, 128, 2), (256, 200, 16), (256, 64, 32)]   # (N = 256)
+                       (256, 128, 8), (256, 128, 2), (256, 200, 16), (256, 64, 32),   # (N = 256)
+                       (128, 64, 8), (128, 64, 2), (128, 100, 16), (128, 32, 32)]   # (N = 128)
 
 
 @pytest.mark.parametrize("N,K,L", LANE_GEO_CHAR_CODES, ids=[f"N{n}_K{k}_L{l}" for n, k, l in LANE_GEO_CHAR_CODES])
