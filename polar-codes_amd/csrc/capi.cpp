@@ -1200,7 +1200,10 @@ int pcd_create(size_t block_length, size_t list_size, const uint32_t* frozen, si
     // (not for the SC decoders of N <= 256: a lone wave of sc_pair_n8 / n7_kernel finishes its up to 32 codewords as fast as the sibling one --
     //  tools/latency_small_n.py, us per call from device pointers, pair / sibling: N = 128 29 / 30, N = 256 36 / 37, N = 512 52 / 48)
     const bool pair_is_quick = d->L <= 1 && d->has_pair && d->logN <= 8;
-    if ((d->has_pair || d->has_lane) && !pair_is_quick && !PAMD_ENV("PCD_NO_SMALL")) {
+    // (nor for the list decoders on the 2 / 4-lane kernels and at N <= 256: L = 2, one row per call, lone lane wave / sibling: N = 128 48 / 58,
+    //  N = 256 73 / 89, N = 512 123 / 133, N = 1024 213 / 222 us; L = 8: N = 128 49 / 49, N = 256 72 / 73, N = 512 123 / 115, N = 1024 214 / 192)
+    const bool lane_is_quick = d->L > 1 && d->dectype != 2 && d->has_lane && d->lane_k && (d->lane_k->lcl <= 2 || d->logN <= 8);
+    if ((d->has_pair || d->has_lane) && !pair_is_quick && !lane_is_quick && !PAMD_ENV("PCD_NO_SMALL")) {
         pcd_decoder* sm = nullptr;
         if (create_decoder(block_length, list_size, frozen, n_frozen, type, device, true, &sm) == PCD_OK) {
             d->small = sm;

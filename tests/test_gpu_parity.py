@@ -926,6 +926,25 @@ def test_large_host_batch_goes_through_the_pinned_ring(built_library):
     assert np.array_equal(met.view(np.uint32), fq.metrics[idx].view(np.uint32))
 
 
+@pytest.mark.parametrize("N,L", [(128, 1), (256, 1), (128, 8), (256, 2), (1024, 4), (2048, 3)])
+def test_decoders_whose_lone_wave_is_quick_have_no_sibling(built_library, N, L):
+    """SC at N <= 256 (sc_pair_n7 / n8_kernel) and the list decoders on the 2 / 4-lane kernels or at N <= 256: a lone wave of the
+    throughput kernel answers a call of one row as fast as a one-codeword-per-wave sibling would (tools/latency_small_n.py), so there is
+    none -- pcd_small_batch_rows() is 0 -- and one row, a few rows and a ragged wave decode to the oracle's answers"""
+    import pypolar_amd
+    pypolar_amd.SMALL_BATCH_ROWS = None          # (the library's own routing)
+    frozen = np.asarray(pypolar_amd.frozen_bits(N, N // 2, 0.0, "BB"), dtype=np.uint32)
+    rng = np.random.default_rng(N + L)
+    llr = ((1.0 + 0.8 * rng.standard_normal((41, N))) * np.where(rng.random((41, N)) < 0.5, 1, -1)).astype(np.float32)
+    d = pypolar_amd.PolarDecoder(N, L, frozen, "float")
+    d.setErrorDetection(8, "crc")
+    assert d.small_batch_rows() == 0
+    e_out, e_ok, _ = ob.decode_batch(N, L, frozen, 8, llr, True, "float")
+    for rows in (1, 3, 33, 41):
+        out, ok = d.decode_batch(llr[:rows])
+        assert np.array_equal(out, e_out[:rows]) and np.array_equal(ok.astype(np.uint8), e_ok[:rows])
+
+
 @pytest.mark.parametrize("name", ["cfg2_n1024_k512_sc_awgn.bin", "cfg3_n1024_k512_l8_crc24_awgn.bin", "cfg4_n1024_k176_l8_crc11_awgn.bin",
                                   "mix_n1024_k512_l8_crc24_awgn.bin", "char_cfg3_n1024_k512_l8_crc24.bin", "cfg5_n4096_k2048_l32_crc32_awgn.bin"])
 def test_small_batches_take_the_low_latency_geometry_with_identical_results(built_library, name):
