@@ -1295,7 +1295,8 @@ static int create_decoder(size_t block_length, size_t list_size, const uint32_t*
         // 9 leaves at rate 0.96 169 / 144; N = 512 L = 8: 23 leaves (K = 24) 113 / 158, 32 leaves (K = 48) 110 / 104, 17 leaves at rate 0.94
         // 75.5 / 67.8; L = 2: the lane kernels win every one of those (N = 256 K = 16: 685 / 584).
         // N = 128: every tree (L = 8: K = 8 575 / 454, K = 64 272 / 217; L = 2: K = 64 1 096 / 705).
-        const unsigned min_leaves = d->logN >= 10 ? 48u : (d->logN == 7 || d->L <= 4 || 2u * d->K >= d->N) ? 0u : (d->logN == 9 ? 28u : 20u);
+        // (N = 64 likewise: L = 8 K = 32 430 / 331, K = 8 668 / 533; L = 2 K = 32 1 693 / 1 078)
+        const unsigned min_leaves = d->logN >= 10 ? 48u : (d->logN <= 7 || d->L <= 4 || 2u * d->K >= d->N) ? 0u : (d->logN == 9 ? 28u : 20u);
         if (!small && !geo_default && pamd::find_lane_kernel(d->logN, d->L, chr, false) && !PAMD_ENV("PCD_NO_LANE") &&
             (d->scl_prog.leaves >= min_leaves || PAMD_ENV("PCD_FORCE_LANE"))) {
             bool big = false, hi = false;

@@ -12,7 +12,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
     out.leaves = scl.leaves;
     out.inner = scl.inner;
     if (needs_big) *needs_big = false;
-    if (logN < 7 || logN > 12) return false;
+    if (logN < 6 || logN > 12) return false;
     const std::vector<Ins>& v = scl.ins;
     auto put = [&](Op op, unsigned stage, unsigned side, unsigned off) {
         Ins i;
@@ -45,7 +45,7 @@ bool lower_lane(unsigned logN, const Program& scl, Program& out, bool chr, bool*
                 put(LN_VT, 8, x.side, 0);             // one live path and does this F; the root's G is an ordinary G of stage 8
                 continue;
             }
-            if (logN == 7 && x.stage == 7 && !isg) put(LN_VT, 7, x.side, 0);  // N = 128: stage 7 is the channel row -- copied into the LDS column of the one live path; the F follows as an ordinary F
+            if (logN <= 7 && x.stage == logN && !isg) put(LN_VT, logN, x.side, 0);  // N = 128: stage 7 is the channel row -- copied into the LDS column of the one live path; the F follows as an ordinary F
             if (logN != 10 && x.stage >= 9) {
                 // N = 512 / 2048 / 4096: every stage above 8 is virtual -- the op of stage 9 becomes ONE pass over the channel row
                 // that recomputes the stages in between (op_vtg); off bit l = the op at stage logN - l is a G

@@ -8,10 +8,10 @@
 
 #define PAMD_LANE_GEOS(X) X(12, 5) X(10, 4) X(10, 5) X(11, 3) X(9, 3) X(9, 4) X(9, 5) X(11, 4) X(11, 5) X(12, 3) X(12, 4) \
     X(9, 1) X(9, 2) X(10, 1) X(10, 2) X(11, 1) X(11, 2) X(12, 2) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(8, 5) \
-    X(7, 1) X(7, 2) X(7, 3) X(7, 4) X(7, 5)
+    X(7, 1) X(7, 2) X(7, 3) X(7, 4) X(7, 5) X(6, 1) X(6, 2) X(6, 3) X(6, 4) X(6, 5)
 #define PAMD_LANE_GEOS_CHAR(Y) Y(9, 3) Y(9, 4) Y(9, 5) Y(10, 4) Y(10, 5) Y(11, 3) Y(11, 4) Y(11, 5) Y(12, 3) Y(12, 4) Y(12, 5) \
     Y(9, 1) Y(9, 2) Y(10, 1) Y(10, 2) Y(11, 1) Y(11, 2) Y(12, 2) Y(8, 1) Y(8, 2) Y(8, 3) Y(8, 4) Y(8, 5) \
-    Y(7, 1) Y(7, 2) Y(7, 3) Y(7, 4) Y(7, 5)
+    Y(7, 1) Y(7, 2) Y(7, 3) Y(7, 4) Y(7, 5) Y(6, 1) Y(6, 2) Y(6, 3) Y(6, 4) Y(6, 5)
 // N >= 2048 with an all-frozen leaf of 512 / 1024 LLRs in the tree (low rates): the same kernels with that leaf, as translation
 // units of their own (scl_lane_n<logN>_l<lcl>_hi.hip) -- the code it adds moved cfg 5 by 2.5 % when it sat in the one kernel
 #define PAMD_LANE_GEOS_HI(Z) Z(11, 3) Z(11, 4) Z(11, 5) Z(12, 3) Z(12, 4) Z(12, 5) Z(11, 1) Z(11, 2) Z(12, 2)

@@ -2475,7 +2475,35 @@ __device__ __forceinline__ void op_vtg_first(Path& p, const RowT* chan, uint32_t
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
-#if LN_LOGN == 7
+#if LN_LOGN == 6
+// N = 64: the channel row IS stage 6 -- a register block.  The lanes of a codeword fetch its 16 chunks between them and pass them through the LDS
+// column of the codeword's first lane; then EVERY lane reads the 16 chunks into its own v[190 .. 253]: the live path finds the row in its own
+// registers, and so does whoever later looks it up in the lane the inherited slot word names.
+template <bool CH>
+__device__ __forceinline__ void op_copy6(Path& p, const RowT* chan)
+{
+    constexpr int NC = LC >= 16 ? 1 : 16 / LC;  // chunks per lane (32 lanes: the first 16 fetch one each)
+    const RowT* rp = chan + 4 * (p.q & 15);
+    uint32_t col = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u + (uint32_t)(p.q & 15) * 1024u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<NC>([&](auto I) { vtg_load<128 + 4 * decltype(I)::value, 0>(rp + 4 * LC * decltype(I)::value); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<NC>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        vtg_widen<128 + 4 * i, 0, RowT>();
+        const uint32_t cc = col;  // (a copy: the asm operands of a generic lambda do not capture)
+        asm volatile("s_nop 0\n\tds_write_b128 %[c], v[%[r]:%[r]+3] offset:%[o]" ::[c] "v"(cc), [r] "n"(128 + 4 * i), [o] "n"(4 * LDS_S7 + 1024 * LC * i) : "memory");
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t src = (uint32_t)(uintptr_t)p.lds + (uint32_t)p.g0 * 16u;
+    static_for<16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const uint32_t ss = src;
+        asm volatile("ds_read_b128 v[%[r]:%[r]+3], %[a] offset:%[o]" ::[a] "v"(ss), [r] "n"(RS(6) + 4 * i), [o] "n"(4 * LDS_S7 + 1024 * i) : "memory");
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+#elif LN_LOGN == 7
 // N = 128: the channel row IS stage 7.  The one live path sits in the first lane of its codeword; the LC lanes of the codeword fetch the
 // row's 32 chunks between them (all loads in flight at once) and write them into that lane's LDS column, where the F of the root finds
 // them -- and, through the slot word every path inherits, the root's G.
@@ -2876,6 +2904,8 @@ void scl_lane_kernel(const DecodeParams P)
                 if (DIAG && (P.ablate & 1024u)) op_vt<CH>(p, off, chan, absmask, signmask);  // (idempotent: costed by doing it twice)
 #elif LN_LOGN == 7
                 op_copy7<CH>(p, chan);
+#elif LN_LOGN == 6
+                op_copy6<CH>(p, chan);
 #else
                 if (!(DIAG && (P.ablate & 1u))) op_vtg<CH>(p, off, chan, absmask, signmask);
 #endif
@@ -3141,6 +3171,10 @@ void scl_lane_kernel(const DecodeParams P)
                     const uint32_t r0 = rdu<RBR7>(), r1 = rdu<RBR7 + 1>(), r2 = rdu<RBR7 + 2>(), r3 = rdu<RBR7 + 3>();
                     xw[0] = l0 ^ r0; xw[1] = l1 ^ r1; xw[2] = l2 ^ r2; xw[3] = l3 ^ r3;
                     xw[4 % XW] = r0; xw[5 % XW] = r1; xw[6 % XW] = r2; xw[7 % XW] = r3;
+                }
+                if constexpr (LOGN == 6) {
+                    const uint32_t l0 = rd_lane<RBL0 + 5>(p.owner(6) << 2), r0 = rdu<RBR0 + 5>();
+                    xw[0] = l0 ^ r0; xw[1 % XW] = r0;
                 }
                 if constexpr (LOGN == 7) {
                     const uint32_t ho = p.owner(7) << 2;

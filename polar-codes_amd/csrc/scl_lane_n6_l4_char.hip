@@ -1,0 +1,11 @@
+// lane-per-path list kernel of the int8 decoder (SclFipChar), N = 64, up to 16 paths (4 codewords per wave): the channel row IS stage 6 (a register block, copied into every lane)
+#define LN_LOGN 6
+#define LN_LCL 4
+#ifndef LN_BIG
+#define LN_BIG 0
+#endif
+#define LN_CHAR 1
+#define LN_KERNEL_NAME scl_lane_n6_l4_char_kernel
+#define LN_LAUNCH_NAME launch_scl_lane_n6_l4_char
+#define LN_ARENA_NAME scl_lane_n6_l4_char_arena_words
+#include "scl_lane_kernel.hip"

@@ -347,7 +347,9 @@ LANE_GEO_CODES = [(512, 256, 8, "BB"), (512, 128, 6, "BB"), (512, 256, 16, "BB")
                   # N = 256: stage 8 is the channel row (no top-of-tree pass; the root's children are register blocks)
                   (256, 128, 8, "BB"), (256, 128, 2, "BB"), (256, 100, 3, "BE"), (256, 64, 16, "BB"), (256, 200, 32, "BB"), (256, 128, 5, "rand"), (256, 230, 8, "BB"),
                   # N = 128: stage 7 (the LDS column of the first path) is the channel row
-                  (128, 64, 8, "BB"), (128, 64, 2, "BB"), (128, 50, 4, "BE"), (128, 32, 16, "BB"), (128, 100, 32, "BB"), (128, 64, 7, "rand"), (128, 8, 8, "BB")]
+                  (128, 64, 8, "BB"), (128, 64, 2, "BB"), (128, 50, 4, "BE"), (128, 32, 16, "BB"), (128, 100, 32, "BB"), (128, 64, 7, "rand"), (128, 8, 8, "BB"),
+                  # N = 64: stage 6 (a register block, copied into every lane)
+                  (64, 32, 8, "BB"), (64, 32, 2, "BB"), (64, 24, 4, "BE"), (64, 16, 16, "BB"), (64, 50, 32, "BB"), (64, 32, 6, "rand")]
 
 
 @pytest.mark.parametrize("N,K,L,kind", LANE_GEO_CODES, ids=[f"N{n}_K{k}_L{l}_{c}" for n, k, l, c in LANE_GEO_CODES])
@@ -386,7 +388,8 @@ LANE_GEO_CHAR_CODES = [(512, 200, 32), (1024, 512, 16), (1024, 512, 32), (2048, 
                        (2048, 1800, 8), (4096, 3000, 8), (4096, 2560, 32), (2048, 256, 16),   # (leaves of 512 / 1024 LLRs, the repetition leaf included)
                        (512, 200, 2), (1024, 512, 4), (1024, 512, 2), (2048, 1024, 3), (2048, 256, 2), (4096, 2048, 4), (4096, 3000, 4),   # (2 / 4 lanes per codeword)
                        (256, 128, 8), (256, 128, 2), (256, 200, 16), (256, 64, 32),   # (N = 256)
-                       (128, 64, 8), (128, 64, 2), (128, 100, 16), (128, 32, 32)]   # (N = 128)
+                       (128, 64, 8), (128, 64, 2), (128, 100, 16), (128, 32, 32),   # (N = 128)
+                       (64, 32, 8), (64, 32, 2), (64, 48, 16), (64, 16, 32)]   # (N = 64)
 
 
 @pytest.mark.parametrize("N,K,L", LANE_GEO_CHAR_CODES, ids=[f"N{n}_K{k}_L{l}" for n, k, l in LANE_GEO_CHAR_CODES])
@@ -926,7 +929,7 @@ def test_large_host_batch_goes_through_the_pinned_ring(built_library):
     assert np.array_equal(met.view(np.uint32), fq.metrics[idx].view(np.uint32))
 
 
-@pytest.mark.parametrize("N,L", [(128, 1), (256, 1), (128, 8), (256, 2), (1024, 4), (2048, 3)])
+@pytest.mark.parametrize("N,L", [(128, 1), (256, 1), (128, 8), (256, 2), (1024, 4), (2048, 3), (64, 8)])
 def test_decoders_whose_lone_wave_is_quick_have_no_sibling(built_library, N, L):
     """SC at N <= 256 (sc_pair_n7 / n8_kernel) and the list decoders on the 2 / 4-lane kernels or at N <= 256: a lone wave of the
     throughput kernel answers a call of one row as fast as a one-codeword-per-wave sibling would (tools/latency_small_n.py), so there is

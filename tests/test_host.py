@@ -323,14 +323,15 @@ def test_sc_builder_refuses_the_sets_the_reference_refuses(built_library):
 
 @pytest.mark.parametrize("N,L,cw,groups", [
     (64, 1, 8, 1), (128, 1, 32, 1), (256, 1, 32, 1), (512, 1, 32, 1), (1024, 1, 32, 1), (4096, 1, 4, 1),       # SC: 8 lanes per codeword up to 64, 2 lanes at N = 128 ... 1024 (sc_pair_kernel)
-    (64, 2, 8, 16), (64, 4, 4, 16), (8192, 3, 2, 8),                                          # path groups: 4 lanes per path up to N = 2048 for L <= 4 (N < 128 and > 4096 only, since round 4)
+    (32, 2, 8, 16), (32, 4, 4, 16), (8192, 3, 2, 8),                                          # path groups: 4 lanes per path up to N = 2048 for L <= 4 (N < 64 and > 4096 only, since round 4)
+    (64, 2, 32, 64), (64, 8, 8, 64), (64, 16, 4, 64),                                          # N = 64: stage 6
     (256, 2, 32, 64), (256, 4, 16, 64), (256, 8, 8, 64), (256, 16, 4, 64),                     # N = 256 (round 4): stage 8 is the channel row
     (128, 2, 32, 64), (128, 8, 8, 64), (128, 32, 2, 64),                                       # N = 128: stage 7
     (1024, 8, 8, 64), (1024, 5, 8, 64),                                                       # lane-per-path kernel: N = 1024, 4 < L <= 8
     (512, 8, 8, 64), (2048, 8, 8, 64), (4096, 8, 8, 64),                                      # ... and, since round 4, N = 512 / 2048 / 4096
     (1024, 16, 4, 64), (1024, 32, 2, 64), (4096, 32, 2, 64), (2048, 12, 4, 64), (512, 24, 2, 64),  # ... with 16 / 32 lanes per codeword for L > 8
     (1024, 2, 32, 64), (1024, 4, 16, 64), (2048, 3, 16, 64), (512, 2, 32, 64), (4096, 4, 16, 64),  # ... and 2 / 4 lanes for L = 2 / 3 .. 4 (32 / 16 codewords per wave)
-    (4096, 2, 4, 8), (8192, 8, 1, 8), (8192, 16, 1, 16), (16384, 8, 1, 8), (64, 16, 1, 16)])  # 8 lanes / one codeword elsewhere (N = 4096 L = 2: 32 codewords of 16 KB per wave lose to the path groups)
+    (4096, 2, 4, 8), (8192, 8, 1, 8), (8192, 16, 1, 16), (16384, 8, 1, 8), (32, 16, 1, 16)])  # 8 lanes / one codeword elsewhere (N = 4096 L = 2: 32 codewords of 16 KB per wave lose to the path groups)
 def test_launch_geometry_choices(built_library, N, L, cw, groups):
     """codewords per wave and path groups per wave the host picks (capi.cpp, compute_geometry): the measured choices of
     DESIGN.md section 3 -- a change here is a performance change and should come with a sweep (tools/perf_sweep.py)"""
@@ -371,7 +372,8 @@ def test_lane_kernel_rule(built_library, dectype, K, kind, lane):
     (2048, 8, 72, "scl_lane_n11_l3_hi_kernel"),   # half of the code word frozen: an all-frozen leaf of 1024 LLRs at N = 2048
     (256, 8, 128, "scl_lane_n8_l3_kernel"), (256, 2, 16, "scl_lane_n8_l1_kernel"), (256, 32, 200, "scl_lane_n8_l5_kernel"), (512, 8, 480, "scl_lane_n9_l3_kernel"),
     (128, 8, 64, "scl_lane_n7_l3_kernel"), (128, 2, 8, "scl_lane_n7_l1_kernel"), (128, 20, 100, "scl_lane_n7_l5_kernel"),
-    (8192, 4, 4096, "scl_decode_kernel"), (8192, 8, 4096, "scl_decode_kernel"), (64, 8, 32, "scl_decode_kernel"),
+    (64, 8, 32, "scl_lane_n6_l3_kernel"), (64, 2, 8, "scl_lane_n6_l1_kernel"),
+    (8192, 4, 4096, "scl_decode_kernel"), (8192, 8, 4096, "scl_decode_kernel"), (32, 8, 16, "scl_decode_kernel"),
     (512, 8, 24, "scl_decode_kernel"), (256, 8, 16, "scl_decode_kernel")])      # low rates with few leaves (N <= 512: below 28 / 20 leaves; N >= 1024: below 48)
 def test_kernel_name_reports_the_side_of_the_geometry_rules(built_library, N, L, K, name):
     """pcd_kernel_name: which kernel a decoder's calls launch (csrc/scl_lane_geo.h lists the lane-per-path geometries) -- the

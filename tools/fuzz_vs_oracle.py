@@ -25,8 +25,8 @@ while time.time() < t_end:
         print(f"... {n_cfg} configurations, {n_rows} rows, {n_bad} mismatching", flush=True)
     logN = int(rng.integers(3, 16))
     L = int(rng.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 8, 11, 16, 24, 32]))
-    if os.environ.get("FUZZ_LANE") == "geo":  # the round-4 geometries of the lane-per-path kernel: N = 128 .. 4096, L = 2 .. 32
-        logN = int(rng.choice([7, 7, 8, 8, 9, 10, 10, 11, 11, 12]))
+    if os.environ.get("FUZZ_LANE") == "geo":  # the round-4 geometries of the lane-per-path kernel: N = 64 .. 4096, L = 2 .. 32
+        logN = int(rng.choice([6, 6, 7, 7, 8, 8, 9, 10, 10, 11, 11, 12]))
         L = int(rng.choice([2, 2, 3, 4, 4, 5, 7, 8, 8, 9, 12, 16, 16, 17, 24, 32, 32]))
     elif os.environ.get("FUZZ_LANE"):  # only what the lane-per-path list kernel of round 3 takes: N = 1024, 4 < L <= 8
         logN = 10
