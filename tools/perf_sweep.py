@@ -14,7 +14,7 @@ from pypolar_amd.construction import frozen_bits  # noqa: E402
 
 dev = torch.device("cuda", 0)
 print(f"{'N':>6} {'L':>3} {'rows':>8} {'kernel ms':>10} {'cw/s':>12} {'info Gbit/s':>12} {'LDS B/cw':>9}  kernel")
-NS = [int(x) for x in os.environ.get("SWEEP_N", "128,256,512,1024,2048,4096,16384").split(",")]
+NS = [int(x) for x in os.environ.get("SWEEP_N", "64,128,256,512,1024,2048,4096,16384").split(",")]
 LS = [int(x) for x in os.environ.get("SWEEP_L", "1,2,4,8,16,32").split(",")]
 for N in NS:
     for L in LS:
