@@ -243,6 +243,54 @@ def test_full_batch_properties(built_library, name, dectype, L, det, ebn0, lb):
         assert np.array_equal(k0.astype(bool) & good, good)
 
 
+FULL_BATCH_R4 = [
+    # N, K, decoder type, list size, detector bits, Eb/N0 dB, log2 batch -- the kernels of round 4 at batch sizes that take every wave through many groups
+    (128, 64, "float", 1, 0, 5.0, 20), (256, 128, "char", 1, 0, 5.0, 20), (512, 256, "float", 1, 8, 4.0, 20),      # sc_pair_n7 / n8 / n9_kernel
+    (64, 32, "char", 32, 8, 4.0, 16), (128, 64, "float", 8, 8, 4.0, 19), (256, 128, "float", 2, 8, 4.0, 20),          # lane kernels at N <= 256
+    (1024, 512, "float", 4, 8, 3.0, 18), (2048, 1024, "float", 2, 8, 3.0, 17), (512, 256, "char", 4, 8, 3.5, 18),     # 2 / 4 lanes per codeword
+]
+
+
+@pytest.mark.parametrize("N,K,dectype,L,det,ebn0,lb", FULL_BATCH_R4, ids=[f"N{n}_L{l}_{t}_2^{lb}" for n, _, t, l, _, _, lb in FULL_BATCH_R4])
+def test_full_batch_properties_of_the_round4_kernels(built_library, N, K, dectype, L, det, ebn0, lb):
+    """the same properties as above for the kernels that round 4 added (pair kernels at N <= 512, lane kernels at N <= 256 and with 2 / 4
+    lanes per codeword): every replica of a row decodes identically, decoded rows return their payload, a sample equals the oracle"""
+    import pypolar_amd
+    import torch
+    frozen = np.asarray(pypolar_amd.frozen_bits(N, K, 0.0, "BB"), dtype=np.uint32)
+    rng = np.random.default_rng(1234 + N + L)
+    U = 512
+    infos, bits = _systematic_codewords(N, frozen, det, U, rng)
+    sigma = 1.0 / np.sqrt(2.0 * 10 ** (ebn0 / 10.0) * K / N)
+    llr_u = (1.0 - 2.0 * bits + sigma * rng.normal(0, 1, bits.shape)).astype(np.float32)
+    if dectype == "char":
+        llr_u = np.clip(np.rint(llr_u * 16.0), -128, 127).astype(np.int8)
+    B = 1 << lb
+    x = torch.from_numpy(llr_u).to(torch.device("cuda:0")).repeat(B // U, 1)
+    d = pypolar_amd.PolarDecoder(N, L, frozen, dectype)
+    d.setErrorDetection(det, "crc")
+    assert d.kernel_name(L > 1).startswith("sc_pair_n" if L == 1 else "scl_lane_n"), d.kernel_name(L > 1)
+    res = d.decode_batch(x, return_metrics=L > 1)
+    torch.cuda.synchronize()
+    out = res[0].view(B // U, U, -1)
+    assert bool((out == out[0:1]).all()), "replicas of the same row decoded differently"
+    ok = res[1].view(B // U, U)
+    assert bool((ok == ok[0:1]).all())
+    if L > 1:
+        met = res[2].view(B // U, U, -1)
+        assert bool((met.view(torch.int32) == met[0:1].view(torch.int32)).all()), "replicas of the same row carry different metrics"
+    o0, k0 = out[0].cpu().numpy(), ok[0].cpu().numpy()
+    S = 64
+    e_out, e_ok, e_met = ob.decode_batch(N, L, frozen, det, llr_u[:S].astype(np.float32), True, dectype)
+    assert np.array_equal(o0[:S], e_out) and np.array_equal(k0[:S], e_ok)
+    if L > 1:
+        assert np.array_equal(res[2].view(B // U, U, -1)[0, :S].cpu().numpy().view(np.uint32), e_met.view(np.uint32))
+    good = (o0 == infos).all(axis=1)
+    assert good.mean() > 0.9, good.mean()
+    if det:
+        assert np.array_equal(k0.astype(bool) & good, good)
+
+
 def test_repeated_decodes_are_bit_identical(built_library):
     """the same 2^16 noisy rows decoded five times: bytes, verdicts and path metrics must not change from call to call (a
     counted wait that lets a load race its consumer shows up here as a handful of differing rows -- the split first pass
