@@ -29,11 +29,13 @@
 // with those leaves in the one kernel cfg 3 lost 3.8 %, as a template flag of the one source still 2 % (the lean kernel came out
 // with another register allocation); guarded by the preprocessor the lean kernel's token stream is what it was.
 // LN_CHAR (scl_lane_char.hip): the int8 decoder's instantiation (CH = true), a third translation unit for the same reason.
-// LN_LOGN / LN_LCL (scl_lane_geo.hip.inc and the scl_lane_n*_l*.hip stubs, round 4): the same source for other block lengths
-// (N = 2^LN_LOGN = 512 .. 4096) and list sizes (LC = 2^LN_LCL = 8 / 16 / 32 lanes per codeword, i.e. 8 / 4 / 2 codewords per
+// LN_LOGN / LN_LCL (scl_lane_geo.h and the scl_lane_n*_l*.hip stubs, round 4): the same source for other block lengths
+// (N = 2^LN_LOGN = 64 .. 4096) and list sizes (LC = 2^LN_LCL = 2 .. 32 lanes per codeword, i.e. 32 .. 2 codewords per
 // wave).  Whatever the block length, the tree from stage 8 down is the one described above; the stages between the channel
 // row and stage 8 are recomputed from the row by the top-of-tree pass (N = 1024: two levels, LN_VT; otherwise LOGN - 8
-// levels, op_vtg), their partial sums live in the arena.  With the defaults (10, 3) the token stream is what it was.
+// levels, op_vtg), their partial sums live in the arena.  N = 256 / 128 / 64: the row IS stage 8 / 7 / 6 -- copied once into the
+// column / registers of the one live path and found from there through the slot word every path inherits (op_vtg_first with zero
+// levels, op_copy7, op_copy6).  With the defaults (10, 3) the token stream is what it was.
 #ifndef LN_BIG
 #define LN_BIG 0
 #endif
