@@ -1296,12 +1296,19 @@ static int create_decoder(size_t block_length, size_t list_size, const uint32_t*
         // 75.5 / 67.8; L = 2: the lane kernels win every one of those (N = 256 K = 16: 685 / 584).
         // N = 128: every tree (L = 8: K = 8 575 / 454, K = 64 272 / 217; L = 2: K = 64 1 096 / 705).
         // (N = 64 likewise: L = 8 K = 32 430 / 331, K = 8 668 / 533; L = 2 K = 32 1 693 / 1 078)
-        const unsigned min_leaves = d->logN >= 10 ? 48u : (d->logN <= 7 || d->L <= 4 || 2u * d->K >= d->N) ? 0u : (d->logN == 9 ? 28u : 20u);
+        // N = 1024 with 2 / 4 lanes: K = 64 (44 leaves) L = 2 144 / 111 -- from 40 leaves.
+        const unsigned min_leaves = d->logN >= 10 ? ((d->logN == 10 && d->L <= 4) ? 40u : 48u)
+                                                  : (d->logN <= 7 || d->L <= 4 || 2u * d->K >= d->N) ? 0u : (d->logN == 9 ? 28u : 20u);
         if (!small && !geo_default && pamd::find_lane_kernel(d->logN, d->L, chr, false) && !PAMD_ENV("PCD_NO_LANE") &&
             (d->scl_prog.leaves >= min_leaves || PAMD_ENV("PCD_FORCE_LANE"))) {
             bool big = false, hi = false;
             if (pamd::lower_lane(d->logN, d->scl_prog, d->lane_prog, chr, &big, &hi)) {
-                if (const pamd::LaneKernel* lk = pamd::find_lane_kernel(d->logN, d->L, chr, hi)) {
+                const pamd::LaneKernel* lk = pamd::find_lane_kernel(d->logN, d->L, chr, hi);
+                // (the leaves above stage 8 are recomputed from the channel row, which 32 / 16 codewords per wave do not pay at the low rates:
+                //  N = 2048 L = 2 K = 128 38.6 / 47.0, K = 400 36.2 / 37.9, K = 512 35.8 / 32.2; N = 4096 L = 4 K = 256 13.6 / 15.2, K = 512
+                //  11.8 / 12.6, K = 1024 10.1 / 8.8 M cw/s lane / path groups)
+                if (lk && hi && 4u * d->K < d->N && (lk->lcl == 1 || (d->logN == 12 && lk->lcl == 2)) && !PAMD_ENV("PCD_FORCE_LANE")) lk = nullptr;
+                if (lk) {
                     d->has_lane = true;
                     d->lane_k = lk;
                     d->lane_cpw = 64u >> lk->lcl;

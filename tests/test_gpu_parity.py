@@ -391,7 +391,7 @@ LANE_GEO_CODES = [(512, 256, 8, "BB"), (512, 128, 6, "BB"), (512, 256, 16, "BB")
                   # 2 / 4 lanes per codeword (list sizes 2, 3 .. 4: 32 / 16 codewords per wave)
                   (512, 256, 2, "BB"), (512, 300, 4, "BE"), (1024, 512, 2, "BB"), (1024, 512, 4, "BB"), (1024, 700, 3, "BE"), (1024, 512, 4, "rand"),
                   (2048, 1024, 2, "BB"), (2048, 1024, 4, "BB"), (2048, 300, 3, "BB"), (2048, 1800, 2, "BE"), (4096, 2048, 4, "BB"), (4096, 3000, 3, "BB"),
-                  (4096, 700, 4, "BE"),
+                  (4096, 1100, 4, "BE"),
                   # N = 256: stage 8 is the channel row (no top-of-tree pass; the root's children are register blocks)
                   (256, 128, 8, "BB"), (256, 128, 2, "BB"), (256, 100, 3, "BE"), (256, 64, 16, "BB"), (256, 200, 32, "BB"), (256, 128, 5, "rand"), (256, 230, 8, "BB"),
                   # N = 128: stage 7 (the LDS column of the first path) is the channel row
@@ -434,7 +434,7 @@ def test_lane_kernel_geometries(built_library, N, K, L, kind):
 
 LANE_GEO_CHAR_CODES = [(512, 200, 32), (1024, 512, 16), (1024, 512, 32), (2048, 1024, 8), (2048, 1024, 16), (2048, 700, 32), (2048, 256, 8), (4096, 1024, 8),
                        (2048, 1800, 8), (4096, 3000, 8), (4096, 2560, 32), (2048, 256, 16),   # (leaves of 512 / 1024 LLRs, the repetition leaf included)
-                       (512, 200, 2), (1024, 512, 4), (1024, 512, 2), (2048, 1024, 3), (2048, 256, 2), (4096, 2048, 4), (4096, 3000, 4),   # (2 / 4 lanes per codeword)
+                       (512, 200, 2), (1024, 512, 4), (1024, 512, 2), (2048, 1024, 3), (2048, 600, 2), (4096, 2048, 4), (4096, 3000, 4),   # (2 / 4 lanes per codeword)
                        (256, 128, 8), (256, 128, 2), (256, 200, 16), (256, 64, 32),   # (N = 256)
                        (128, 64, 8), (128, 64, 2), (128, 100, 16), (128, 32, 32),   # (N = 128)
                        (64, 32, 8), (64, 32, 2), (64, 48, 16), (64, 16, 32)]   # (N = 64)

@@ -366,7 +366,8 @@ def test_lane_kernel_rule(built_library, dectype, K, kind, lane):
     (4096, 6, 2048, "scl_lane_n12_l3_kernel"), (4096, 16, 2048, "scl_lane_n12_l4_kernel"), (4096, 32, 2048, "scl_lane_n12_l5_kernel"),
     (512, 2, 256, "scl_lane_n9_l1_kernel"), (512, 4, 256, "scl_lane_n9_l2_kernel"), (1024, 2, 512, "scl_lane_n10_l1_kernel"), (1024, 3, 512, "scl_lane_n10_l2_kernel"),
     (2048, 2, 1024, "scl_lane_n11_l1_kernel"), (2048, 4, 1024, "scl_lane_n11_l2_kernel"), (4096, 4, 2048, "scl_lane_n12_l2_kernel"), (4096, 2, 2048, "scl_decode_kernel"),
-    (2048, 2, 256, "scl_lane_n11_l1_hi_kernel"), (4096, 3, 3000, "scl_lane_n12_l2_hi_kernel"),
+    (2048, 2, 1800, "scl_lane_n11_l1_hi_kernel"), (4096, 3, 3000, "scl_lane_n12_l2_hi_kernel"), (1024, 2, 64, "scl_lane_n10_l1_kernel"),
+    (2048, 2, 256, "scl_decode_kernel"), (4096, 4, 512, "scl_decode_kernel"),   # (leaves above stage 8 at a low rate with 32 / 16 codewords per wave: the path groups win)
     (4096, 32, 1024, "scl_lane_n12_l5_hi_kernel"), (2048, 8, 256, "scl_lane_n11_l3_hi_kernel"),   # low rates: an all-frozen leaf of 512 / 1024 LLRs
     (4096, 32, 3000, "scl_lane_n12_l5_hi_kernel"), (2048, 16, 1800, "scl_lane_n11_l4_hi_kernel"),   # high rates: RateOne / SPC leaves of 512 / 1024 LLRs
     (2048, 8, 72, "scl_lane_n11_l3_hi_kernel"),   # half of the code word frozen: an all-frozen leaf of 1024 LLRs at N = 2048

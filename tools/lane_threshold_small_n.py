@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 TYPE = os.environ.get("THR_TYPE", "float")
 N = int(os.environ.get("THR_N", "256"))
 KS = [int(k) for k in os.environ.get("THR_K", "16,32,48,64,200,230,245").split(",")]
-for L in (8, 2):
+for L in [int(l) for l in os.environ.get("THR_L", "8,2").split(",")]:
     for K in KS:
         fz = frozen_bits(N, K, 0.0, "BB")
         cfg = dict(N=N, K=K, L=L, dsnr=0.0, crc=8, crc_type="crc", ebn0=2.0)
