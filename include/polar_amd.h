@@ -105,7 +105,7 @@ int pcd_launch_info(const pcd_decoder* d, int list, unsigned info[4]);
 /* Name of the kernel (as rocprofv3 shows it, without namespace and template arguments) that decode calls of this decoder
    launch: list = 0 the SC program's, 1 the list program's.  Which side of a geometry rule a code fell on is visible here:
    "scl_lane_kernel" / "scl_lane_n12_l5_kernel" ... are the lane-per-path kernels, "scl_decode_kernel" the path-group ones,
-   "sc_pair_kernel" / "sc_pair_n9_kernel" / "sc_pair_n8_kernel" / "sc_pair_n7_kernel" (N = 1024 / 512 / 256 / 128) / "sc_decode_kernel" the SC decoders. */
+   "sc_pair_kernel" / "sc_pair_n9_kernel" / "sc_pair_n8_kernel" / "sc_pair_n7_kernel" / "sc_pair_n6_kernel" (N = 1024 / 512 / 256 / 128 / 64) / "sc_decode_kernel" the SC decoders. */
 int pcd_kernel_name(const pcd_decoder* d, int list, char* buf, size_t cap);
 /* Kernel timing with HIP events recorded on the launch stream around the kernel(s) of every decode call
  * (up to 512 calls after pcd_set_timing(d, 1), which also resets the list).  pcd_kernel_times waits for

@@ -766,6 +766,7 @@ int run_sc_pair(pcd_decoder* d, pamd::DecodeParams P, bool i8, hipStream_t st)
     if (d->logN == 9) HIP_TRY(pamd::launch_sc_pair_n9(P, i8, d->pair_big, grid, st));
     else if (d->logN == 8) HIP_TRY(pamd::launch_sc_pair_n8(P, i8, d->pair_big, grid, st));
     else if (d->logN == 7) HIP_TRY(pamd::launch_sc_pair_n7(P, i8, d->pair_big, grid, st));
+    else if (d->logN == 6) HIP_TRY(pamd::launch_sc_pair_n6(P, i8, d->pair_big, grid, st));
     else HIP_TRY(pamd::launch_sc_pair(P, i8, d->pair_big, grid, st));
     return PCD_OK;
 }
@@ -1510,7 +1511,7 @@ int pcd_kernel_name(const pcd_decoder* d, int list, char* buf, size_t cap)
             name = "scl_decode_kernel";
     } else {
         if (!d->has_sc) return fail(PCD_ERR_INVALID_ARG, "this decoder has no SC program");
-        name = d->has_pair ? (d->logN == 9 ? "sc_pair_n9_kernel" : d->logN == 8 ? "sc_pair_n8_kernel" : d->logN == 7 ? "sc_pair_n7_kernel" : "sc_pair_kernel") : "sc_decode_kernel";
+        name = d->has_pair ? (d->logN == 9 ? "sc_pair_n9_kernel" : d->logN == 8 ? "sc_pair_n8_kernel" : d->logN == 7 ? "sc_pair_n7_kernel" : d->logN == 6 ? "sc_pair_n6_kernel" : "sc_pair_kernel") : "sc_decode_kernel";
     }
     std::snprintf(buf, cap, "%s", name);
     return PCD_OK;

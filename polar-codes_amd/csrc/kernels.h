@@ -70,6 +70,7 @@ hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned
 hipError_t launch_sc_pair_n9(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
 hipError_t launch_sc_pair_n8(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
 hipError_t launch_sc_pair_n7(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
+hipError_t launch_sc_pair_n6(const DecodeParams& P, bool i8rows, bool big, unsigned grid, hipStream_t st);
 // CharContainer::insertLlr(const float*) (bitcontainer.cpp:449-516, N >= 8): round to nearest even, saturate to int8
 hipError_t launch_f32_to_i8(const float* in, int8_t* out, size_t n, hipStream_t st);
 hipError_t launch_collect_failed(const uint8_t* ok, uint32_t rows, uint32_t* list, uint32_t* count,

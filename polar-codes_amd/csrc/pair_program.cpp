@@ -11,7 +11,7 @@ bool lower_pair(unsigned logN, const Program& sc, Program& out, bool chr, bool* 
     out.inner = sc.inner;
     bool big = false;  // a leaf above 128 positions: the BIG instantiations of the kernel
     if (needs_big) *needs_big = false;
-    if (logN < 7 || logN > 10) return false;  // (N = 128 / 256 / 512: sc_pair_n7 / n8 / n9.hip)
+    if (logN < 6 || logN > 10) return false;  // (N = 64 / 128 / 256 / 512: sc_pair_n6 / n7 / n8 / n9.hip)
     auto put = [&](Op op, unsigned stage, unsigned side) {
         Ins i;
         i.op = (uint8_t)op;

@@ -554,7 +554,39 @@ __device__ __forceinline__ void op_top(const TopAddr& A, const uint32_t* lds, in
     });
 }
 
-#if PR_LOGN < 10
+#if PR_LOGN == 6
+// ---- N = 64: the channel row IS local stage 5 (32 values per lane in v[158 .. 189]).  A row is 256 (int8: 64) bytes: both lanes of a pair
+// load all of it (the same addresses: one fetch) into v[190 ..) and pick their pairs of positions -- no transposition through the LDS.
+__device__ __forceinline__ void op_row_copy6(const float* r, uint64_t oddmask)
+{
+    static_for<16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const float* rr = r;
+        asm volatile("global_load_dwordx4 v[%0:%0+3], %1, off offset:%2" ::"n"(190 + 4 * i), "v"(rr), "n"(16 * i) : "memory");
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<32>([&](auto J) {  // local j = the pair j >> 1 of this lane: positions 4 (j >> 1) + 2 p + (j & 1)
+        constexpr int j = decltype(J)::value;
+        constexpr int e0 = ((j >> 1) << 2) | (j & 1);
+        const uint64_t m = oddmask;
+        asm volatile("v_cndmask_b32_e64 v[%0], v[%1], v[%2], %3" ::"n"(RS(5) + j), "n"(190 + e0), "n"(190 + e0 + 2), "s"(m));
+    });
+}
+__device__ __forceinline__ void op_row8_copy6(const int8_t* r, uint32_t sh0, uint32_t sh1)
+{
+    static_for<4>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int8_t* rr = r;
+        asm volatile("global_load_dwordx4 v[%0:%0+3], %1, off offset:%2" ::"n"(190 + 4 * i), "v"(rr), "n"(16 * i) : "memory");
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<32>([&](auto J) {  // the dword j >> 1 holds four positions: this lane's two bytes at bit 16 p and 16 p + 8
+        constexpr int j = decltype(J)::value;
+        const uint32_t sh = (j & 1) ? sh1 : sh0;
+        asm volatile("v_bfe_i32 v[%0], v[%1], %2, 8\n\tv_cvt_f32_i32 v[%0], v[%0]" ::"n"(RS(5) + j), "n"(190 + (j >> 1)), "v"(sh));
+    });
+}
+#elif PR_LOGN < 10
 // ---- N = 512 / 256 / 128: the channel row IS local stage 8 / 7 / 6 -- it goes, line by line through the same transposition, into the
 // AGPRs / the lane's LDS column / v[190 ..) (the staging buffers of N = 256 sit in the rows of the stage-8 bits, which that length never uses)
 constexpr int CP_LINES = (4 << PR_LOGN) / 128;                       // 128-byte lines per fp32 row
@@ -755,7 +787,7 @@ __device__ __forceinline__ void op_top8(const TopAddr& A, const uint32_t* lds, i
     top8_step<SAT, KIND, 3>(A, sh0, sh1, w, absmask, signmask, S);
 }
 
-#if PR_LOGN < 10
+#if PR_LOGN < 10 && PR_LOGN > 6
 // ---- ... int8 rows (N bytes = 4 / 2 / 1 lines): the same, widened on the way ---------------------------------------------------------
 constexpr int CP8_LINES = (1 << PR_LOGN) / 128;
 template <int LS>
@@ -1632,7 +1664,10 @@ void PR_KERNEL_NAME(const DecodeParams P)
                 TA.rp[i] = reinterpret_cast<const float*>(P.llr) + (size_t)rr * N + 4u * ((uint32_t)lane & 7u);
         }
 
-#if PR_LOGN < 10
+#if PR_LOGN == 6
+        if constexpr (I8) op_row8_copy6(reinterpret_cast<const int8_t*>(P.llr) + (size_t)row * N, 16u * L.p, 16u * L.p + 8u);
+        else op_row_copy6(reinterpret_cast<const float*>(P.llr) + (size_t)row * N, 0xAAAAAAAAAAAAAAAAull);
+#elif PR_LOGN < 10
         if constexpr (I8) op_top8_copy(TA, lane, lane16);  // the channel row = the top local stage
         else op_top_copy(TA, lane16);
 #endif
@@ -1881,6 +1916,11 @@ void PR_KERNEL_NAME(const DecodeParams P)
                 v = (v | (v << 4)) & 0x0F0F0F0Fu;
                 return (v | (v << 2)) & 0x33333333u;
             };
+            if constexpr (NWL == 1) {  // (N = 64: lane p takes code word p = the half p of the one local word of both lanes)
+                const uint32_t recv = px(x[0]);
+                const uint32_t ev = odd ? recv : x[0], ov = odd ? x[0] : recv;
+                rw[0] = odd ? (spread(ev >> 16) | (spread(ov >> 16) << 2)) : (spread(ev & 0xFFFFu) | (spread(ov & 0xFFFFu) << 2));
+            }
 #pragma unroll
             for (int k = 0; k < NWL / 2; ++k) {
                 const uint32_t keep = odd ? x[NWL / 2 + k] : x[k], send = odd ? x[k] : x[NWL / 2 + k];
@@ -1984,7 +2024,7 @@ hipError_t launch_sc_pair(const DecodeParams& P, bool i8rows, bool big, unsigned
 }
 
 #else
-// N = 512 / 256 / 128
+// N = 512 / 256 / 128 / 64
 template __global__ void PR_KERNEL_NAME<false, false, false>(const DecodeParams);
 template __global__ void PR_KERNEL_NAME<true, true, false>(const DecodeParams);
 template __global__ void PR_KERNEL_NAME<false, true, false>(const DecodeParams);

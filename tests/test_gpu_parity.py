@@ -246,6 +246,7 @@ def test_full_batch_properties(built_library, name, dectype, L, det, ebn0, lb):
 FULL_BATCH_R4 = [
     # N, K, decoder type, list size, detector bits, Eb/N0 dB, log2 batch -- the kernels of round 4 at batch sizes that take every wave through many groups
     (128, 64, "float", 1, 0, 5.0, 20), (256, 128, "char", 1, 0, 5.0, 20), (512, 256, "float", 1, 8, 4.0, 20),      # sc_pair_n7 / n8 / n9_kernel
+    (64, 32, "float", 1, 0, 5.0, 20), (64, 32, "char", 1, 8, 5.0, 20),                                                # sc_pair_n6_kernel
     (64, 32, "char", 32, 8, 4.0, 16), (128, 64, "float", 8, 8, 4.0, 19), (256, 128, "float", 2, 8, 4.0, 20),          # lane kernels at N <= 256
     (1024, 512, "float", 4, 8, 3.0, 18), (2048, 1024, "float", 2, 8, 3.0, 17), (512, 256, "char", 4, 8, 3.5, 18),     # 2 / 4 lanes per codeword
 ]
@@ -537,12 +538,13 @@ PAIR_CODES_512 = [(256, 0.0, "BB"), (200, 0.0, "BB"), (320, 1.0, "BB"), (88, 0.0
 
 
 PAIR_SMALL = [(512, k, d, c) for k, d, c in PAIR_CODES_512] + [(256, 128, 0.0, "BB"), (256, 100, 1.0, "BB"), (256, 200, 0.0, "BE"), (256, 60, -1.0, "BB"),
-                                                               (256, 230, 2.0, "BB"), (128, 64, 0.0, "BB"), (128, 40, 1.0, "BE"), (128, 100, 0.0, "BB"), (128, 20, 0.0, "BB")]
+                                                               (256, 230, 2.0, "BB"), (128, 64, 0.0, "BB"), (128, 40, 1.0, "BE"), (128, 100, 0.0, "BB"), (128, 20, 0.0, "BB"),
+                                                               (64, 32, 0.0, "BB"), (64, 20, 1.0, "BE"), (64, 50, 0.0, "BB"), (64, 40, 2.0, "BB")]
 
 
 @pytest.mark.parametrize("N,K,dsnr,kind", PAIR_SMALL, ids=[f"N{n}_K{k}_{c}_{d}" for n, k, d, c in PAIR_SMALL])
 def test_pair_kernel_codes_small_blocks(built_library, N, K, dsnr, kind):
-    """The same kernel at N = 512 / 256 / 128 (sc_pair_n9 / n8 / n7_kernel, round 4: the channel row is local stage 8 / 7 / 6 -- fetched
+    """The same kernel at N = 512 / 256 / 128 / 64 (sc_pair_n9 / n8 / n7 / n6_kernel, round 4: the channel row is local stage 8 / 7 / 6 / 5 -- fetched
     once per codeword into the AGPRs / the LDS column / the registers, int8 rows widened on the way --; whatever its lowering cannot
     express runs on sc_decode_kernel): rates and constructions, AWGN / noise / tie rows with negative zeros, ragged batches,
     systematic and not, with and without a detector."""
@@ -562,7 +564,7 @@ def test_pair_kernel_codes_small_blocks(built_library, N, K, dsnr, kind):
         d.setErrorDetection(det, "crc")
         d.setSystematic(systematic)
         if (kind, dsnr) == ("BB", 0.0) and 2 * K == N:
-            assert d.kernel_name(False) == {512: "sc_pair_n9_kernel", 256: "sc_pair_n8_kernel", 128: "sc_pair_n7_kernel"}[N]
+            assert d.kernel_name(False) == {512: "sc_pair_n9_kernel", 256: "sc_pair_n8_kernel", 128: "sc_pair_n7_kernel", 64: "sc_pair_n6_kernel"}[N]
         for cnt in (len(llr), 1, 33):
             out, ok = d.decode_batch(llr[:cnt])
             assert np.array_equal(out, e_out[:cnt]), (K, dsnr, kind, systematic, det, cnt)
@@ -977,7 +979,7 @@ def test_large_host_batch_goes_through_the_pinned_ring(built_library):
     assert np.array_equal(met.view(np.uint32), fq.metrics[idx].view(np.uint32))
 
 
-@pytest.mark.parametrize("N,L", [(128, 1), (256, 1), (128, 8), (256, 2), (1024, 4), (2048, 3), (64, 8)])
+@pytest.mark.parametrize("N,L", [(64, 1), (128, 1), (256, 1), (128, 8), (256, 2), (1024, 4), (2048, 3), (64, 8)])
 def test_decoders_whose_lone_wave_is_quick_have_no_sibling(built_library, N, L):
     """SC at N <= 256 (sc_pair_n7 / n8_kernel) and the list decoders on the 2 / 4-lane kernels or at N <= 256: a lone wave of the
     throughput kernel answers a call of one row as fast as a one-codeword-per-wave sibling would (tools/latency_small_n.py), so there is

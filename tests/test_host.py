@@ -322,7 +322,7 @@ def test_sc_builder_refuses_the_sets_the_reference_refuses(built_library):
 
 
 @pytest.mark.parametrize("N,L,cw,groups", [
-    (64, 1, 8, 1), (128, 1, 32, 1), (256, 1, 32, 1), (512, 1, 32, 1), (1024, 1, 32, 1), (4096, 1, 4, 1),       # SC: 8 lanes per codeword up to 64, 2 lanes at N = 128 ... 1024 (sc_pair_kernel)
+    (32, 1, 8, 1), (64, 1, 32, 1), (128, 1, 32, 1), (256, 1, 32, 1), (512, 1, 32, 1), (1024, 1, 32, 1), (4096, 1, 4, 1),       # SC: 8 lanes per codeword up to 32, 2 lanes at N = 64 ... 1024 (sc_pair_kernel)
     (32, 2, 8, 16), (32, 4, 4, 16), (8192, 3, 2, 8),                                          # path groups: 4 lanes per path up to N = 2048 for L <= 4 (N < 64 and > 4096 only, since round 4)
     (64, 2, 32, 64), (64, 8, 8, 64), (64, 16, 4, 64),                                          # N = 64: stage 6
     (256, 2, 32, 64), (256, 4, 16, 64), (256, 8, 8, 64), (256, 16, 4, 64),                     # N = 256 (round 4): stage 8 is the channel row
@@ -342,7 +342,7 @@ def test_launch_geometry_choices(built_library, N, L, cw, groups):
     assert info["codewords_per_workgroup"] == cw, info
     assert info["path_groups"] == groups, info
     # the int8 SC decoder keeps 16 lanes per codeword (its reductions run over the 32 byte lanes of a 16-lane group)
-    if L == 1 and N <= 64:
+    if L == 1 and N <= 32:
         d8 = pypolar_amd.PolarDecoder(N, 1, frozen_bits(N, N // 2, 0.0, "BB"), "char")
         assert d8.launch_info(False)["codewords_per_workgroup"] == 4
 
@@ -389,6 +389,7 @@ def test_kernel_name_reports_the_side_of_the_geometry_rules(built_library, N, L,
     assert pypolar_amd.PolarDecoder(512, 1, frozen_bits(512, 256, 0.0, "BB"), "char").kernel_name(False) == "sc_pair_n9_kernel"
     assert pypolar_amd.PolarDecoder(256, 1, frozen_bits(256, 128, 0.0, "BB"), "float").kernel_name(False) == "sc_pair_n8_kernel"
     assert pypolar_amd.PolarDecoder(128, 1, frozen_bits(128, 64, 0.0, "BB"), "char").kernel_name(False) == "sc_pair_n7_kernel"
+    assert pypolar_amd.PolarDecoder(64, 1, frozen_bits(64, 32, 0.0, "BB"), "float").kernel_name(False) == "sc_pair_n6_kernel"
     assert pypolar_amd.PolarDecoder(2048, 1, frozen_bits(2048, 1024, 0.0, "BB"), "float").kernel_name(False) == "sc_decode_kernel"
     with pytest.raises(Exception):   # (PCD_ERR_INVALID_ARG: this decoder has no list program)
         sc.kernel_name(True)
@@ -396,7 +397,7 @@ def test_kernel_name_reports_the_side_of_the_geometry_rules(built_library, N, L,
 
 @pytest.mark.parametrize("dectype", ["float", "char"])
 def test_pair_kernel_takes_the_trees_it_can_express(built_library, dectype):
-    """host side of the two-lanes-per-codeword SC kernel (pair_program.cpp, lower_pair): N = 128 ... 1024, ROne nodes at every
+    """host side of the two-lanes-per-codeword SC kernel (pair_program.cpp, lower_pair): N = 64 ... 1024, ROne nodes at every
     stage, leaves up to 512 positions (above 128 in separate instantiations of the kernel, picked per decoder); whatever else
     a construction needs (a double-SPC leaf above 128 positions) keeps sc_decode_kernel -- no GPU needed:
     pcd_launch_info reports the geometry the host picked"""
@@ -411,9 +412,9 @@ def test_pair_kernel_takes_the_trees_it_can_express(built_library, dectype):
     assert on_pair >= 18, on_pair                                      # (20 constructions)
     for K in (512, 400, 640):                                           # the BASELINE code and its neighbours must be on it
         assert pypolar_amd.PolarDecoder(1024, 1, frozen_bits(1024, K, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] == 32
-    for N in (64, 2048):                                                # other block lengths: sc_decode_kernel
+    for N in (32, 2048):                                                # other block lengths: sc_decode_kernel
         assert pypolar_amd.PolarDecoder(N, 1, frozen_bits(N, N // 2, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] in (4, 8)
-    for N in (128, 256, 512):                                           # round 4: sc_pair_n7 / n8 / n9.hip
+    for N in (64, 128, 256, 512):                                       # round 4: sc_pair_n6 / n7 / n8 / n9.hip
         assert pypolar_amd.PolarDecoder(N, 1, frozen_bits(N, N // 2, 0.0, "BB"), dectype).launch_info(False)["codewords_per_workgroup"] == 32
 
 
@@ -432,7 +433,7 @@ def test_code_objects_keep_the_build_contracts(built_library):
     rows, problems = codeobj.analyse(pypolar_amd.library_path())
     assert not problems, "\n".join(problems)
     names = " ".join(r["kernel"] for r in rows)
-    for k in ("scl_lane_kernel", "scl_lane_char_kernel", "scl_lane_char_big_kernel", "scl_lane_big_kernel", "sc_pair_kernel", "sc_pair_n9_kernel", "sc_pair_n8_kernel", "sc_pair_n7_kernel", "sc_decode_kernel",
+    for k in ("scl_lane_kernel", "scl_lane_char_kernel", "scl_lane_char_big_kernel", "scl_lane_big_kernel", "sc_pair_kernel", "sc_pair_n9_kernel", "sc_pair_n8_kernel", "sc_pair_n7_kernel", "sc_pair_n6_kernel", "sc_decode_kernel",
               "scl_decode_kernel", "encode_kernel"):
         assert k in names, k   # (the check saw the kernels it is about)
     assert sum(r["long_branches"] for r in rows) > 0   # (... and long branches exist: the pattern match is alive)
