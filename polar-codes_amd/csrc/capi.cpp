@@ -1308,7 +1308,10 @@ static int create_decoder(size_t block_length, size_t list_size, const uint32_t*
                 // (the leaves above stage 8 are recomputed from the channel row, which 32 / 16 codewords per wave do not pay at the low rates:
                 //  N = 2048 L = 2 K = 128 38.6 / 47.0, K = 400 36.2 / 37.9, K = 512 35.8 / 32.2; N = 4096 L = 4 K = 256 13.6 / 15.2, K = 512
                 //  11.8 / 12.6, K = 1024 10.1 / 8.8 M cw/s lane / path groups)
-                if (lk && hi && 4u * d->K < d->N && (lk->lcl == 1 || (d->logN == 12 && lk->lcl == 2)) && !PAMD_ENV("PCD_FORCE_LANE")) lk = nullptr;
+                //  (... and at N = 4096 at rate 1/32 with any number of lanes: K = 128 L = 8 10.0 / 11.6, L = 32 2.9 / 3.1)
+                if (lk && hi && ((4u * d->K < d->N && (lk->lcl == 1 || (d->logN == 12 && lk->lcl == 2))) || (d->logN == 12 && 32u * d->K <= d->N)) &&
+                    !PAMD_ENV("PCD_FORCE_LANE"))
+                    lk = nullptr;
                 if (lk) {
                     d->has_lane = true;
                     d->lane_k = lk;
