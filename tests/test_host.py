@@ -5,6 +5,7 @@
   * argument checking / error mapping mirrors the reference (decoder.cpp:26-52, errordetector.cpp)
   * decoding without a GPU fails loudly (no CPU fallback)."""
 import ctypes as C
+import importlib.util
 import os
 import re
 
@@ -437,6 +438,18 @@ def test_code_objects_keep_the_build_contracts(built_library):
               "scl_decode_kernel", "encode_kernel"):
         assert k in names, k   # (the check saw the kernels it is about)
     assert sum(r["long_branches"] for r in rows) > 0   # (... and long branches exist: the pattern match is alive)
+
+
+def test_long_branch_check_tells_a_live_pair_from_a_reserved_one():
+    """the pattern match of tools/codeobj.py on two hand-made functions: a long branch through a pair nothing else touches passes, one through
+    a pair another instruction uses is flagged"""
+    spec = importlib.util.spec_from_file_location("codeobj", os.path.join(ROOT, "tools", "codeobj.py"))
+    codeobj = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(codeobj)
+    safe = ["s_getpc_b64 s[98:99]", "s_add_u32 s98, s98, 0x100", "s_addc_u32 s99, s99, 0", "s_setpc_b64 s[98:99]", "v_mov_b32_e32 v1, s4", "s_mov_b32 s5, 0"]
+    live = ["s_mov_b64 s[4:5], exec", "s_getpc_b64 s[4:5]", "s_add_u32 s4, s4, 0x100", "s_addc_u32 s5, s5, 0", "s_setpc_b64 s[4:5]", "s_and_b64 exec, exec, s[4:5]"]
+    assert codeobj.long_branch_report(safe) == [(0, (98, 99), True)]
+    assert codeobj.long_branch_report(live) == [(1, (4, 5), False)]
 
 
 def test_library_exports_only_the_c_abi(built_library):

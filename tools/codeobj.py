@@ -121,15 +121,23 @@ def long_branch_report(instrs):
                 member.update(range(i, j + 1))
                 break
     rep = []
-    for i, j, pair in seqs:
-        clean = True
-        for k, ins in enumerate(instrs):
-            if k in member:
-                continue
-            if sregs_of(ins) & set(pair):
-                clean = False
+    if not seqs:
+        return rep
+    # scalar registers used outside the long-branch sequences themselves (one pass over the function)
+    used = set()
+    wanted = set()
+    for _, _, pair in seqs:
+        wanted.update(pair)
+    for k, ins in enumerate(instrs):
+        if k in member or " s" not in ins and "\ts" not in ins and ",s" not in ins:
+            continue
+        r = sregs_of(ins) & wanted
+        if r:
+            used |= r
+            if used == wanted:
                 break
-        rep.append((i, pair, clean))
+    for i, j, pair in seqs:
+        rep.append((i, pair, not (used & set(pair))))
     return rep
 
 
@@ -139,13 +147,16 @@ HAND_ALLOCATED = ("scl_lane", "sc_pair_kernel")  # kernels that own v[104..255] 
 def analyse(lib):
     rows = []
     problems = []
+    from concurrent.futures import ThreadPoolExecutor
     with tempfile.TemporaryDirectory() as td:
-        for idx, data in code_objects(lib):
+        def load(item):  # (llvm-readelf / llvm-objdump per code object: subprocesses, so threads run them side by side)
+            idx, data = item
             p = os.path.join(td, "co%d.o" % idx)
             open(p, "wb").write(data)
-            notes = kernel_notes(p)
-            funcs = disassemble(p)
-            sizes = function_sizes(p)
+            return idx, kernel_notes(p), disassemble(p), function_sizes(p)
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+            loaded = list(pool.map(load, code_objects(lib)))
+        for idx, notes, funcs, sizes in loaded:
             for sym, d in notes.items():
                 name = d.get("name", sym).strip("'\"")
                 fn = sym[:-3] if sym.endswith(".kd") else sym
