@@ -69,6 +69,11 @@
 // N = 2048 / 4096: the two reductions in front of the merge network cost a lone wave more than the rarer exact-metric fix-ups /
 // tie emulations save (- 0.5 ... - 5 %).  (A variant that carried the scale from fork to fork instead of reducing it in front of
 // every network was exact and changed none of these numbers: the reductions are not what the map costs at N = 1024.)
+// LN_LINKEY_NOHI: ... measured from 0 instead of from the best metric of the codeword (one reduction less in front of the network, at most one
+// bit of resolution lost: metrics and span are of the same order once the list is full): cfg 5 1.489 -> 1.505 M cw/s, A/B on one box
+#ifndef LN_LINKEY_NOHI
+#define LN_LINKEY_NOHI 1
+#endif
 #ifndef LN_LINKEY
 #define LN_LINKEY (!LN_CHAR && LN_LCL == 5 && LN_LOGN >= 11)
 #endif
@@ -1158,10 +1163,18 @@ __device__ __forceinline__ void select_fork(Path& p, const float (&cm)[C], uint3
         bb = umin(fbits(cm[0]), fbits(cm[1]));
         bw = umax(fbits(cm[0]), fbits(cm[1]));
     }
+#if LN_LINKEY_NOHI
+    // (variant: distances from 0 instead of from the best metric -- one reduction less, at most one bit of resolution lost)
+    const uint32_t lou = cw_max(live ? (full ? bb : bw) : 0u);
+    const float hi = 0.0f;
+    const uint32_t er = umax((lou & 0x7FFFFFFFu) >> 23, 22u);
+    const float kscale = bitsf((276u - er) << 23);
+#else
     const uint32_t hiu = cw_min(live ? bb : INF), lou = cw_max(live ? (full ? bb : bw) : 0u);
     const float hi = bitsf(hiu);
     const uint32_t er = umax(fbits(hi - bitsf(lou)) >> 23, 22u);  // biased exponent of the span (clamped: a span of 0 still gives a finite scale)
     const float kscale = bitsf((276u - er) << 23);                 // 2^(22 - exponent): span * kscale in [2^22, 2^23)
+#endif
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         if (c < C) {
