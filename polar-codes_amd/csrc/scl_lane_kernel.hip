@@ -2830,9 +2830,9 @@ __device__ __forceinline__ void op_fg_reg(Path& p, uint32_t absmask, uint32_t si
 // =====================================================================================================================
 // CH: the int8 list decoder SclFipChar.  LN_I8ROWS: the channel rows are int8 and are widened in the top-of-tree pass (always
 // for CH; the float decoder called with int8 rows -- decode_vector(const char*) -- has its own translation units)
-#if !defined(LN_OPAQUE_LANE) && !LN_GEO_DEFAULT && (LN_LOGN == 10 || (LN_LOGN >= 11 && LN_LCL == 5 && !LN_HILEAF && !LN_CHAR))
-// (N = 1024 outside the default geometry: the arena and row pointers are enough -- no scratch, + 2.4 %, A/B on one box; 32 lanes
-//  at N = 2048 / 4096 without the leaves above stage 8: + 0.3 %, no scratch either)
+#if !defined(LN_OPAQUE_LANE) && !LN_GEO_DEFAULT && (LN_LOGN == 10 || (LN_LOGN >= 11 && !LN_HILEAF && !LN_CHAR))
+// (N = 1024 outside the default geometry: the arena and row pointers are enough -- no scratch, + 2.4 %, A/B on one box; the float kernels
+//  of N = 2048 / 4096 without the leaves above stage 8: + 0.3 ... 2 % at every number of lanes, no scratch either)
 #define LN_OPAQUE_LANE 3
 #endif
 template <bool DIAG, bool CH = false>
